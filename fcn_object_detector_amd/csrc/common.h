@@ -1,0 +1,48 @@
+// Internal helpers shared by the gfx950 kernels of libfcnhip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/fcnhip.h"
+
+namespace fcn {
+
+// thread-local error text behind fcn_last_error_string()
+char* err_buf();
+int set_err(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(fcn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define FCN_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return ::fcn::set_err(-(int)e__, "%s failed: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+#define FCN_LAUNCH_CHECK(name)                                                                \
+    do {                                                                                      \
+        hipError_t e__ = hipGetLastError();                                                   \
+        if (e__ != hipSuccess)                                                                \
+            return ::fcn::set_err(-(int)e__, "launch %s failed: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+#define FCN_REQUIRE(cond, code, ...)                         \
+    do {                                                     \
+        if (!(cond)) return ::fcn::set_err(code, __VA_ARGS__); \
+    } while (0)
+
+inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// grid for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, no more
+inline int stream_grid(long long work_items, int block) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 2048) g = 2048;
+    return (int)g;
+}
+
+}  // namespace fcn

@@ -1,0 +1,360 @@
+// DetectNet post-processing and target generation for gfx950 — integer / index work, bit-exact.
+//
+// (1) fcn_detect_decode_group: gridbox_to_boxes + vote_boxes -> cv.groupRectangles
+//     (reference: scripts/fcn_object_detector.py:337-394; OpenCV 3 objdetect
+//     groupRectangles()/partition()/SimilarRects, un-vendored — semantics restated in DESIGN.md).
+//     One workgroup per (image, class):
+//       a. threshold the coverage map and compact the positive cells in row-major order
+//          (wavefront ballot + popcount prefix, so candidate order == np.where order);
+//       b. candidate = (double)bbox + cell origin, converted to int like the Python->Rect converter;
+//       c. connected components of the SimilarRects relation with a lock-free union-find in LDS
+//          whose roots are always the smallest member index, so "classes numbered by first member"
+//          falls out as the ascending order of roots;
+//       d. integer sums per component (LDS atomics: exact and order-independent), float mean with
+//          round-half-even, the n <= groupThreshold and containment filters, the height filter of
+//          vote_boxes, and an ordered compaction of the survivors.
+// (2) fcn_gen_targets: ArgumentationEngine.bounding_box_parameterized_labels
+//     (reference: scripts/data_argumentation_layer/argumentation_engine.py:69-109 with
+//     JaccardCoeff.iou :26-55, generate_box_labels :272-278, grid_region :283-292).
+#include <math.h>
+
+#include "common.h"
+
+using namespace fcn;
+
+namespace {
+
+constexpr int kDetThreads = 1024;
+constexpr int kDetWaves = kDetThreads / 64;
+constexpr int kMaxCand = 4096;  // LDS capacity: parent + count + 4 sums = 6 * 16 KiB
+
+struct DetP {
+    fcn_detect_params p;
+    double eps;
+    const float* cvg;
+    const float* bbox;
+    size_t cvg_image_stride, box_image_stride;
+    int* ws;            // per problem: rects[4*G] + list[G]
+    int32_t* out_rects;
+    int32_t* out_weights;
+    int32_t* out_count;
+};
+
+__device__ __forceinline__ int round_coord(double v, int mode) {
+    double r = mode == FCN_RECT_ROUND_TRUNCATE ? trunc(v) : rint(v);  // rint: round-half-even (cvRound)
+    r = fmin(fmax(r, -2147483648.0), 2147483647.0);
+    return (int)r;
+}
+
+// exclusive prefix of `flag` over the workgroup in thread order; returns the total through *total
+__device__ __forceinline__ int block_excl_scan(bool flag, int* wsum /*[kDetWaves]*/, int* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const int within = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();  // previous users of wsum are done
+    if (lane == 0) wsum[wid] = __popcll(m);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kDetWaves; ++w) {
+        const int v = wsum[w];
+        if (w < wid) base += v;
+        tot += v;
+    }
+    *total = tot;
+    return base + within;
+}
+
+__device__ __forceinline__ int uf_find(const int* parent, int x) {
+    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return x;
+}
+
+// union keeping the smaller index as root
+__device__ __forceinline__ void uf_union(int* parent, int a, int b) {
+    while (true) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }  // a > b: hook a under b
+        const int old = atomicCAS(&parent[a], a, b);
+        if (old == a) return;
+    }
+}
+
+__global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
+    __shared__ int parent[kMaxCand];
+    __shared__ int cnt[kMaxCand];
+    __shared__ int sum[4][kMaxCand];
+    __shared__ int wsum[kDetWaves];
+    __shared__ int s_any;
+
+    const fcn_detect_params& P = d.p;
+    const int cls = blockIdx.x % P.num_classes;
+    const int img = blockIdx.x / P.num_classes;
+    const int G = P.gy * P.gx;
+    const int tid = threadIdx.x;
+    const float* cvg = d.cvg + (size_t)img * d.cvg_image_stride;
+    const float* box = d.bbox + (size_t)img * d.box_image_stride;
+    int* rects = d.ws + (size_t)blockIdx.x * 5 * G;  // [4][G] as x | y | w | h planes
+    int* list = rects + 4 * (size_t)G;               // compacted root / survivor lists
+    int32_t* o_rects = d.out_rects + (size_t)blockIdx.x * P.max_out * 4;
+    int32_t* o_w = d.out_weights + (size_t)blockIdx.x * P.max_out;
+
+    if (tid == 0) s_any = 0;
+
+    // ---- a+b: threshold, ordered compaction, candidate rectangles ----------------------------
+    int M = 0;
+    bool any_nonzero = false;
+    for (int base = 0; base < G; base += kDetThreads) {
+        const int cell = base + tid;
+        bool pos = false;
+        if (cell < G) pos = cvg[(size_t)cell * P.cvg_cstride + P.cvg_coffset + cls] >= P.prob_thresh;
+        int tot;
+        const int at = M + block_excl_scan(pos, wsum, &tot);
+        if (pos) {
+            const int y = cell / P.gx, x = cell - y * P.gx;
+            const float* b = box + (size_t)cell * P.box_cstride + P.box_coffset + 4 * cls;
+            const double x1 = (double)b[0] + (double)(x * P.cell_w);
+            const double y1 = (double)b[1] + (double)(y * P.cell_h);
+            const double x2 = (double)b[2] + (double)(x * P.cell_w);
+            const double y2 = (double)b[3] + (double)(y * P.cell_h);
+            any_nonzero |= (x1 != 0.0) | (y1 != 0.0) | (x2 != 0.0) | (y2 != 0.0);
+            rects[0 * G + at] = round_coord(x1, P.round_mode);
+            rects[1 * G + at] = round_coord(y1, P.round_mode);
+            rects[2 * G + at] = round_coord(x2, P.round_mode);  // read back as width  (reference passes x2)
+            rects[3 * G + at] = round_coord(y2, P.round_mode);  // read back as height (reference passes y2)
+        }
+        M += tot;
+    }
+    if (any_nonzero) atomicOr(&s_any, 1);
+    for (int i = tid; i < M; i += kDetThreads) {
+        parent[i] = i;
+        cnt[i] = 0;
+        sum[0][i] = sum[1][i] = sum[2][i] = sum[3][i] = 0;
+    }
+    __syncthreads();
+    // vote_boxes: `if not propose_boxes.any(): return []`
+    if (M == 0 || s_any == 0) {
+        if (tid == 0) d.out_count[blockIdx.x] = 0;
+        return;
+    }
+
+    // groupRectangles: groupThreshold <= 0 returns the input untouched with weight 1
+    if (P.group_thresh <= 0) {
+        int outn = 0;
+        for (int base = 0; base < M; base += kDetThreads) {
+            const int i = base + tid;
+            const bool keep = i < M && rects[3 * G + i] - rects[1 * G + i] >= P.min_height;
+            int tot;
+            const int at = outn + block_excl_scan(keep, wsum, &tot);
+            if (keep && at < P.max_out) {
+                o_rects[at * 4 + 0] = rects[0 * G + i];
+                o_rects[at * 4 + 1] = rects[1 * G + i];
+                o_rects[at * 4 + 2] = rects[2 * G + i];
+                o_rects[at * 4 + 3] = rects[3 * G + i];
+                o_w[at] = 1;
+            }
+            outn += tot;
+        }
+        if (tid == 0) d.out_count[blockIdx.x] = outn;
+        return;
+    }
+
+    // ---- c: partition(): union every SimilarRects pair ----------------------------------------
+    for (int i = 0; i < M; ++i) {
+        const int xi = rects[0 * G + i], yi = rects[1 * G + i], wi = rects[2 * G + i], hi = rects[3 * G + i];
+        for (int j = i + 1 + tid; j < M; j += kDetThreads) {
+            const int xj = rects[0 * G + j], yj = rects[1 * G + j], wj = rects[2 * G + j], hj = rects[3 * G + j];
+            const double delta = d.eps * (double)(min(wi, wj) + min(hi, hj)) * 0.5;
+            if ((double)abs(xi - xj) <= delta && (double)abs(yi - yj) <= delta && (double)abs(xi + wi - xj - wj) <= delta &&
+                (double)abs(yi + hi - yj - hj) <= delta)
+                uf_union(parent, i, j);
+        }
+    }
+    __syncthreads();
+
+    // ---- d: per-class integer sums -------------------------------------------------------------
+    for (int i = tid; i < M; i += kDetThreads) {
+        const int r = uf_find(parent, i);
+        atomicAdd(&sum[0][r], rects[0 * G + i]);
+        atomicAdd(&sum[1][r], rects[1 * G + i]);
+        atomicAdd(&sum[2][r], rects[2 * G + i]);
+        atomicAdd(&sum[3][r], rects[3 * G + i]);
+        atomicAdd(&cnt[r], 1);
+    }
+    __syncthreads();
+    // roots in ascending order == classes in partition()'s numbering
+    int nc = 0;
+    for (int base = 0; base < M; base += kDetThreads) {
+        const int i = base + tid;
+        const bool is_root = i < M && parent[i] == i;
+        int tot;
+        const int at = nc + block_excl_scan(is_root, wsum, &tot);
+        if (is_root) {
+            list[at] = i;
+            // mean = saturate_cast<int>(sum * (1.f / n)): float multiply, round-half-even
+            const float s = __fdiv_rn(1.f, (float)cnt[i]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = __fmul_rn((float)sum[k][i], s);
+                float r = rintf(v);
+                r = fminf(fmaxf(r, -2147483648.f), 2147483520.f);
+                sum[k][i] = (int)r;
+            }
+        }
+        nc += tot;
+    }
+    __syncthreads();
+
+    // filters + ordered emission
+    int outn = 0;
+    for (int base = 0; base < nc; base += kDetThreads) {
+        const int ci = base + tid;
+        bool keep = false;
+        int r1 = 0;
+        if (ci < nc) {
+            r1 = list[ci];
+            const int n1 = cnt[r1];
+            if (n1 > P.group_thresh) {
+                const int x1 = sum[0][r1], y1 = sum[1][r1], w1 = sum[2][r1], h1 = sum[3][r1];
+                keep = true;
+                for (int cj = 0; cj < nc; ++cj) {
+                    const int r2 = list[cj];
+                    const int n2 = cnt[r2];
+                    if (cj == ci || n2 <= P.group_thresh) continue;
+                    const int x2 = sum[0][r2], y2 = sum[1][r2], w2 = sum[2][r2], h2 = sum[3][r2];
+                    const int dx = round_coord((double)w2 * d.eps, FCN_RECT_ROUND_NEAREST_EVEN);
+                    const int dy = round_coord((double)h2 * d.eps, FCN_RECT_ROUND_NEAREST_EVEN);
+                    if (x1 >= x2 - dx && y1 >= y2 - dy && x1 + w1 <= x2 + w2 + dx && y1 + h1 <= y2 + h2 + dy &&
+                        (n2 > max(3, n1) || n1 < 3)) {
+                        keep = false;
+                        break;
+                    }
+                }
+                // vote_boxes: keep if rect[3] - rect[1] >= 20
+                if (keep && h1 - y1 < P.min_height) keep = false;
+            }
+        }
+        int tot;
+        const int at = outn + block_excl_scan(keep, wsum, &tot);
+        if (keep && at < P.max_out) {
+            o_rects[at * 4 + 0] = sum[0][r1];
+            o_rects[at * 4 + 1] = sum[1][r1];
+            o_rects[at * 4 + 2] = sum[2][r1];
+            o_rects[at * 4 + 3] = sum[3][r1];
+            o_w[at] = cnt[r1];
+        }
+        outn += tot;
+    }
+    if (tid == 0) d.out_count[blockIdx.x] = outn;
+}
+
+// ---------------------------------------------------------------------------------------------
+// target generation: one lane per (image, class, cell)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gen_targets_kernel(const int32_t* __restrict__ rects, const int32_t* __restrict__ labels,
+                                                          const int32_t* __restrict__ offs, int batch, int C, int gy, int gx, int stride,
+                                                          double iou_thresh, float* __restrict__ fg, float* __restrict__ bbox,
+                                                          float* __restrict__ size, float* __restrict__ obj, float* __restrict__ cvgb) {
+    const int G = gy * gx;
+    const long long total = (long long)batch * C * G;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int cell = (int)(t % G);
+        const int cls = (int)((t / G) % C);
+        const int img = (int)(t / ((long long)G * C));
+        const int j = cell / gx, i = cell - j * gx;
+        const int cx = i * stride, cy = j * stride;
+        int hit = -1;
+        for (int r = offs[img]; r < offs[img + 1]; ++r) {
+            if (labels[r] != cls) continue;
+            const int rx = rects[4 * r + 0], ry = rects[4 * r + 1], rw = rects[4 * r + 2], rh = rects[4 * r + 3];
+            // JaccardCoeff.iou(cell, rect) — argumentation_engine.py:26-55
+            const int ix = max(cx, rx), iy = max(cy, ry);
+            const int iw = min(cx + stride, rx + rw) - ix;
+            const int ih = min(cy + stride, ry + rh) - iy;
+            if (iw < 0 || ih < 0) continue;
+            const int ux = min(cx, rx), uy = min(cy, ry);
+            const int uw = max(cx + stride, rx + rw) - ux;
+            const int uh = max(cy + stride, ry + rh) - uy;
+            const float aub = (float)((double)uw * (double)uh);   // area of the bounding box of the union
+            const float anb = (float)((double)iw * (double)ih);
+            const float area_ratio = __fdiv_rn((float)((double)stride * (double)stride), (float)((double)rw * (double)rh));
+            float score = __fdiv_rn(anb, aub);
+            score = __fdiv_rn(score, area_ratio);
+            if ((double)score > iou_thresh) hit = r;  // later rects overwrite earlier ones
+        }
+        const size_t o4 = ((size_t)img * 4 * C + 4 * cls) * G + cell;
+        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, s0 = 0.f, s1 = 0.f, ob = 0.f, cv = 0.f;
+        if (hit >= 0) {
+            const int rx = rects[4 * hit + 0], ry = rects[4 * hit + 1], rw = rects[4 * hit + 2], rh = rects[4 * hit + 3];
+            b0 = (float)(rx - cx);
+            b1 = (float)(ry - cy);
+            b2 = (float)(rx + rw - cx);
+            b3 = (float)(ry + rh - cy);
+            s0 = (float)(1.0 / (double)rw);
+            s1 = (float)(1.0 / (double)rh);
+            ob = __fdiv_rn((float)((double)stride * (double)stride), (float)((double)rw * (double)rh));
+            cv = 1.f;
+        }
+        bbox[o4] = b0; bbox[o4 + G] = b1; bbox[o4 + 2 * (size_t)G] = b2; bbox[o4 + 3 * (size_t)G] = b3;
+        size[o4] = s0; size[o4 + G] = s1; size[o4 + 2 * (size_t)G] = s0; size[o4 + 3 * (size_t)G] = s1;
+        obj[o4] = ob; obj[o4 + G] = ob; obj[o4 + 2 * (size_t)G] = ob; obj[o4 + 3 * (size_t)G] = ob;
+        cvgb[o4] = cv; cvgb[o4 + G] = cv; cvgb[o4 + 2 * (size_t)G] = cv; cvgb[o4 + 3 * (size_t)G] = cv;
+        fg[((size_t)img * C + cls) * G + cell] = cv;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fcn_detect_workspace_bytes(const fcn_detect_params* h_p, int batch) {
+    if (!h_p || batch <= 0) return 0;
+    return (size_t)batch * h_p->num_classes * 5 * (size_t)h_p->gy * h_p->gx * sizeof(int32_t);
+}
+
+int fcn_detect_decode_group(const float* cvg, const float* bbox, int batch, size_t cvg_image_stride, size_t box_image_stride,
+                            const fcn_detect_params* h_p, void* d_workspace, int32_t* out_rects, int32_t* out_weights,
+                            int32_t* out_count, fcn_stream_t s) {
+    FCN_REQUIRE(cvg && bbox && h_p && d_workspace && out_rects && out_weights && out_count && batch > 0, FCN_E_ARG, "detect: null/empty");
+    const fcn_detect_params& P = *h_p;
+    FCN_REQUIRE(P.num_classes > 0 && P.gy > 0 && P.gx > 0 && P.max_out > 0, FCN_E_ARG, "detect: bad grid/classes/max_out");
+    FCN_REQUIRE((long long)P.gy * P.gx <= kMaxCand, FCN_E_UNSUPPORTED, "detect: grid %dx%d exceeds %d cells", P.gy, P.gx, kMaxCand);
+    FCN_REQUIRE(P.cvg_coffset >= 0 && P.cvg_cstride >= P.cvg_coffset + P.num_classes, FCN_E_ARG, "detect: coverage slice out of range");
+    FCN_REQUIRE(P.box_coffset >= 0 && P.box_cstride >= P.box_coffset + 4 * P.num_classes, FCN_E_ARG, "detect: bbox slice out of range");
+    FCN_REQUIRE(P.round_mode == FCN_RECT_ROUND_NEAREST_EVEN || P.round_mode == FCN_RECT_ROUND_TRUNCATE, FCN_E_ARG, "detect: bad round_mode");
+    FCN_REQUIRE((long long)batch * P.num_classes < (1 << 30), FCN_E_UNSUPPORTED, "detect: too many problems");
+    DetP d;
+    d.p = P;
+    d.eps = P.eps;
+    d.cvg = cvg;
+    d.bbox = bbox;
+    d.cvg_image_stride = cvg_image_stride;
+    d.box_image_stride = box_image_stride;
+    d.ws = reinterpret_cast<int*>(d_workspace);
+    d.out_rects = out_rects;
+    d.out_weights = out_weights;
+    d.out_count = out_count;
+    hipLaunchKernelGGL(detect_kernel, dim3(batch * P.num_classes), dim3(kDetThreads), 0, as_stream(s), d);
+    FCN_LAUNCH_CHECK("detect_decode_group");
+    return 0;
+}
+
+int fcn_gen_targets(const int32_t* rects, const int32_t* labels, const int32_t* rect_offsets, int batch, int num_classes, int gy, int gx,
+                    int stride, double iou_thresh, float* foreground, float* bbox, float* size, float* obj, float* cvg_block,
+                    fcn_stream_t s) {
+    FCN_REQUIRE(rects && labels && rect_offsets && foreground && bbox && size && obj && cvg_block, FCN_E_ARG, "gen_targets: null");
+    FCN_REQUIRE(batch > 0 && num_classes > 0 && gy > 0 && gx > 0 && stride > 0, FCN_E_ARG, "gen_targets: bad extents");
+    const long long total = (long long)batch * num_classes * gy * gx;
+    hipLaunchKernelGGL(gen_targets_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(s), rects, labels, rect_offsets, batch,
+                       num_classes, gy, gx, stride, iou_thresh, foreground, bbox, size, obj, cvg_block);
+    FCN_LAUNCH_CHECK("gen_targets");
+    return 0;
+}
+
+}  // extern "C"

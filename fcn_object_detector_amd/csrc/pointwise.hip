@@ -1,0 +1,422 @@
+// HBM-bound layers of the detector for gfx950: pooling, LRN, element-wise, layout changes.
+//
+// Stands in for Caffe's PoolingLayer / LRNLayer / ReLULayer / SigmoidLayer / PowerLayer /
+// EltwiseLayer / DeconvolutionLayer(group == channels) forward passes as executed by
+// net.forward() (reference: scripts/fcn_object_detector.py:87) over models/deploy.prototxt
+// (pool :54-64, LRN :65-75) and train/fcn_bbox/train_val.prototxt (deconv :544-565, eltwise
+// :567-651).  All activations are NHWC: a pixel's channels are contiguous, so every kernel here
+// moves 16 bytes per lane (4 channels) with consecutive lanes on consecutive addresses, and the
+// LRN channel window is a contiguous run inside one pixel.
+#include <float.h>
+#include <math.h>
+
+#include "common.h"
+
+using namespace fcn;
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------
+// NCHW <-> NHWC (pycaffe boundary).  32x32 LDS tile transpose over (C, H*W) per image.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int HW, int dst_cstride, int dst_coffset) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* s = src + (size_t)n * C * HW;
+    float* d = dst + (size_t)n * HW * dst_cstride;
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        tile[i][tx] = (c < C && p < HW) ? s[(size_t)c * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        if (p < HW && c < C) d[(size_t)p * dst_cstride + dst_coffset + c] = tile[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int C, int HW, int src_cstride, int src_coffset) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* s = src + (size_t)n * HW * src_cstride;
+    float* d = dst + (size_t)n * C * HW;
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        tile[i][tx] = (p < HW && c < C) ? s[(size_t)p * src_cstride + src_coffset + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        if (c < C && p < HW) d[(size_t)c * HW + p] = tile[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MAX pooling (Caffe semantics: window clipped to the image, strict '>' so the first maximum in
+// raster order wins, start value -FLT_MAX).  One lane = 4 channels of one output pixel.
+// ---------------------------------------------------------------------------------------------
+template <bool VEC4, bool WITH_IDX>
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y, int32_t* __restrict__ idx,
+                                                      int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
+                                                      int OH, int OW, int y_cstride, int y_coffset) {
+    const int cg = VEC4 ? C / 4 : C;  // channel groups per pixel
+    const long long total = (long long)N * OH * OW * cg;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(t % cg);
+        long long pix = t / cg;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        int hs = oy * stride - pad, ws = ox * stride - pad;
+        const int he = min(hs + k, H), we = min(ws + k, W);
+        hs = max(hs, 0);
+        ws = max(ws, 0);
+        const float* xb = x + (size_t)n * H * W * x_cstride + (VEC4 ? g * 4 : g);
+        const size_t o = ((size_t)(n * OH + oy) * OW + ox);
+        if (VEC4) {
+            float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+            int4 mi = make_int4(-1, -1, -1, -1);
+            for (int iy = hs; iy < he; ++iy)
+                for (int ix = ws; ix < we; ++ix) {
+                    const float4 v = ld4(xb + ((size_t)iy * W + ix) * x_cstride);
+                    const int id = iy * W + ix;
+                    if (v.x > m.x) { m.x = v.x; mi.x = id; }
+                    if (v.y > m.y) { m.y = v.y; mi.y = id; }
+                    if (v.z > m.z) { m.z = v.z; mi.z = id; }
+                    if (v.w > m.w) { m.w = v.w; mi.w = id; }
+                }
+            st4(y + o * y_cstride + y_coffset + g * 4, m);
+            if (WITH_IDX) *reinterpret_cast<int4*>(idx + o * C + g * 4) = mi;
+        } else {
+            float m = -FLT_MAX;
+            int mi = -1;
+            for (int iy = hs; iy < he; ++iy)
+                for (int ix = ws; ix < we; ++ix) {
+                    const float v = xb[((size_t)iy * W + ix) * x_cstride];
+                    if (v > m) { m = v; mi = iy * W + ix; }
+                }
+            y[o * y_cstride + y_coffset + g] = m;
+            if (WITH_IDX) idx[o * C + g] = mi;
+        }
+    }
+}
+
+// AVE pooling: divisor = window area clipped to H+pad (Caffe counts the padding), sum over the image part
+__global__ __launch_bounds__(256) void avepool_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                                                      int x_cstride, int k, int stride, int pad, int OH, int OW, int y_cstride,
+                                                      int y_coffset) {
+    const long long total = (long long)N * OH * OW * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        long long pix = t / C;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        int hs = oy * stride - pad, ws = ox * stride - pad;
+        int he = min(hs + k, H + pad), we = min(ws + k, W + pad);
+        const float area = (float)((he - hs) * (we - ws));
+        hs = max(hs, 0);
+        ws = max(ws, 0);
+        he = min(he, H);
+        we = min(we, W);
+        const float* xb = x + (size_t)n * H * W * x_cstride + c;
+        float acc = 0.f;
+        for (int iy = hs; iy < he; ++iy)
+            for (int ix = ws; ix < we; ++ix) acc += xb[((size_t)iy * W + ix) * x_cstride];
+        y[((size_t)(n * OH + oy) * OW + ox) * y_cstride + y_coffset + c] = acc / area;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LRN across channels, local_size 5 fast path: one lane = 4 channels; the 5-wide window of those
+// 4 channels lives in the 12 floats c-4..c+7 of the same pixel (three 16-byte loads).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lrn5_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ scale,
+                                                   long long pixels, int C, int x_cstride, int y_cstride, float alpha_over_n,
+                                                   float beta, float kk) {
+    const int cg = C / 4;
+    const long long total = pixels * cg;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(t % cg);
+        const long long pix = t / cg;
+        const float* xp = x + (size_t)pix * x_cstride + g * 4;
+        const float4 c = ld4(xp);
+        const float4 l = g > 0 ? ld4(xp - 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 r = g + 1 < cg ? ld4(xp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float q[12] = {l.x * l.x, l.y * l.y, l.z * l.z, l.w * l.w, c.x * c.x, c.y * c.y,
+                             c.z * c.z, c.w * c.w, r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w};
+        float4 s;
+        s.x = kk + alpha_over_n * (q[2] + q[3] + q[4] + q[5] + q[6]);
+        s.y = kk + alpha_over_n * (q[3] + q[4] + q[5] + q[6] + q[7]);
+        s.z = kk + alpha_over_n * (q[4] + q[5] + q[6] + q[7] + q[8]);
+        s.w = kk + alpha_over_n * (q[5] + q[6] + q[7] + q[8] + q[9]);
+        float4 o;
+        o.x = c.x * powf(s.x, -beta);
+        o.y = c.y * powf(s.y, -beta);
+        o.z = c.z * powf(s.z, -beta);
+        o.w = c.w * powf(s.w, -beta);
+        st4(y + (size_t)pix * y_cstride + g * 4, o);
+        if (scale) st4(scale + (size_t)pix * C + g * 4, s);
+    }
+}
+
+// generic window (any odd/even local_size, any C)
+__global__ __launch_bounds__(256) void lrn_generic_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ scale,
+                                                          long long pixels, int C, int x_cstride, int y_cstride, int local_size,
+                                                          float alpha_over_n, float beta, float kk) {
+    const long long total = pixels * C;
+    const int pre = (local_size - 1) / 2;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const long long pix = t / C;
+        const float* xp = x + (size_t)pix * x_cstride;
+        float acc = 0.f;
+        for (int j = c - pre; j < c - pre + local_size; ++j)
+            if (j >= 0 && j < C) acc += xp[j] * xp[j];
+        const float s = kk + alpha_over_n * acc;
+        y[(size_t)pix * y_cstride + c] = xp[c] * powf(s, -beta);
+        if (scale) scale[(size_t)pix * C + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat element-wise ops (count floats, 16 B per lane when count and pointers allow)
+// ---------------------------------------------------------------------------------------------
+enum { OP_RELU = 0, OP_SIGMOID = 1, OP_POWER = 2 };
+
+template <int OP>
+__device__ __forceinline__ float unary(float v, float a, float b, float c) {
+    if (OP == OP_RELU) return v > 0.f ? v : v * a;
+    if (OP == OP_SIGMOID) return 1.f / (1.f + expf(-v));
+    const float t = c + b * v;  // Power: (shift + scale * x) ^ power
+    return a == 1.f ? t : powf(t, a);
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ x, float* __restrict__ y, size_t count, float a, float b,
+                                                    float c) {
+    const size_t n4 = count / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = ld4(x + i * 4);
+        v.x = unary<OP>(v.x, a, b, c);
+        v.y = unary<OP>(v.y, a, b, c);
+        v.z = unary<OP>(v.z, a, b, c);
+        v.w = unary<OP>(v.w, a, b, c);
+        st4(y + i * 4, v);
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) y[i] = unary<OP>(x[i], a, b, c);
+}
+
+__global__ __launch_bounds__(256) void unary_scalar_kernel(const float* __restrict__ x, float* __restrict__ y, size_t count, int op,
+                                                           float a, float b, float c) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float v = x[i];
+        y[i] = op == OP_RELU ? unary<OP_RELU>(v, a, b, c) : op == OP_SIGMOID ? unary<OP_SIGMOID>(v, a, b, c) : unary<OP_POWER>(v, a, b, c);
+    }
+}
+
+__global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                                      size_t count, int op, float ca, float cb) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float u = a[i], v = b[i];
+        y[i] = op == FCN_ELT_PROD ? u * v : op == FCN_ELT_SUM ? ca * u + cb * v : fmaxf(u, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, long long pixels,
+                                                            int C, int src_cstride, int src_coffset, int dst_cstride, int dst_coffset) {
+    const long long total = pixels * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const long long pix = t / C;
+        dst[(size_t)pix * dst_cstride + dst_coffset + c] = src[(size_t)pix * src_cstride + src_coffset + c];
+    }
+}
+
+// depthwise transposed convolution (Caffe Deconvolution with group == channels), gather form:
+// y[oy][ox][c] = b[c] + sum over (r, q) with (oy + p - r) % s == 0, (ox + p - q) % s == 0 of
+//                x[(oy+p-r)/s][(ox+p-q)/s][c] * w[c][r][q]
+__global__ __launch_bounds__(256) void deconv_dw_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int N, int H, int W, int C,
+                                                        int x_cstride, int k, int stride, int pad, int OH, int OW, int y_cstride,
+                                                        int y_coffset) {
+    const long long total = (long long)N * OH * OW * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        long long pix = t / C;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        float acc = bias ? bias[c] : 0.f;
+        const float* xb = x + (size_t)n * H * W * x_cstride + c;
+        const float* wc = w + (size_t)c * k * k;
+        for (int r = (oy + pad) % stride; r < k; r += stride) {
+            const int iy = (oy + pad - r) / stride;
+            if (oy + pad - r < 0 || iy >= H) continue;
+            for (int q = (ox + pad) % stride; q < k; q += stride) {
+                const int ix = (ox + pad - q) / stride;
+                if (ox + pad - q < 0 || ix >= W) continue;
+                acc += xb[((size_t)iy * W + ix) * x_cstride] * wc[r * k + q];
+            }
+        }
+        y[((size_t)(n * OH + oy) * OW + ox) * y_cstride + y_coffset + c] = acc;
+    }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+int launch_unary(int op, const float* x, float* y, size_t count, float a, float b, float c, fcn_stream_t s) {
+    FCN_REQUIRE(x && y, FCN_E_ARG, "unary: null");
+    if (count == 0) return 0;
+    hipStream_t st = as_stream(s);
+    if (aligned16(x) && aligned16(y)) {
+        const int grid = stream_grid((long long)(count / 4 + 1), 256);
+        if (op == OP_RELU) hipLaunchKernelGGL(unary_kernel<OP_RELU>, dim3(grid), dim3(256), 0, st, x, y, count, a, b, c);
+        else if (op == OP_SIGMOID) hipLaunchKernelGGL(unary_kernel<OP_SIGMOID>, dim3(grid), dim3(256), 0, st, x, y, count, a, b, c);
+        else hipLaunchKernelGGL(unary_kernel<OP_POWER>, dim3(grid), dim3(256), 0, st, x, y, count, a, b, c);
+    } else {
+        hipLaunchKernelGGL(unary_scalar_kernel, dim3(stream_grid((long long)count, 256)), dim3(256), 0, st, x, y, count, op, a, b, c);
+    }
+    FCN_LAUNCH_CHECK("unary");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int dst_cstride, int dst_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, FCN_E_ARG, "nchw_to_nhwc: bad args");
+    FCN_REQUIRE(dst_coffset >= 0 && dst_cstride >= dst_coffset + C, FCN_E_ARG, "nchw_to_nhwc: slice exceeds dst_cstride");
+    FCN_REQUIRE(N <= 65535, FCN_E_UNSUPPORTED, "nchw_to_nhwc: batch too large");
+    const int HW = H * W;
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, dst_cstride, dst_coffset);
+    FCN_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+int fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W, int src_cstride, int src_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, FCN_E_ARG, "nhwc_to_nchw: bad args");
+    FCN_REQUIRE(src_coffset >= 0 && src_cstride >= src_coffset + C, FCN_E_ARG, "nhwc_to_nchw: slice exceeds src_cstride");
+    FCN_REQUIRE(N <= 65535, FCN_E_UNSUPPORTED, "nhwc_to_nchw: batch too large");
+    const int HW = H * W;
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, src_cstride, src_coffset);
+    FCN_LAUNCH_CHECK("nhwc_to_nchw");
+    return 0;
+}
+
+int fcn_maxpool_fwd_f32(const float* x, float* y, int32_t* idx, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
+                        int OH, int OW, int y_cstride, int y_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && OH > 0 && OW > 0, FCN_E_ARG,
+                "maxpool: bad args");
+    FCN_REQUIRE(pad < k, FCN_E_ARG, "maxpool: pad must be smaller than the kernel");
+    FCN_REQUIRE((OH - 1) * stride - pad < H && (OW - 1) * stride - pad < W, FCN_E_ARG,
+                "maxpool: last window starts outside the image (OH/OW too large)");
+    FCN_REQUIRE(x_cstride >= C && y_coffset >= 0 && y_cstride >= y_coffset + C, FCN_E_ARG, "maxpool: channel slice out of range");
+    const bool vec = C % 4 == 0 && x_cstride % 4 == 0 && y_cstride % 4 == 0 && y_coffset % 4 == 0 && aligned16(x) && aligned16(y) &&
+                     (!idx || aligned16(idx));
+    const long long work = (long long)N * OH * OW * (vec ? C / 4 : C);
+    const int grid = stream_grid(work, 256);
+    hipStream_t st = as_stream(s);
+#define FCN_POOL_ARGS x, y, idx, N, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride, y_coffset
+    if (vec && idx) hipLaunchKernelGGL((maxpool_kernel<true, true>), dim3(grid), dim3(256), 0, st, FCN_POOL_ARGS);
+    else if (vec) hipLaunchKernelGGL((maxpool_kernel<true, false>), dim3(grid), dim3(256), 0, st, FCN_POOL_ARGS);
+    else if (idx) hipLaunchKernelGGL((maxpool_kernel<false, true>), dim3(grid), dim3(256), 0, st, FCN_POOL_ARGS);
+    else hipLaunchKernelGGL((maxpool_kernel<false, false>), dim3(grid), dim3(256), 0, st, FCN_POOL_ARGS);
+#undef FCN_POOL_ARGS
+    FCN_LAUNCH_CHECK("maxpool");
+    return 0;
+}
+
+int fcn_avepool_fwd_f32(const float* x, float* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad, int OH, int OW,
+                        int y_cstride, int y_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && OH > 0 && OW > 0, FCN_E_ARG,
+                "avepool: bad args");
+    FCN_REQUIRE((OH - 1) * stride - pad < H && (OW - 1) * stride - pad < W, FCN_E_ARG, "avepool: OH/OW too large");
+    FCN_REQUIRE(x_cstride >= C && y_coffset >= 0 && y_cstride >= y_coffset + C, FCN_E_ARG, "avepool: channel slice out of range");
+    const long long work = (long long)N * OH * OW * C;
+    hipLaunchKernelGGL(avepool_kernel, dim3(stream_grid(work, 256)), dim3(256), 0, as_stream(s), x, y, N, H, W, C, x_cstride, k, stride, pad,
+                       OH, OW, y_cstride, y_coffset);
+    FCN_LAUNCH_CHECK("avepool");
+    return 0;
+}
+
+int fcn_lrn_fwd_f32(const float* x, float* y, float* scale, int pixels, int C, int x_cstride, int y_cstride, int local_size, float alpha,
+                    float beta, float k, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && pixels > 0 && C > 0 && local_size > 0, FCN_E_ARG, "lrn: bad args");
+    FCN_REQUIRE(x_cstride >= C && y_cstride >= C, FCN_E_ARG, "lrn: channel stride smaller than C");
+    const float aon = alpha / (float)local_size;
+    hipStream_t st = as_stream(s);
+    const bool fast = local_size == 5 && C % 4 == 0 && x_cstride % 4 == 0 && y_cstride % 4 == 0 && aligned16(x) && aligned16(y) &&
+                      (!scale || aligned16(scale));
+    if (fast) {
+        hipLaunchKernelGGL(lrn5_kernel, dim3(stream_grid((long long)pixels * (C / 4), 256)), dim3(256), 0, st, x, y, scale,
+                           (long long)pixels, C, x_cstride, y_cstride, aon, beta, k);
+    } else {
+        hipLaunchKernelGGL(lrn_generic_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, st, x, y, scale,
+                           (long long)pixels, C, x_cstride, y_cstride, local_size, aon, beta, k);
+    }
+    FCN_LAUNCH_CHECK("lrn");
+    return 0;
+}
+
+int fcn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, fcn_stream_t s) {
+    return launch_unary(OP_RELU, x, y, count, negative_slope, 0.f, 0.f, s);
+}
+
+int fcn_sigmoid_fwd_f32(const float* x, float* y, size_t count, fcn_stream_t s) { return launch_unary(OP_SIGMOID, x, y, count, 0.f, 0.f, 0.f, s); }
+
+int fcn_power_fwd_f32(const float* x, float* y, size_t count, float power, float scale, float shift, fcn_stream_t s) {
+    return launch_unary(OP_POWER, x, y, count, power, scale, shift, s);
+}
+
+int fcn_eltwise_fwd_f32(const float* a, const float* b, float* y, size_t count, int op, float ca, float cb, fcn_stream_t s) {
+    FCN_REQUIRE(a && b && y, FCN_E_ARG, "eltwise: null");
+    FCN_REQUIRE(op == FCN_ELT_PROD || op == FCN_ELT_SUM || op == FCN_ELT_MAX, FCN_E_ARG, "eltwise: bad op %d", op);
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(eltwise_kernel, dim3(stream_grid((long long)count, 256)), dim3(256), 0, as_stream(s), a, b, y, count, op, ca, cb);
+    FCN_LAUNCH_CHECK("eltwise");
+    return 0;
+}
+
+int fcn_copy_channels_f32(const float* src, float* dst, int pixels, int C, int src_cstride, int src_coffset, int dst_cstride,
+                          int dst_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(src && dst && pixels > 0 && C > 0, FCN_E_ARG, "copy_channels: bad args");
+    FCN_REQUIRE(src_coffset >= 0 && dst_coffset >= 0 && src_cstride >= src_coffset + C && dst_cstride >= dst_coffset + C, FCN_E_ARG,
+                "copy_channels: slice out of range");
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, as_stream(s), src, dst,
+                       (long long)pixels, C, src_cstride, src_coffset, dst_cstride, dst_coffset);
+    FCN_LAUNCH_CHECK("copy_channels");
+    return 0;
+}
+
+int fcn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int C, int x_cstride,
+                                 int k, int stride, int pad, int OH, int OW, int y_cstride, int y_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0, FCN_E_ARG, "deconv: bad args");
+    FCN_REQUIRE(OH == stride * (H - 1) + k - 2 * pad && OW == stride * (W - 1) + k - 2 * pad, FCN_E_ARG,
+                "deconv: OH/OW do not match s(H-1)+k-2p");
+    FCN_REQUIRE(x_cstride >= C && y_coffset >= 0 && y_cstride >= y_coffset + C, FCN_E_ARG, "deconv: channel slice out of range");
+    hipLaunchKernelGGL(deconv_dw_kernel, dim3(stream_grid((long long)N * OH * OW * C, 256)), dim3(256), 0, as_stream(s), x, w, bias, y, N,
+                       H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride, y_coffset);
+    FCN_LAUNCH_CHECK("deconv_depthwise");
+    return 0;
+}
+
+}  // extern "C"

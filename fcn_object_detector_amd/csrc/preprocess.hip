@@ -1,0 +1,107 @@
+// Inference pre-processing on the device for gfx950.
+//
+// Stands in for the host-side numpy/OpenCV chain of the reference's ROS node
+// (scripts/fcn_object_detector.py:79-82 and demean_rgb_image :407-413):
+//     im = frame.astype(float); im[:,:,c] -= mean[c]; im = (im - im.min()) / (im.max() - im.min())
+//     im = cv.resize(im, (W, H))            # bilinear, float64 image, float coefficients
+//     blob[...] = im.transpose(2, 0, 1)     # float64 -> float32
+// The min/max of (px - mean[c]) over the frame equals min/max over c of (min/max_c(px) - mean[c]), so
+// the reduction runs on the uint8 pixels with integer atomics (exact), and the rest is one pass that
+// writes the network's NHWC input directly.  Arithmetic is float64 like the reference's.
+#include <math.h>
+
+#include "common.h"
+
+using namespace fcn;
+
+namespace {
+
+__constant__ double kMeanBGR[3] = {104.0069879317889, 116.66876761696767, 122.6789143406786};
+
+__global__ void minmax_init_kernel(int* mm) {
+    if (threadIdx.x < 3) {
+        mm[threadIdx.x] = 255;
+        mm[3 + threadIdx.x] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__ frame, long long npix, int* mm) {
+    int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int v = frame[p * 3 + c];
+            lo[c] = min(lo[c], v);
+            hi[c] = max(hi[c], v);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[c] = min(lo[c], __shfl_xor(lo[c], off));
+            hi[c] = max(hi[c], __shfl_xor(hi[c], off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&mm[c], lo[c]);
+            atomicMax(&mm[3 + c], hi[c]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restrict__ frame, int h, int w, float* __restrict__ dst, int H,
+                                                          int W, int cstride, const int* __restrict__ mm) {
+    double gmin = 1e300, gmax = -1e300;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gmin = fmin(gmin, (double)mm[c] - kMeanBGR[c]);
+        gmax = fmax(gmax, (double)mm[3 + c] - kMeanBGR[c]);
+    }
+    const double range = gmax - gmin;
+    const double scale_x = (double)w / (double)W, scale_y = (double)h / (double)H;
+    const long long total = (long long)H * W;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int X = (int)(t % W), Y = (int)(t / W);
+        // OpenCV resize INTER_LINEAR coordinate + coefficient computation (coefficients are float)
+        float fx = (float)(((double)X + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= w - 1) { fx = 0.f; sx = w - 1; }
+        float fy = (float)(((double)Y + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        if (sy < 0) { fy = 0.f; sy = 0; }
+        if (sy >= h - 1) { fy = 0.f; sy = h - 1; }
+        const int sx1 = min(sx + 1, w - 1), sy1 = min(sy + 1, h - 1);
+        const double a0 = (double)(1.f - fx), a1 = (double)fx, b0 = (double)(1.f - fy), b1 = (double)fy;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double m = kMeanBGR[c];
+            const double s00 = ((double)frame[((size_t)sy * w + sx) * 3 + c] - m - gmin) / range;
+            const double s01 = ((double)frame[((size_t)sy * w + sx1) * 3 + c] - m - gmin) / range;
+            const double s10 = ((double)frame[((size_t)sy1 * w + sx) * 3 + c] - m - gmin) / range;
+            const double s11 = ((double)frame[((size_t)sy1 * w + sx1) * 3 + c] - m - gmin) / range;
+            const double r0 = s00 * a0 + s01 * a1;
+            const double r1 = s10 * a0 + s11 * a1;
+            dst[(size_t)t * cstride + c] = (float)(r0 * b0 + r1 * b1);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride, float* d_minmax, fcn_stream_t s) {
+    FCN_REQUIRE(frame && dst && d_minmax && h > 0 && w > 0 && H > 0 && W > 0 && dst_cstride >= 3, FCN_E_ARG, "preprocess: bad args");
+    hipStream_t st = as_stream(s);
+    int* mm = reinterpret_cast<int*>(d_minmax);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(64), 0, st, mm);
+    hipLaunchKernelGGL(minmax_kernel, dim3(stream_grid((long long)h * w, 256)), dim3(256), 0, st, frame, (long long)h * w, mm);
+    hipLaunchKernelGGL(resize_norm_kernel, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, st, frame, h, w, dst, H, W, dst_cstride,
+                       mm);
+    FCN_LAUNCH_CHECK("preprocess_bgr8");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Host mirror of the reference's inference node, with the arithmetic on the GPU.
+
+Mirrors ``FCNObjectDetector`` (reference: scripts/fcn_object_detector.py) without
+ROS: same method names, argument meaning and defaults —
+
+  demean_rgb_image + cv.resize + transpose  (:79-82, :407-413)  -> fcn_preprocess_bgr8
+  net.forward()                             (:87)               -> hipGraph replay
+  gridbox_to_boxes + vote_boxes             (:337-394)          -> fcn_detect_decode_group
+  np.asarray(dtype=int) + resize_detection  (:123-124, :396-405) -> host ints (5 numbers per box)
+
+The node reads blobs ``pool_score`` / ``upscore_pool5_bbox`` at stride 8 and skips the
+background channel (:89-90, :360); the shipped models/deploy.prototxt exposes
+``coverage`` / ``bboxes`` at stride 16 without a background channel, so the
+blob mapping is a parameter (:class:`HeadMapping`) with both presets.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as L
+from .engine import DeviceBuffer, Engine
+
+F32 = np.float32
+
+
+class HeadMapping:
+    """Which blobs hold coverage / boxes, the grid stride, and whether channel 0 is background."""
+
+    def __init__(self, cvg_blob: str, bbox_blob: str, stride: int, skip_background: bool):
+        self.cvg_blob, self.bbox_blob, self.stride, self.skip_background = cvg_blob, bbox_blob, int(stride), bool(skip_background)
+
+    @classmethod
+    def reference_node(cls) -> "HeadMapping":
+        # fcn_object_detector.py:89-90 and :360 (stride = 16/2)
+        return cls("pool_score", "upscore_pool5_bbox", 8, True)
+
+    @classmethod
+    def detectnet_deploy(cls) -> "HeadMapping":
+        # models/deploy.prototxt:2144-2176; boundary_adjustment/boundary_refinement.py:265-302 (stride 16)
+        return cls("coverage", "bboxes", 16, False)
+
+    @classmethod
+    def auto(cls, blob_names: Sequence[str]) -> "HeadMapping":
+        if "pool_score" in blob_names and "upscore_pool5_bbox" in blob_names:
+            return cls.reference_node()
+        if "coverage" in blob_names and "bboxes" in blob_names:
+            return cls.detectnet_deploy()
+        raise KeyError("net exposes neither (pool_score, upscore_pool5_bbox) nor (coverage, bboxes)")
+
+
+class GridDecoder:
+    """Device-side gridbox_to_boxes + vote_boxes (cv.groupRectangles) for a fixed grid."""
+
+    def __init__(self, batch: int, num_classes: int, gy: int, gx: int, im_w: int, im_h: int,
+                 prob_thresh: float = 0.5, min_boxes: int = 3, eps: float = 0.2, min_height: int = 20,
+                 round_mode: int = L.RECT_ROUND_NEAREST_EVEN, max_out: Optional[int] = None):
+        self.batch, self.C, self.gy, self.gx = int(batch), int(num_classes), int(gy), int(gx)
+        p = L.DetectParams()
+        p.num_classes, p.gy, p.gx = self.C, self.gy, self.gx
+        p.cell_w, p.cell_h = int(im_w) // self.gx, int(im_h) // self.gy     # :368-369 integer division
+        p.prob_thresh, p.group_thresh, p.eps = float(np.float32(prob_thresh)), int(min_boxes), float(eps)
+        p.min_height, p.round_mode = int(min_height), int(round_mode)
+        p.max_out = int(max_out) if max_out else self.gy * self.gx
+        self.params = p
+        lib = L.load()
+        slots = self.batch * self.C
+        self.ws = DeviceBuffer(max(int(lib.fcn_detect_workspace_bytes(C.byref(p), self.batch)), 16), zero=False)
+        self.d_rects = DeviceBuffer(slots * p.max_out * 16, zero=True)
+        self.d_weights = DeviceBuffer(slots * p.max_out * 4, zero=True)
+        self.d_count = DeviceBuffer(slots * 4, zero=True)
+        self.h_rects = np.zeros((slots, p.max_out, 4), np.int32)
+        self.h_weights = np.zeros((slots, p.max_out), np.int32)
+        self.h_count = np.zeros((slots,), np.int32)
+
+    def launch(self, cvg_ptr: int, cvg_cstride: int, cvg_coffset: int, cvg_image_stride: int,
+               box_ptr: int, box_cstride: int, box_coffset: int, box_image_stride: int, stream: Optional[int]) -> None:
+        p = self.params
+        p.cvg_cstride, p.cvg_coffset, p.box_cstride, p.box_coffset = cvg_cstride, cvg_coffset, box_cstride, box_coffset
+        L.call("fcn_detect_decode_group", cvg_ptr, box_ptr, self.batch, cvg_image_stride, box_image_stride, C.byref(p),
+               self.ws.ptr, self.d_rects.ptr, self.d_weights.ptr, self.d_count.ptr, stream)
+
+    def fetch(self, stream: Optional[int]) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """Per image: (detections (D,5) float64 [x1,y1,x2,y2,log n] in reference order, labels (D,) int)."""
+        L.call("fcn_memcpy_d2h_async", self.h_count.ctypes.data, self.d_count.ptr, self.h_count.nbytes, stream)
+        L.call("fcn_memcpy_d2h_async", self.h_rects.ctypes.data, self.d_rects.ptr, self.h_rects.nbytes, stream)
+        L.call("fcn_memcpy_d2h_async", self.h_weights.ctypes.data, self.d_weights.ptr, self.h_weights.nbytes, stream)
+        L.call("fcn_stream_sync", stream)
+        out = []
+        for img in range(self.batch):
+            dets, labels = [], []
+            for c in range(self.C):
+                slot = img * self.C + c
+                n = int(self.h_count[slot])
+                if n > self.params.max_out:
+                    raise RuntimeError("detection overflow: %d clusters > max_out %d" % (n, self.params.max_out))
+                for r, wgt in zip(self.h_rects[slot, :n], self.h_weights[slot, :n]):
+                    dets.append([float(r[0]), float(r[1]), float(r[2]), float(r[3]), math.log(int(wgt))])   # :347-348
+                    labels.append(c)
+            out.append((np.asarray(dets, dtype=np.float64).reshape(-1, 5), np.asarray(labels, dtype=np.int64)))
+        return out
+
+
+def detect_from_maps(cvg: np.ndarray, bbox: np.ndarray, im_w: int, im_h: int, prob_thresh: float = 0.5,
+                     min_boxes: int = 3, eps: float = 0.2, min_height: int = 20,
+                     round_mode: int = L.RECT_ROUND_NEAREST_EVEN) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """Run the device decode+group kernel on host maps: cvg (N,C,gy,gx), bbox (N,4C,gy,gx) float32 (NCHW)."""
+    cvg = np.ascontiguousarray(cvg, F32)
+    bbox = np.ascontiguousarray(bbox, F32)
+    n, c, gy, gx = cvg.shape
+    assert bbox.shape == (n, 4 * c, gy, gx)
+    L.call("fcn_init", 0)
+    cv_nhwc = np.ascontiguousarray(cvg.transpose(0, 2, 3, 1))
+    bb_nhwc = np.ascontiguousarray(bbox.transpose(0, 2, 3, 1))
+    d_c, d_b = DeviceBuffer(cv_nhwc.nbytes, zero=False), DeviceBuffer(bb_nhwc.nbytes, zero=False)
+    L.call("fcn_memcpy_h2d_async", d_c.ptr, cv_nhwc.ctypes.data, cv_nhwc.nbytes, None)
+    L.call("fcn_memcpy_h2d_async", d_b.ptr, bb_nhwc.ctypes.data, bb_nhwc.nbytes, None)
+    dec = GridDecoder(n, c, gy, gx, im_w, im_h, prob_thresh, min_boxes, eps, min_height, round_mode)
+    dec.launch(d_c.ptr, c, 0, gy * gx * c, d_b.ptr, 4 * c, 0, gy * gx * 4 * c, None)
+    return dec.fetch(None)
+
+
+def generate_targets(rects_per_image: Sequence[Sequence[Sequence[int]]], labels_per_image: Sequence[Sequence[int]],
+                     im_w: int, im_h: int, stride: int, num_classes: int, iou_thresh: float = 0.1) -> Tuple[np.ndarray, ...]:
+    """Device bounding_box_parameterized_labels for a batch: returns (foreground, bbox, size, obj, coverage_block) NCHW."""
+    batch = len(rects_per_image)
+    gy, gx = int(im_h) // int(stride), int(im_w) // int(stride)      # grid_region: Python-2 integer division (:284)
+    offs = np.zeros(batch + 1, np.int32)
+    flat_r, flat_l = [], []
+    for i, (rs, ls) in enumerate(zip(rects_per_image, labels_per_image)):
+        if len(rs) != len(ls):
+            raise ValueError("image %d: %d rects but %d labels" % (i, len(rs), len(ls)))
+        for r, lab in zip(rs, ls):
+            if not 0 <= int(lab) < num_classes:
+                raise IndexError("label %d outside [0, %d)" % (lab, num_classes))   # numpy would raise on the write (:107)
+            flat_r.append([int(v) for v in r])
+            flat_l.append(int(lab))
+        offs[i + 1] = len(flat_r)
+    rects = np.asarray(flat_r, np.int32).reshape(-1, 4)
+    labels = np.asarray(flat_l, np.int32)
+    L.call("fcn_init", 0)
+    d_r = DeviceBuffer(max(rects.nbytes, 16), zero=False)
+    d_l = DeviceBuffer(max(labels.nbytes, 16), zero=False)
+    d_o = DeviceBuffer(offs.nbytes, zero=False)
+    if rects.size:
+        L.call("fcn_memcpy_h2d_async", d_r.ptr, rects.ctypes.data, rects.nbytes, None)
+        L.call("fcn_memcpy_h2d_async", d_l.ptr, labels.ctypes.data, labels.nbytes, None)
+    L.call("fcn_memcpy_h2d_async", d_o.ptr, offs.ctypes.data, offs.nbytes, None)
+    G = gy * gx
+    outs = [np.zeros((batch, num_classes, gy, gx), F32)] + [np.zeros((batch, 4 * num_classes, gy, gx), F32) for _ in range(4)]
+    devs = [DeviceBuffer(o.nbytes, zero=False) for o in outs]
+    L.call("fcn_gen_targets", d_r.ptr, d_l.ptr, d_o.ptr, batch, num_classes, gy, gx, int(stride), float(iou_thresh),
+           devs[0].ptr, devs[1].ptr, devs[2].ptr, devs[3].ptr, devs[4].ptr, None)
+    for o, d in zip(outs, devs):
+        L.call("fcn_memcpy_d2h_async", o.ctypes.data, d.ptr, o.nbytes, None)
+    L.call("fcn_device_sync")
+    return tuple(outs)
+
+
+def resize_detection(in_size: Sequence[int], boxes: np.ndarray, net_w: int, net_h: int) -> np.ndarray:
+    """fcn_object_detector.py:396-405 — scale columns 0..3 in place on the integer array (truncating)."""
+    diffx = float(in_size[1]) / float(net_w)
+    diffy = float(in_size[0]) / float(net_h)
+    for i in range(len(boxes)):
+        boxes[i, 0] = boxes[i, 0] * diffx
+        boxes[i, 1] = boxes[i, 1] * diffy
+        boxes[i, 2] = boxes[i, 2] * diffx
+        boxes[i, 3] = boxes[i, 3] * diffy
+    return boxes
+
+
+class FCNObjectDetector:
+    """ROS-free mirror of the reference node: ``run_detector(frame_bgr_uint8) -> (boxes (D,5) int, labels (D,) int)``."""
+
+    def __init__(self, engine: Engine, detection_threshold: float = 0.5, min_boxes: int = 3, nms_eps: float = 0.2,
+                 mapping: Optional[HeadMapping] = None, round_mode: int = L.RECT_ROUND_NEAREST_EVEN):
+        self.engine = engine
+        self.prob_thresh, self.min_boxes, self.eps = detection_threshold, min_boxes, nms_eps   # :33-35 defaults
+        self.mapping = mapping or HeadMapping.auto(list(engine.blobs))
+        data = engine.blobs["data"]
+        self.batch, _, self.im_height, self.im_width = data.shape
+        cvg, box = engine.blobs[self.mapping.cvg_blob], engine.blobs[self.mapping.bbox_blob]
+        skip = 1 if self.mapping.skip_background else 0
+        self.num_classes = cvg.channels - skip
+        gx, gy = int(self.im_width / self.mapping.stride), int(self.im_height / self.mapping.stride)   # :362-363
+        if (gy, gx) != tuple(cvg.shape[2:]):
+            raise ValueError("grid %dx%d from stride %d does not match blob %s %s" % (gy, gx, self.mapping.stride,
+                                                                                     self.mapping.cvg_blob, cvg.shape))
+        self.decoder = GridDecoder(self.batch, self.num_classes, gy, gx, self.im_width, self.im_height, self.prob_thresh,
+                                   self.min_boxes, self.eps, 20, round_mode)
+        self._cvg_args = (cvg.buf.ptr, cvg.cstride, cvg.coffset + skip, cvg.pixels // self.batch * cvg.cstride)
+        self._box_args = (box.buf.ptr, box.cstride, box.coffset, box.pixels // self.batch * box.cstride)
+        self._frame_dev: Optional[DeviceBuffer] = None
+        self._minmax = DeviceBuffer(32)
+
+    def run_detector(self, frame: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        eng = self.engine
+        if self.batch != 1:
+            raise ValueError("run_detector handles one frame; build the engine with batch 1")
+        frame = np.ascontiguousarray(frame, np.uint8)
+        h, w, c = frame.shape
+        if c != 3:
+            raise ValueError("expected a BGR uint8 frame")
+        with eng.lock:
+            L.call("fcn_init", eng.device)
+            if self._frame_dev is None or self._frame_dev.nbytes < frame.nbytes:
+                self._frame_dev = DeviceBuffer(frame.nbytes, zero=False)
+            data = eng.blobs["data"]
+            L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, frame.ctypes.data, frame.nbytes, eng.stream)
+            L.call("fcn_preprocess_bgr8", self._frame_dev.ptr, h, w, data.ptr, self.im_height, self.im_width, data.cstride,
+                   self._minmax.ptr, eng.stream)
+            eng.forward_resident(1)
+            self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
+            dets, labels = self.decoder.fetch(eng.stream)[0]
+            data.host_valid = False
+        boxes = np.asarray(dets, dtype=np.int64).reshape(-1, 5)        # :123 np.asarray(..., dtype=np.int) truncates
+        if not len(boxes):
+            return boxes, labels
+        return resize_detection(frame.shape, boxes, self.im_width, self.im_height), labels

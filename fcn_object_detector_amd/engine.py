@@ -1,0 +1,760 @@
+"""Device executor: turns a :class:`NetSpec` into a launch plan over libfcnhip.so.
+
+This is the MI355X replacement of the tensor engine the reference reaches
+through ``caffe.Net`` (reference: scripts/fcn_object_detector.py:87,317-328).
+
+Design:
+  * activations live in HBM as NHWC float32 with a per-blob channel stride;
+    Concat is free — the producers of an inception module write their channel
+    slice of the concat buffer directly;
+  * ReLU (in place after a conv), the Sigmoid coverage head, the Power(shift)
+    input transform and the inception 3x3/s1 max-pool branch are fused into the
+    convolution kernel's prologue/epilogue;
+  * independent convolutions (inception branches, the two heads) are merged into
+    ONE grouped launch;
+  * the whole forward is captured once into a hipGraph and replayed per frame,
+    so the per-frame host cost is one graph launch.
+Blob contents are exposed to Python as NCHW float32 (pycaffe layout); the
+NCHW<->NHWC change happens on the device at the boundary only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as L
+from .netspec import Layer, NetSpec, kernel_stride_pad
+
+F32 = np.float32
+
+
+def _r4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+class DeviceBuffer:
+    """Owns one hipMalloc allocation."""
+
+    def __init__(self, nbytes: int, zero: bool = True):
+        p = C.c_void_p()
+        L.call("fcn_malloc", C.byref(p), nbytes)
+        self.ptr = int(p.value)
+        self.nbytes = int(nbytes)
+        if zero:
+            L.call("fcn_memset_async", self.ptr, 0, self.nbytes, None)
+            L.call("fcn_device_sync")
+
+    def free(self) -> None:
+        if getattr(self, "ptr", 0):
+            try:
+                L.load().fcn_free(self.ptr)
+            finally:
+                self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """A numpy float32 array backed by hipHostMalloc memory (stable address for graph memcpy nodes)."""
+
+    def __init__(self, shape: Tuple[int, ...]):
+        n = int(np.prod(shape)) if len(shape) else 1
+        p = C.c_void_p()
+        L.call("fcn_host_malloc", C.byref(p), max(n, 1) * 4)
+        self.ptr = int(p.value)
+        buf = (C.c_float * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=F32, count=n).reshape(shape)
+        self.array[...] = 0
+
+    def free(self) -> None:
+        if getattr(self, "ptr", 0):
+            self.array = None
+            try:
+                L.load().fcn_host_free(self.ptr)
+            finally:
+                self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Blob:
+    """One named blob: NCHW shape, NHWC device view (buffer, channel offset, channel stride)."""
+
+    def __init__(self, name: str, shape: Tuple[int, ...]):
+        self.name = name
+        self.shape = tuple(shape)
+        self.buf: Optional[DeviceBuffer] = None
+        self.coffset = 0
+        self.cstride = 0
+        self.lazy_shift = 0.0          # value added when the blob is read back (fused Power layer)
+        self.host: Optional[np.ndarray] = None
+        self.pinned: Optional[PinnedArray] = None
+        self.host_valid = False        # host copy reflects the device contents
+        self.is_input = False
+
+    @property
+    def channels(self) -> int:
+        return self.shape[1] if len(self.shape) == 4 else 1
+
+    @property
+    def pixels(self) -> int:
+        return self.shape[0] * self.shape[2] * self.shape[3] if len(self.shape) == 4 else 1
+
+    @property
+    def ptr(self) -> int:
+        """Device address of channel 0 of pixel 0 of this view."""
+        return self.buf.ptr + 4 * self.coffset
+
+    @property
+    def contiguous(self) -> bool:
+        return self.coffset == 0 and self.cstride == self.channels
+
+
+class Op:
+    """One launch (or fused group of launches) of the plan."""
+
+    def __init__(self, kind: str, name: str, run: Callable[[Optional[int]], None], flops: float = 0.0, bytes_: float = 0.0):
+        self.kind = kind
+        self.name = name
+        self.run = run
+        self.flops = flops
+        self.bytes = bytes_
+
+
+class Engine:
+    """Executes a NetSpec on one GPU through libfcnhip.so."""
+
+    def __init__(self, spec: NetSpec, data_shapes: Optional[Dict[str, Tuple[int, ...]]] = None,
+                 params: Optional[Dict[str, List[np.ndarray]]] = None, device: int = 0,
+                 fuse: bool = True, group_convs: bool = True):
+        self.spec = spec
+        self.device = device
+        self.fuse = fuse
+        self.group_convs = group_convs
+        L.call("fcn_init", device)
+        sp = C.c_void_p()
+        L.call("fcn_stream_create", C.byref(sp))
+        self.stream = int(sp.value)
+        self.lock = threading.RLock()
+        self.shapes = spec.infer(data_shapes)
+        self.blobs: Dict[str, Blob] = {}
+        self.params_host: Dict[str, List[np.ndarray]] = {}
+        self.params_dev: Dict[str, List[DeviceBuffer]] = {}
+        self.ops: List[Op] = []
+        self.graph_io: Optional[int] = None
+        self.graph_core: Optional[int] = None
+        self._staging: Dict[str, DeviceBuffer] = {}
+        self._keep: List[object] = []
+        self._conv_layer_meta: Dict[str, dict] = {}
+        self.inputs = spec.data_tops()
+        self.outputs = [b for b in spec.output_blobs() if b in self.shapes]
+        self._plan_buffers()
+        self._alloc_params(params)
+        self._build_ops()
+
+    # ------------------------------------------------------------------ buffers
+    def _plan_buffers(self) -> None:
+        spec = self.spec
+        producers: Dict[str, List[Layer]] = {}
+        consumers: Dict[str, List[Layer]] = {}
+        for l in spec.layers:
+            for t in l.tops:
+                producers.setdefault(t, []).append(l)
+            for b in l.bottoms:
+                consumers.setdefault(b, []).append(l)
+        self.producers, self.consumers = producers, consumers
+        data_tops = set(self.inputs)
+
+        alias: Dict[str, Tuple[str, int]] = {}   # child blob -> (parent blob, channel offset in parent)
+        shift: Dict[str, float] = {}
+        self.copy_concats = set()
+        for l in spec.layers:
+            if l.type == "Concat":
+                off = 0
+                ok = True
+                plan = []
+                for b in l.bottoms:
+                    c = self.shapes[b][1]
+                    prods = [p for p in producers.get(b, []) if not (p.type in ("ReLU", "Dropout") and p.bottoms == p.tops)]
+                    good = (self.fuse and b not in data_tops and b not in alias and c % 4 == 0 and len(prods) == 1
+                            and prods[0].type in ("Convolution", "Pooling")
+                            and sum(1 for q in consumers.get(b, []) if q.type == "Concat") == 1)
+                    ok = ok and good
+                    plan.append((b, off))
+                    off += c
+                if ok:
+                    for b, o in plan:
+                        alias[b] = (l.tops[0], o)
+                else:
+                    self.copy_concats.add(l.name)
+            elif l.type == "Dropout" and spec.phase == "TEST" and l.tops[0] != l.bottoms[0]:
+                alias[l.tops[0]] = (l.bottoms[0], 0)       # identity at test time: share the view
+            elif l.type == "Power" and self.fuse and l.tops[0] != l.bottoms[0]:
+                p = l.sub("power_param")
+                cons = consumers.get(l.tops[0], [])
+                if (float(p.get("power", 1.0)) == 1.0 and float(p.get("scale", 1.0)) == 1.0 and cons
+                        and all(q.type == "Convolution" for q in cons)):
+                    alias[l.tops[0]] = (l.bottoms[0], 0)
+                    shift[l.tops[0]] = float(p.get("shift", 0.0))
+            elif l.type == "Slice":
+                n, c, h, w = self.shapes[l.bottoms[0]]
+                off = 0
+                for t in l.tops:
+                    alias[t] = (l.bottoms[0], off)
+                    off += self.shapes[t][1]
+        self.alias, self.shift = alias, shift
+
+        # allocate roots, then resolve views
+        for name, shp in self.shapes.items():
+            self.blobs[name] = Blob(name, shp)
+        for name, blob in self.blobs.items():
+            if name in alias:
+                continue
+            if len(blob.shape) == 4:
+                blob.cstride = _r4(blob.channels)
+                blob.buf = DeviceBuffer(blob.pixels * blob.cstride * 4)
+            else:
+                blob.cstride = 1
+                blob.buf = DeviceBuffer(16)
+        for name in alias:
+            root, off = name, 0
+            total_shift = 0.0
+            seen = 0
+            while root in alias:
+                total_shift += shift.get(root, 0.0)
+                root, o = alias[root]
+                off += o
+                seen += 1
+                if seen > 64:
+                    raise RuntimeError("alias cycle at blob %s" % name)
+            b, r = self.blobs[name], self.blobs[root]
+            b.buf, b.coffset, b.cstride = r.buf, r.coffset + off, r.cstride
+            b.lazy_shift = total_shift
+        for nm in self.inputs:
+            if nm in self.blobs:
+                self.blobs[nm].is_input = True
+
+    def _alloc_params(self, params: Optional[Dict[str, List[np.ndarray]]]) -> None:
+        from .netspec import fill_params
+        if params is None:
+            params = fill_params(self.spec, seed=0)
+        for l in self.spec.param_layers():
+            shapes = self.spec.param_shapes[l.name]
+            blobs = params.get(l.name)
+            if blobs is None:
+                raise KeyError("no parameters for layer %s" % l.name)
+            host = []
+            for arr, shp in zip(blobs, shapes):
+                a = np.ascontiguousarray(arr, dtype=F32)
+                if a.shape != tuple(shp):
+                    if a.size != int(np.prod(shp)):
+                        raise ValueError("layer %s: parameter shape %s does not match %s" % (l.name, a.shape, shp))
+                    a = a.reshape(shp)
+                host.append(a.copy())
+            self.params_host[l.name] = host
+            self.params_dev[l.name] = []
+            self._upload_params(l)
+
+    def _packed_weight(self, l: Layer) -> np.ndarray:
+        w = self.params_host[l.name][0]
+        if l.type == "Convolution":
+            co, ci, kh, kw = w.shape
+            ci4 = _r4(ci)
+            out = np.zeros((co, kh, kw, ci4), F32)           # OHWI, Cin padded to a multiple of 4
+            out[..., :ci] = w.transpose(0, 2, 3, 1)
+            return out
+        if l.type == "Deconvolution":
+            c, cog, kh, kw = w.shape
+            if cog != 1:
+                raise NotImplementedError("Deconvolution %s: only group == channels (one filter per channel)" % l.name)
+            return np.ascontiguousarray(w.reshape(c, kh, kw))
+        raise NotImplementedError(l.type)
+
+    def _upload_params(self, l: Layer) -> None:
+        host = self.params_host[l.name]
+        packed = [self._packed_weight(l)] + [np.ascontiguousarray(h) for h in host[1:]]
+        devs = self.params_dev[l.name]
+        for i, arr in enumerate(packed):
+            if i >= len(devs):
+                devs.append(DeviceBuffer(arr.nbytes, zero=False))
+            L.call("fcn_memcpy_h2d_async", devs[i].ptr, arr.ctypes.data, arr.nbytes, None)
+        L.call("fcn_device_sync")
+
+    def set_params(self, layer: str, blobs: Sequence[np.ndarray]) -> None:
+        """Replace a layer's parameter blobs (Caffe layouts: conv OIHW + bias) and re-upload."""
+        lay = next(l for l in self.spec.layers if l.name == layer)
+        shapes = self.spec.param_shapes[layer]
+        self.params_host[layer] = [np.ascontiguousarray(b, dtype=F32).reshape(s).copy() for b, s in zip(blobs, shapes)]
+        self._upload_params(lay)
+
+    # ------------------------------------------------------------------ plan
+    def _conv_desc(self, l: Layer, fused_relu: bool, sig_top: Optional[str], pool3_src: Optional[str]) -> L.ConvDesc:
+        p = l.sub("convolution_param")
+        k, s, pad = kernel_stride_pad(p)
+        if int(p.get("group", 1)) != 1:
+            raise NotImplementedError("grouped Convolution (layer %s) is not used by the reference nets" % l.name)
+        src_name = pool3_src if pool3_src else l.bottoms[0]
+        xb, yb = self.blobs[src_name], self.blobs[l.tops[0]]
+        n, cin, h, w = xb.shape
+        _, cout, oh, ow = yb.shape
+        if xb.coffset % 4 or xb.cstride % 4:
+            raise NotImplementedError("conv input view of %s is not 16-byte aligned" % l.name)
+        d = L.ConvDesc()
+        d.x, d.w = xb.ptr, self.params_dev[l.name][0].ptr
+        d.bias = self.params_dev[l.name][1].ptr if len(self.params_dev[l.name]) > 1 else None
+        d.y = yb.buf.ptr
+        d.N, d.H, d.W, d.Cin, d.x_cstride = n, h, w, _r4(cin), xb.cstride
+        d.Cout, d.kh, d.kw, d.pad, d.stride, d.OH, d.OW = cout, k, k, pad, s, oh, ow
+        d.y_cstride, d.y_coffset = yb.cstride, yb.coffset
+        flags = 0
+        if fused_relu:
+            flags |= L.CONV_RELU
+        if sig_top:
+            sb = self.blobs[sig_top]
+            d.y2, d.y2_cstride, d.y2_coffset = sb.buf.ptr, sb.cstride, sb.coffset
+            flags |= L.CONV_SIGMOID2
+        if pool3_src:
+            flags |= L.CONV_POOL3
+        d.flags = flags
+        d.in_shift = self.blobs[l.bottoms[0]].lazy_shift if not pool3_src else 0.0
+        return d
+
+    def _build_ops(self) -> None:
+        spec, B = self.spec, self.blobs
+        layers = spec.layers
+        skip = set()
+        pending: List[Tuple[Layer, L.ConvDesc, float, float]] = []   # convs not yet emitted (grouping window)
+        pending_reads: set = set()
+        pending_writes: set = set()
+        lib = L.load()
+
+        def flush() -> None:
+            if not pending:
+                return
+            items = list(pending)
+            pending.clear()
+            pending_reads.clear()
+            pending_writes.clear()
+            name = "+".join(l.name for l, _, _, _ in items)
+            flops = sum(f for _, _, f, _ in items)
+            byts = sum(b for _, _, _, b in items)
+            if len(items) == 1:
+                desc = items[0][1]
+                self._keep.append(desc)
+                self.ops.append(Op("conv", name, lambda st, d=desc: L.check(lib.fcn_conv2d_fwd_f32(C.byref(d), st)), flops, byts))
+                return
+            arr = (L.ConvDesc * len(items))(*[d for _, d, _, _ in items])
+            ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(items))), zero=False)
+            grp = L.ConvGroup()
+            L.call("fcn_conv2d_group_prepare", arr, len(items), ws.ptr, C.byref(grp))
+            self._keep.extend([arr, ws, grp])
+            self.ops.append(Op("conv_group", name, lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
+
+        def root_of(name: str) -> Tuple[int, int, int]:
+            b = B[name]
+            return (b.buf.ptr, b.coffset, b.channels)
+
+        def overlaps(a: Tuple[int, int, int], b: Tuple[int, int, int]) -> bool:
+            return a[0] == b[0] and a[1] < b[1] + b[2] and b[1] < a[1] + a[2]
+
+        def depends_on_pending(reads: Sequence[str], writes: Sequence[str]) -> bool:
+            for r in reads:
+                rr = root_of(r)
+                if any(overlaps(rr, w) for w in pending_writes):
+                    return True
+            for wname in writes:
+                ww = root_of(wname)
+                if any(overlaps(ww, w) for w in pending_writes) or any(overlaps(ww, r) for r in pending_reads):
+                    return True
+            return False
+
+        for li, l in enumerate(layers):
+            if l.name in skip:
+                continue
+            t = l.type
+            if t in ("Data", "Python", "Input", "DummyData", "MemoryData", "ImageData", "HDF5Data"):
+                continue
+            if t == "Convolution":
+                top = l.tops[0]
+                fused_relu, sig_top = False, None
+                if self.fuse:
+                    # in-place ReLU directly after this conv
+                    for nxt in layers[li + 1:]:
+                        if top in nxt.bottoms or top in nxt.tops:
+                            if nxt.type == "ReLU" and nxt.bottoms == [top] and nxt.tops == [top] and \
+                                    float(nxt.sub("relu_param").get("negative_slope", 0.0)) == 0.0:
+                                fused_relu = True
+                                skip.add(nxt.name)
+                            break
+                    if not fused_relu:
+                        cons = self.consumers.get(top, [])
+                        if len(cons) == 1 and cons[0].type == "Sigmoid" and cons[0].tops[0] != top and \
+                                len(self.producers.get(top, [])) == 1:
+                            sig_top = cons[0].tops[0]
+                            skip.add(cons[0].name)
+                # 3x3/s1/p1 MAX pool feeding only this 1x1 conv -> fused into the loader
+                pool3_src = None
+                if self.fuse:
+                    prods = self.producers.get(l.bottoms[0], [])
+                    if len(prods) == 1 and prods[0].type == "Pooling" and len(self.consumers.get(l.bottoms[0], [])) == 1 \
+                            and l.bottoms[0] not in self.outputs:
+                        pl = prods[0]
+                        pp = pl.sub("pooling_param")
+                        pk, ps, ppad = kernel_stride_pad(pp) if not bool(pp.get("global_pooling", False)) else (0, 0, 0)
+                        ck, cs, cpad = kernel_stride_pad(l.sub("convolution_param"))
+                        if str(pp.get("pool", "MAX")) == "MAX" and (pk, ps, ppad) == (3, 1, 1) and (ck, cs, cpad) == (1, 1, 0) \
+                                and pl.name in self._fused_pools:
+                            pool3_src = pl.bottoms[0]
+                desc = self._conv_desc(l, fused_relu, sig_top, pool3_src)
+                n, cin, h, w = B[l.bottoms[0]].shape
+                _, cout, oh, ow = B[top].shape
+                k = desc.kh
+                flops = 2.0 * n * cout * oh * ow * cin * k * k
+                byts = 4.0 * (n * cin * h * w + n * cout * oh * ow + cout * cin * k * k + cout)
+                reads = [pool3_src or l.bottoms[0]]
+                writes = [top] + ([sig_top] if sig_top else [])
+                if not self.group_convs or len(pending) >= 8 or depends_on_pending(reads, writes):
+                    flush()
+                pending.append((l, desc, flops, byts))
+                pending_reads.update(root_of(r) for r in reads)
+                pending_writes.update(root_of(wn) for wn in writes)
+                self._conv_layer_meta[l.name] = dict(relu=fused_relu, sigmoid_top=sig_top, pool3=pool3_src)
+                if not self.group_convs:
+                    flush()
+                continue
+            if t == "Pooling" and l.name in self._fused_pools:
+                # materialised lazily only if somebody reads the blob; the consumer conv pools on the fly
+                continue
+            # any non-conv layer: make sure convs it depends on are emitted first
+            if t in ("Concat",) and l.name not in self.copy_concats:
+                continue      # producers already wrote their slices
+            if t == "Slice":
+                continue      # tops are views of the bottom
+            if t == "Dropout" and spec.phase == "TEST":
+                if l.tops[0] == l.bottoms[0] or l.tops[0] in self.alias:
+                    continue
+            if t == "Power" and l.tops[0] in self.shift:
+                continue      # folded into the consumer convolutions' loaders
+            flush()
+            self._emit_simple(l)
+        flush()
+
+    # pools that are only consumed by a 1x1 conv and can be fused into its loader
+    @property
+    def _fused_pools(self) -> set:
+        if hasattr(self, "_fused_pools_cache"):
+            return self._fused_pools_cache
+        out = set()
+        if self.fuse:
+            for l in self.spec.layers:
+                if l.type != "Pooling":
+                    continue
+                pp = l.sub("pooling_param")
+                if bool(pp.get("global_pooling", False)) or str(pp.get("pool", "MAX")) != "MAX":
+                    continue
+                if kernel_stride_pad(pp) != (3, 1, 1):
+                    continue
+                top = l.tops[0]
+                cons = self.consumers.get(top, [])
+                if len(cons) != 1 or cons[0].type != "Convolution" or top in self.outputs or top in self.alias:
+                    continue
+                if kernel_stride_pad(cons[0].sub("convolution_param")) != (1, 1, 0):
+                    continue
+                if self.spec.phase == "TRAIN":
+                    continue   # backward needs the pooled activations and their argmax
+                out.add(l.name)
+        self._fused_pools_cache = out
+        return out
+
+    def _emit_simple(self, l: Layer) -> None:
+        B, lib, t = self.blobs, L.load(), l.type
+        if t == "Pooling":
+            xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+            pp = l.sub("pooling_param")
+            n, c, h, w = xb.shape
+            _, _, oh, ow = yb.shape
+            if bool(pp.get("global_pooling", False)):
+                k, s, pad = h, 1, 0
+            else:
+                k, s, pad = kernel_stride_pad(pp)
+            byts = 4.0 * (xb.pixels * c + yb.pixels * c)
+            if str(pp.get("pool", "MAX")) == "MAX":
+                self.ops.append(Op("maxpool", l.name, lambda st: L.check(lib.fcn_maxpool_fwd_f32(
+                    xb.ptr, yb.buf.ptr, None, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)), 0.0, byts))
+            else:
+                self.ops.append(Op("avepool", l.name, lambda st: L.check(lib.fcn_avepool_fwd_f32(
+                    xb.ptr, yb.buf.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)), 0.0, byts))
+        elif t == "LRN":
+            xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+            p = l.sub("lrn_param")
+            if str(p.get("norm_region", "ACROSS_CHANNELS")) != "ACROSS_CHANNELS":
+                raise NotImplementedError("LRN WITHIN_CHANNEL")
+            if yb.coffset != 0:
+                raise NotImplementedError("LRN into a channel slice")
+            ls, al, be, kk = int(p.get("local_size", 5)), float(p.get("alpha", 1.0)), float(p.get("beta", 0.75)), float(p.get("k", 1.0))
+            self.ops.append(Op("lrn", l.name, lambda st: L.check(lib.fcn_lrn_fwd_f32(
+                xb.ptr, yb.ptr, None, xb.pixels, xb.channels, xb.cstride, yb.cstride, ls, al, be, kk, st)),
+                0.0, 8.0 * xb.pixels * xb.channels))
+        elif t in ("ReLU", "Sigmoid", "Power"):
+            xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+            if xb.coffset or yb.coffset or xb.cstride != yb.cstride:
+                raise NotImplementedError("%s on a channel slice (layer %s)" % (t, l.name))
+            count = xb.pixels * xb.cstride
+            if t == "ReLU":
+                ns = float(l.sub("relu_param").get("negative_slope", 0.0))
+                fn = lambda st: L.check(lib.fcn_relu_fwd_f32(xb.ptr, yb.ptr, count, ns, st))
+            elif t == "Sigmoid":
+                fn = lambda st: L.check(lib.fcn_sigmoid_fwd_f32(xb.ptr, yb.ptr, count, st))
+            else:
+                p = l.sub("power_param")
+                pw, sc, sh = float(p.get("power", 1.0)), float(p.get("scale", 1.0)), float(p.get("shift", 0.0))
+                fn = lambda st: L.check(lib.fcn_power_fwd_f32(xb.ptr, yb.ptr, count, pw, sc, sh, st))
+            self.ops.append(Op(t.lower(), l.name, fn, 0.0, 8.0 * count))
+        elif t == "Dropout":
+            if self.spec.phase != "TEST":
+                raise NotImplementedError("Dropout in TRAIN phase is handled by the training engine")
+            xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+            self.ops.append(Op("copy", l.name, lambda st: L.check(lib.fcn_copy_channels_f32(
+                xb.buf.ptr, yb.buf.ptr, xb.pixels, xb.channels, xb.cstride, xb.coffset, yb.cstride, yb.coffset, st))))
+        elif t == "Concat":
+            off = 0
+            yb = B[l.tops[0]]
+            for bn in l.bottoms:
+                xb = B[bn]
+                o = off
+                self.ops.append(Op("copy", l.name + ":" + bn, lambda st, xb=xb, o=o: L.check(lib.fcn_copy_channels_f32(
+                    xb.buf.ptr, yb.buf.ptr, xb.pixels, xb.channels, xb.cstride, xb.coffset, yb.cstride, yb.coffset + o, st)),
+                    0.0, 8.0 * xb.pixels * xb.channels))
+                off += xb.channels
+        elif t == "Eltwise":
+            p = l.sub("eltwise_param")
+            opname = str(p.get("operation", "SUM"))
+            op = {"PROD": L.ELT_PROD, "SUM": L.ELT_SUM, "MAX": L.ELT_MAX}[opname]
+            coeff = [float(c) for c in p.getall("coeff")] or [1.0] * len(l.bottoms)
+            yb = B[l.tops[0]]
+            srcs = [B[b] for b in l.bottoms]
+            for b in srcs + [yb]:
+                if not (b.coffset == 0 and b.cstride == yb.cstride):
+                    raise NotImplementedError("Eltwise on channel slices (layer %s)" % l.name)
+            count = yb.pixels * yb.cstride
+            a = srcs[0]
+            for i, b in enumerate(srcs[1:], start=1):
+                ca = coeff[0] if i == 1 else 1.0
+                self.ops.append(Op("eltwise", l.name, lambda st, a=a, b=b, ca=ca, cb=coeff[i]: L.check(lib.fcn_eltwise_fwd_f32(
+                    a.ptr, b.ptr, yb.ptr, count, op, ca, cb, st)), 0.0, 12.0 * count))
+                a = yb
+        elif t == "Deconvolution":
+            p = l.sub("convolution_param")
+            k, s, pad = kernel_stride_pad(p)
+            xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+            n, c, h, w = xb.shape
+            _, co, oh, ow = yb.shape
+            if int(p.get("group", 1)) != c or co != c:
+                raise NotImplementedError("Deconvolution %s: only group == channels == num_output" % l.name)
+            wdev = self.params_dev[l.name][0].ptr
+            bdev = self.params_dev[l.name][1].ptr if len(self.params_dev[l.name]) > 1 else None
+            self.ops.append(Op("deconv", l.name, lambda st: L.check(lib.fcn_deconv_depthwise_fwd_f32(
+                xb.ptr, wdev, bdev, yb.buf.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)),
+                2.0 * yb.pixels * c * (k / s) ** 2, 4.0 * (xb.pixels + yb.pixels) * c))
+        else:
+            raise NotImplementedError("layer type %r (layer %s) has no forward kernel yet" % (t, l.name))
+
+    # ------------------------------------------------------------------ host <-> device
+    def _stage(self, name: str) -> DeviceBuffer:
+        st = self._staging.get(name)
+        if st is None:
+            b = self.blobs[name]
+            st = DeviceBuffer(max(int(np.prod(b.shape)) if b.shape else 1, 1) * 4, zero=False)
+            self._staging[name] = st
+        return st
+
+    def host_array(self, name: str) -> np.ndarray:
+        b = self.blobs[name]
+        if b.host is None:
+            b.pinned = PinnedArray(b.shape)
+            b.host = b.pinned.array
+        return b.host
+
+    def _enqueue_upload(self, name: str, stream: Optional[int]) -> None:
+        b = self.blobs[name]
+        host = self.host_array(name)
+        lib = L.load()
+        if len(b.shape) != 4:
+            L.check(lib.fcn_memcpy_h2d_async(b.ptr, host.ctypes.data, host.nbytes, stream))
+            return
+        n, c, h, w = b.shape
+        st = self._stage(name)
+        L.check(lib.fcn_memcpy_h2d_async(st.ptr, host.ctypes.data, host.nbytes, stream))
+        L.check(lib.fcn_nchw_to_nhwc_f32(st.ptr, b.buf.ptr, n, c, h, w, b.cstride, b.coffset, stream))
+
+    def _enqueue_download(self, name: str, stream: Optional[int]) -> None:
+        b = self.blobs[name]
+        host = self.host_array(name)
+        lib = L.load()
+        if len(b.shape) != 4:
+            L.check(lib.fcn_memcpy_d2h_async(host.ctypes.data, b.ptr, host.nbytes, stream))
+            return
+        n, c, h, w = b.shape
+        st = self._stage(name)
+        L.check(lib.fcn_nhwc_to_nchw_f32(b.buf.ptr, st.ptr, n, c, h, w, b.cstride, b.coffset, stream))
+        L.check(lib.fcn_memcpy_d2h_async(host.ctypes.data, st.ptr, host.nbytes, stream))
+
+    def _materialize_fused_pool(self, name: str) -> bool:
+        """A pool blob whose kernel was folded into its consumer conv is computed on demand."""
+        for l in self.spec.layers:
+            if l.type == "Pooling" and l.name in self._fused_pools and l.tops[0] == name:
+                xb, yb = self.blobs[l.bottoms[0]], self.blobs[name]
+                n, c, h, w = xb.shape
+                L.call("fcn_maxpool_fwd_f32", xb.ptr, yb.buf.ptr, None, n, h, w, c, xb.cstride, 3, 1, 1, h, w,
+                       yb.cstride, yb.coffset, self.stream)
+                return True
+        return False
+
+    def read_blob(self, name: str) -> np.ndarray:
+        """Synchronised NCHW float32 host copy of a blob (pycaffe ``net.blobs[name].data``)."""
+        with self.lock:
+            L.call("fcn_init", self.device)
+            b = self.blobs[name]
+            host = self.host_array(name)
+            if not b.host_valid:
+                self._materialize_fused_pool(name)
+                self._enqueue_download(name, self.stream)
+                L.call("fcn_stream_sync", self.stream)
+                if b.lazy_shift:
+                    host += F32(b.lazy_shift)
+                b.host_valid = True
+            return host
+
+    # ------------------------------------------------------------------ execution
+    def run_ops(self, stream: Optional[int]) -> None:
+        for op in self.ops:
+            op.run(stream)
+
+    def _capture(self, with_io: bool) -> int:
+        L.call("fcn_graph_begin", self.stream)
+        try:
+            if with_io:
+                for nm in self.inputs:
+                    self._enqueue_upload(nm, self.stream)
+            self.run_ops(self.stream)
+            if with_io:
+                for nm in self.outputs:
+                    self._enqueue_download(nm, self.stream)
+        finally:
+            g = C.c_void_p()
+            L.call("fcn_graph_end", self.stream, C.byref(g))
+        return int(g.value)
+
+    def forward(self, use_graph: bool = True) -> Dict[str, np.ndarray]:
+        """Upload inputs, run every layer, download the output blobs (synchronous, like Net.forward())."""
+        with self.lock:
+            L.call("fcn_init", self.device)
+            for nm in self.inputs:
+                self.host_array(nm)
+            for nm in self.outputs:
+                self.host_array(nm)
+            if use_graph:
+                if self.graph_io is None:
+                    self.graph_io = self._capture(with_io=True)
+                L.call("fcn_graph_launch", self.graph_io, self.stream)
+            else:
+                for nm in self.inputs:
+                    self._enqueue_upload(nm, self.stream)
+                self.run_ops(self.stream)
+                for nm in self.outputs:
+                    self._enqueue_download(nm, self.stream)
+            L.call("fcn_stream_sync", self.stream)
+            for b in self.blobs.values():
+                b.host_valid = False
+            out = {}
+            for nm in self.outputs:
+                b = self.blobs[nm]
+                if b.lazy_shift:
+                    b.host += F32(b.lazy_shift)
+                b.host_valid = True
+                out[nm] = b.host
+            for nm in self.inputs:
+                self.blobs[nm].host_valid = True
+            return out
+
+    def upload_inputs(self) -> None:
+        with self.lock:
+            for nm in self.inputs:
+                self._enqueue_upload(nm, self.stream)
+            L.call("fcn_stream_sync", self.stream)
+
+    def forward_resident(self, iters: int = 1, use_graph: bool = True) -> float:
+        """Run the layer stack ``iters`` times on inputs already in HBM; returns HIP-event ms for all iterations."""
+        with self.lock:
+            L.call("fcn_init", self.device)
+            if use_graph and self.graph_core is None:
+                self.graph_core = self._capture(with_io=False)
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            L.call("fcn_event_create", C.byref(e0))
+            L.call("fcn_event_create", C.byref(e1))
+            L.call("fcn_event_record", e0, self.stream)
+            for _ in range(iters):
+                if use_graph:
+                    L.call("fcn_graph_launch", self.graph_core, self.stream)
+                else:
+                    self.run_ops(self.stream)
+            L.call("fcn_event_record", e1, self.stream)
+            L.call("fcn_event_sync", e1)
+            ms = C.c_float()
+            L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+            L.call("fcn_event_destroy", e0)
+            L.call("fcn_event_destroy", e1)
+            for b in self.blobs.values():
+                if not b.is_input:
+                    b.host_valid = False
+            return float(ms.value)
+
+    def time_ops(self, reps: int = 20) -> List[Tuple[str, str, float, float, float]]:
+        """Per-op HIP-event timing (ms) on the engine's stream: [(kind, name, ms, flops, bytes)]."""
+        out = []
+        with self.lock:
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            L.call("fcn_event_create", C.byref(e0))
+            L.call("fcn_event_create", C.byref(e1))
+            for op in self.ops:
+                op.run(self.stream)
+                L.call("fcn_event_record", e0, self.stream)
+                for _ in range(reps):
+                    op.run(self.stream)
+                L.call("fcn_event_record", e1, self.stream)
+                L.call("fcn_event_sync", e1)
+                ms = C.c_float()
+                L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+                out.append((op.kind, op.name, ms.value / reps, op.flops, op.bytes))
+            L.call("fcn_event_destroy", e0)
+            L.call("fcn_event_destroy", e1)
+        return out
+
+    def close(self) -> None:
+        with self.lock:
+            lib = L.load()
+            for g in (self.graph_io, self.graph_core):
+                if g:
+                    lib.fcn_graph_destroy(g)
+            self.graph_io = self.graph_core = None
+            if self.stream:
+                lib.fcn_stream_sync(self.stream)
+                lib.fcn_stream_destroy(self.stream)
+                self.stream = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,145 @@
+"""ctypes binding of libfcnhip.so (include/fcnhip.h).
+
+The shipped path has no CPU fallback: if the HIP library is missing or fails to
+load, every entry point raises :class:`FcnLibraryError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcnhip.so")
+
+
+class FcnLibraryError(RuntimeError):
+    pass
+
+
+class FcnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libfcnhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("y2", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("x_cstride", C.c_int32),
+        ("Cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("pad", C.c_int32), ("stride", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32),
+        ("y_cstride", C.c_int32), ("y_coffset", C.c_int32), ("y2_cstride", C.c_int32), ("y2_coffset", C.c_int32),
+        ("flags", C.c_int32), ("in_shift", C.c_float),
+    ]
+
+
+class ConvGroup(C.Structure):
+    _fields_ = [("d_probs", C.c_void_p), ("n", C.c_int32), ("cfg", C.c_int32), ("total_tiles", C.c_int32)]
+
+
+class DetectParams(C.Structure):
+    _fields_ = [
+        ("num_classes", C.c_int32), ("gy", C.c_int32), ("gx", C.c_int32), ("cell_w", C.c_int32), ("cell_h", C.c_int32),
+        ("cvg_cstride", C.c_int32), ("cvg_coffset", C.c_int32), ("box_cstride", C.c_int32), ("box_coffset", C.c_int32),
+        ("prob_thresh", C.c_float), ("group_thresh", C.c_int32), ("eps", C.c_double), ("min_height", C.c_int32),
+        ("round_mode", C.c_int32), ("max_out", C.c_int32),
+    ]
+
+
+CONV_RELU, CONV_SIGMOID2, CONV_POOL3 = 1, 2, 4
+ELT_PROD, ELT_SUM, ELT_MAX = 0, 1, 2
+RECT_ROUND_NEAREST_EVEN, RECT_ROUND_TRUNCATE = 0, 1
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes).  Every symbol include/fcnhip.h declares is listed here.
+PROTOTYPES = {
+    "fcn_abi_version": (_i, []),
+    "fcn_last_error_string": (C.c_char_p, []),
+    "fcn_device_count": (_i, [C.POINTER(_i)]),
+    "fcn_init": (_i, [_i]),
+    "fcn_device_name": (_i, [C.c_char_p, _i]),
+    "fcn_device_sync": (_i, []),
+    "fcn_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "fcn_free": (_i, [_vp]),
+    "fcn_host_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "fcn_host_free": (_i, [_vp]),
+    "fcn_memset_async": (_i, [_vp, _i, _sz, _vp]),
+    "fcn_memcpy_h2d_async": (_i, [_vp, _vp, _sz, _vp]),
+    "fcn_memcpy_d2h_async": (_i, [_vp, _vp, _sz, _vp]),
+    "fcn_memcpy_d2d_async": (_i, [_vp, _vp, _sz, _vp]),
+    "fcn_stream_create": (_i, [C.POINTER(_vp)]),
+    "fcn_stream_destroy": (_i, [_vp]),
+    "fcn_stream_sync": (_i, [_vp]),
+    "fcn_event_create": (_i, [C.POINTER(_vp)]),
+    "fcn_event_destroy": (_i, [_vp]),
+    "fcn_event_record": (_i, [_vp, _vp]),
+    "fcn_event_sync": (_i, [_vp]),
+    "fcn_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),
+    "fcn_graph_begin": (_i, [_vp]),
+    "fcn_graph_end": (_i, [_vp, C.POINTER(_vp)]),
+    "fcn_graph_launch": (_i, [_vp, _vp]),
+    "fcn_graph_destroy": (_i, [_vp]),
+    "fcn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_conv2d_fwd_f32": (_i, [C.POINTER(ConvDesc), _vp]),
+    "fcn_conv2d_group_workspace_bytes": (_sz, [_i]),
+    "fcn_conv2d_group_prepare": (_i, [C.POINTER(ConvDesc), _i, _vp, C.POINTER(ConvGroup)]),
+    "fcn_conv2d_fwd_group_f32": (_i, [C.POINTER(ConvGroup), _vp]),
+    "fcn_maxpool_fwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "fcn_avepool_fwd_f32": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
+    "fcn_lrn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
+    "fcn_relu_fwd_f32": (_i, [_vp, _vp, _sz, _f, _vp]),
+    "fcn_sigmoid_fwd_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "fcn_power_fwd_f32": (_i, [_vp, _vp, _sz, _f, _f, _f, _vp]),
+    "fcn_eltwise_fwd_f32": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _vp]),
+    "fcn_copy_channels_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_deconv_depthwise_fwd_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
+    "fcn_preprocess_bgr8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "fcn_detect_workspace_bytes": (_sz, [C.POINTER(DetectParams), _i]),
+    "fcn_detect_decode_group": (_i, [_vp, _vp, _i, _sz, _sz, C.POINTER(DetectParams), _vp, _vp, _vp, _vp, _vp]),
+    "fcn_gen_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """Load libfcnhip.so (once) and attach prototypes.  Raises loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise FcnLibraryError(
+                "libfcnhip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C fcn_object_detector_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        try:
+            lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+        except OSError as e:  # pragma: no cover - depends on the box
+            raise FcnLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+        for name, (res, args) in PROTOTYPES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise FcnLibraryError("libfcnhip.so lacks symbol %s (stale build?)" % name) from e
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().fcn_last_error_string()
+        raise FcnError(rc, msg.decode("utf-8", "replace") if msg else "")
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning entry point and raise :class:`FcnError` on a non-zero code."""
+    check(getattr(load(), name)(*args))

@@ -1,0 +1,331 @@
+"""pycaffe-compatible front end over the MI355X engine (fcn_object_detector_amd).
+
+Put ``<repo>/fcn_object_detector_amd/python`` on PYTHONPATH — the same way the
+reference puts ``$CAFFE_ROOT/python`` there (reference: train/train.sh:19-22) —
+and ``import caffe`` resolves to this package.  Only the surface the reference's
+hot path uses is provided:
+
+  caffe.Net(proto, weights, caffe.TEST)          fcn_object_detector.py:317
+  net.blobs[name].data / .reshape(...)            fcn_object_detector.py:82,89-90,324-328
+  net.forward()                                   fcn_object_detector.py:87
+  caffe.set_device / caffe.set_mode_gpu           fcn_object_detector.py:68-69
+  caffe.io.Transformer(...)                       fcn_object_detector.py:319-322
+  caffe.Layer (setup/reshape/forward/backward)    data_argumentation_layer.py:14-127
+
+All arithmetic runs in libfcnhip.so on the GPU; there is no CPU mode.
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import threading
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import numpy as np
+
+_PKG_PARENT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if _PKG_PARENT not in sys.path:
+    sys.path.insert(0, _PKG_PARENT)
+
+from fcn_object_detector_amd import lib as _L  # noqa: E402
+from fcn_object_detector_amd import proto as _proto  # noqa: E402
+from fcn_object_detector_amd.engine import Engine as _Engine  # noqa: E402
+from fcn_object_detector_amd.netspec import NetSpec as _NetSpec, fill_params as _fill_params  # noqa: E402
+
+from . import io  # noqa: E402,F401
+
+TRAIN = 0
+TEST = 1
+__version__ = "1.0.0-fcnhip"
+
+_state = threading.local()
+_default_device = 0
+
+
+def set_device(device_id: int) -> None:
+    """Select the GPU for the calling thread (Caffe's mode/device are thread-local as well)."""
+    global _default_device
+    _state.device = int(device_id)
+    _default_device = int(device_id)
+    _L.call("fcn_init", int(device_id))
+
+
+def set_mode_gpu() -> None:
+    _L.call("fcn_init", getattr(_state, "device", _default_device))
+
+
+def set_mode_cpu() -> None:
+    raise RuntimeError("this caffe front end has no CPU mode: the engine is libfcnhip.so on an MI355X")
+
+
+def _current_device() -> int:
+    return getattr(_state, "device", _default_device)
+
+
+class Layer(object):
+    """Base class of Python layers (``type: 'Python'``); mirrors caffe.Layer."""
+
+    def __init__(self):
+        self.param_str = ""
+        self.blobs = []
+        self.phase = TEST
+
+    def setup(self, bottom, top):
+        pass
+
+    def reshape(self, bottom, top):
+        pass
+
+    def forward(self, bottom, top):
+        pass
+
+    def backward(self, top, propagate_down, bottom):
+        pass
+
+
+class _TopProxy(object):
+    """What a Python layer sees as ``top[i]`` / ``bottom[i]``: ``reshape(*dims)`` and a float32 ``data`` array."""
+
+    def __init__(self, name: str):
+        self.name = name
+        self.shape_ = None
+        self._data = None
+        self.diff = None
+
+    def reshape(self, *dims):
+        dims = tuple(int(d) for d in (dims[0] if len(dims) == 1 and isinstance(dims[0], (tuple, list)) else dims))
+        if self.shape_ != dims:
+            self.shape_ = dims
+            if self._data is None or self._data.shape != dims:
+                self._data = np.zeros(dims, np.float32)
+
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def shape(self):
+        return self.shape_
+
+    @property
+    def num(self):
+        return self.shape_[0]
+
+    @property
+    def channels(self):
+        return self.shape_[1]
+
+    @property
+    def height(self):
+        return self.shape_[2]
+
+    @property
+    def width(self):
+        return self.shape_[3]
+
+
+class _Blob(object):
+    """``net.blobs[name]``: ``.data`` is a writable NCHW float32 array synchronised with the device."""
+
+    def __init__(self, net: "Net", name: str):
+        self._net = net
+        self._name = name
+
+    @property
+    def data(self) -> np.ndarray:
+        return self._net._blob_data(self._name)
+
+    @property
+    def shape(self):
+        return tuple(self._net._shape(self._name))
+
+    @property
+    def num(self):
+        return self.shape[0]
+
+    @property
+    def channels(self):
+        return self.shape[1]
+
+    @property
+    def height(self):
+        return self.shape[2]
+
+    @property
+    def width(self):
+        return self.shape[3]
+
+    @property
+    def count(self):
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    def reshape(self, *dims) -> None:
+        dims = tuple(int(d) for d in (dims[0] if len(dims) == 1 and isinstance(dims[0], (tuple, list)) else dims))
+        self._net._reshape_blob(self._name, dims)
+
+
+class _Param(object):
+    """``net.params[layer][i]``: Caffe-layout (OIHW / bias) host array; edits are uploaded at the next forward."""
+
+    def __init__(self, net: "Net", layer: str, index: int):
+        self._net, self._layer, self._index = net, layer, index
+
+    @property
+    def data(self) -> np.ndarray:
+        self._net._params_touched.add(self._layer)
+        return self._net._engine.params_host[self._layer][self._index]
+
+    @property
+    def shape(self):
+        return self._net._engine.params_host[self._layer][self._index].shape
+
+
+class Net(object):
+    def __init__(self, network_file, *args, **kwargs):
+        weights = kwargs.pop("weights", None)
+        phase = kwargs.pop("phase", None)
+        for a in args:
+            if isinstance(a, (int, np.integer)) and not isinstance(a, bool):
+                phase = int(a)
+            elif a is not None:
+                weights = a
+        if kwargs:
+            raise TypeError("unexpected arguments to caffe.Net: %s" % sorted(kwargs))
+        if phase is None:
+            raise TypeError("caffe.Net needs a phase (caffe.TRAIN or caffe.TEST)")
+        if not os.path.isfile(str(network_file)):
+            raise IOError("network file not found: %s" % network_file)
+        if weights is not None and not os.path.isfile(str(weights)):
+            raise IOError("weights file not found: %s" % weights)
+        self._phase = "TRAIN" if phase == TRAIN else "TEST"
+        self._proto_path = str(network_file)
+        self._msg = _proto.parse_file(self._proto_path)
+        self._device = _current_device()
+        self._lock = threading.RLock()
+        self._py_layers: List[tuple] = []
+        self._data_shapes: Dict[str, tuple] = {}
+        self._params_touched = set()
+        self._user_shapes: Dict[str, tuple] = {}
+        self._engine: Optional[_Engine] = None
+        self._setup_python_layers()
+        self._build(initial_params=None)
+        if weights is not None:
+            self.copy_from(str(weights))
+
+    # ---- construction -------------------------------------------------
+    def _setup_python_layers(self) -> None:
+        spec = _NetSpec(self._msg, self._phase)
+        for l in spec.layers:
+            if l.type != "Python":
+                continue
+            pp = l.sub("python_param")
+            mod = importlib.import_module(str(pp.get("module")))
+            cls = getattr(mod, str(pp.get("layer")))
+            inst = cls.__new__(cls)
+            Layer.__init__(inst)
+            try:
+                cls.__init__(inst)
+            except TypeError:
+                pass
+            inst.param_str = str(pp.get("param_str", ""))
+            inst.phase = TRAIN if self._phase == "TRAIN" else TEST
+            bottoms = [_TopProxy(b) for b in l.bottoms]
+            tops = [_TopProxy(t) for t in l.tops]
+            inst.setup(bottoms, tops)
+            inst.reshape(bottoms, tops)
+            for t in tops:
+                if t.shape_ is None:
+                    raise RuntimeError("Python layer %s did not reshape top %s" % (l.name, t.name))
+                self._data_shapes[t.name] = t.shape_
+            self._py_layers.append((l, inst, bottoms, tops))
+
+    def _build(self, initial_params) -> None:
+        spec = _NetSpec(self._msg, self._phase)
+        shapes = dict(self._data_shapes)
+        shapes.update(self._user_shapes)
+        params = initial_params
+        if params is None:
+            spec.infer({**spec.input_shapes, **shapes})
+            params = _fill_params(spec, seed=0)
+        self._spec = spec
+        self._engine = _Engine(spec, data_shapes=shapes, params=params, device=self._device)
+        self.blobs = OrderedDict((name, _Blob(self, name)) for name in self._engine.shapes)
+        self.params = OrderedDict(
+            (l.name, [_Param(self, l.name, i) for i in range(len(self._engine.params_host[l.name]))])
+            for l in spec.param_layers())
+        self.inputs = list(spec.input_shapes.keys())
+        self.outputs = list(self._engine.outputs)
+        self._touched_inputs = set(self._engine.inputs)
+
+    def _shape(self, name: str):
+        return self._engine.shapes[name]
+
+    def _reshape_blob(self, name: str, dims) -> None:
+        with self._lock:
+            if tuple(self._engine.shapes[name]) == tuple(dims):
+                return
+            if name not in self._engine.inputs:
+                raise ValueError("only input blobs can be reshaped (blob %r)" % name)
+            self._user_shapes[name] = tuple(dims)
+            params = {k: [a.copy() for a in v] for k, v in self._engine.params_host.items()}
+            self._engine.close()
+            self._build(initial_params=params)
+
+    def _blob_data(self, name: str) -> np.ndarray:
+        eng = self._engine
+        if name in eng.inputs:
+            self._touched_inputs.add(name)
+            return eng.host_array(name)
+        return eng.read_blob(name)
+
+    # ---- weights ------------------------------------------------------
+    def copy_from(self, weights_path: str) -> None:
+        """Load a binary .caffemodel by layer name (Net::CopyTrainedLayersFrom)."""
+        blobs = _proto.read_caffemodel(weights_path)
+        for lname, arrs in blobs.items():
+            if lname not in self._engine.params_host:
+                continue
+            want = self._engine.params_host[lname]
+            if len(arrs) != len(want):
+                raise ValueError("layer %s: caffemodel has %d blobs, net needs %d" % (lname, len(arrs), len(want)))
+            for a, w in zip(arrs, want):
+                if a.size != w.size:
+                    raise ValueError("layer %s: cannot copy param of %d elements into %s" % (lname, a.size, w.shape))
+            self._engine.set_params(lname, [a.reshape(w.shape) for a, w in zip(arrs, want)])
+
+    def save(self, path: str) -> None:
+        layers = [(l.name, l.type, self._engine.params_host[l.name]) for l in self._spec.param_layers()]
+        _proto.write_caffemodel(path, layers, self._spec.name)
+
+    # ---- execution ----------------------------------------------------
+    def forward(self, blobs=None, start=None, end=None, **kwargs) -> Dict[str, np.ndarray]:
+        if start is not None or end is not None:
+            raise NotImplementedError("partial forward (start/end) is not used by the reference")
+        with self._lock:
+            _L.call("fcn_init", self._device)
+            eng = self._engine
+            for lname in list(self._params_touched):
+                eng.set_params(lname, eng.params_host[lname])
+            self._params_touched.clear()
+            for k, v in kwargs.items():
+                if k not in eng.inputs:
+                    raise KeyError("forward(): %r is not an input blob" % k)
+                eng.host_array(k)[...] = v
+            for l, inst, bottoms, tops in self._py_layers:
+                inst.reshape(bottoms, tops)
+                inst.forward(bottoms, tops)
+                for t in tops:
+                    if tuple(t.shape_) != tuple(eng.shapes[t.name]):
+                        raise NotImplementedError("Python layer %s changed the shape of %s" % (l.name, t.name))
+                    eng.host_array(t.name)[...] = t.data
+            out = eng.forward()
+            res = {k: out[k] for k in self.outputs}
+            if blobs:
+                for b in blobs:
+                    res[b] = eng.read_blob(b)
+            return res
+
+    def backward(self, **kwargs):
+        raise NotImplementedError("Net.backward(): training runs through the `caffe train` tool")

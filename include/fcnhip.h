@@ -1,0 +1,202 @@
+/*
+ * fcnhip.h — C ABI of libfcnhip.so, the MI355X (gfx950) engine behind the
+ * pycaffe-compatible shim in fcn_object_detector_amd/python/caffe.
+ *
+ * The reference has no FFI of its own for this path: its arithmetic lives in an
+ * external Caffe install reached through pycaffe (reference:
+ * scripts/fcn_object_detector.py:9,68-69,87,317 and
+ * scripts/data_argumentation_layer/data_argumentation_layer.py:4,14) and through
+ * the `caffe train` binary (reference: train/train.sh:25-28).  Each entry point
+ * below names the Caffe/OpenCV call of the reference it stands in for.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer unless its name starts
+ *     with h_; shapes are int32; activations are NHWC float32 with an explicit
+ *     channel stride (`*_cstride`, floats per pixel) so several producers can write
+ *     channel slices of one buffer (Concat without a copy);
+ *   - every function returns 0 on success, a negative value = -hipError_t, a positive
+ *     value = argument-validation code (FCN_E_*); fcn_last_error_string() returns a
+ *     thread-local message.  Nothing aborts, nothing prints;
+ *   - everything is enqueued on the caller's stream (fcn_stream_t, may be NULL for the
+ *     default stream) and is asynchronous unless the name ends in _sync;
+ *   - the caller owns every buffer; the library keeps no pointer past a call except
+ *     inside an fcn_graph_t it was asked to capture.
+ */
+#ifndef FCNHIP_H_
+#define FCNHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCN_ABI_VERSION 1
+
+/* argument-validation codes (positive returns) */
+#define FCN_E_ARG       1   /* null pointer / non-positive extent            */
+#define FCN_E_ALIGN     2   /* channel count / stride / pointer not 16-B ok  */
+#define FCN_E_UNSUPPORTED 3 /* geometry the kernels do not implement          */
+#define FCN_E_STATE     4   /* call not valid in the current state            */
+#define FCN_E_CAPACITY  5   /* output capacity too small                      */
+
+typedef void* fcn_stream_t;
+typedef void* fcn_event_t;
+typedef void* fcn_graph_t;
+typedef void* fcn_comm_t;
+
+/* ---- runtime: replaces caffe.set_device / set_mode_gpu (fcn_object_detector.py:68-69)
+ *      and Caffe's SyncedMemory allocation + H<->D copies behind blob.data ---- */
+int  fcn_abi_version(void);
+const char* fcn_last_error_string(void);
+int  fcn_device_count(int* count);
+int  fcn_init(int device);                 /* per-thread hipSetDevice; idempotent, thread-safe */
+int  fcn_device_name(char* h_buf, int len);
+int  fcn_device_sync(void);
+int  fcn_malloc(void** p, size_t bytes);
+int  fcn_free(void* p);
+int  fcn_host_malloc(void** h_p, size_t bytes);   /* pinned host memory for blob.data views */
+int  fcn_host_free(void* h_p);
+int  fcn_memset_async(void* p, int value, size_t bytes, fcn_stream_t s);
+int  fcn_memcpy_h2d_async(void* dst, const void* h_src, size_t bytes, fcn_stream_t s);
+int  fcn_memcpy_d2h_async(void* h_dst, const void* src, size_t bytes, fcn_stream_t s);
+int  fcn_memcpy_d2d_async(void* dst, const void* src, size_t bytes, fcn_stream_t s);
+int  fcn_stream_create(fcn_stream_t* s);
+int  fcn_stream_destroy(fcn_stream_t s);
+int  fcn_stream_sync(fcn_stream_t s);
+int  fcn_event_create(fcn_event_t* e);
+int  fcn_event_destroy(fcn_event_t e);
+int  fcn_event_record(fcn_event_t e, fcn_stream_t s);
+int  fcn_event_sync(fcn_event_t e);
+int  fcn_event_elapsed_ms(fcn_event_t start, fcn_event_t stop, float* h_ms);
+/* hipGraph capture of a whole Net::Forward / ForwardBackward launch sequence */
+int  fcn_graph_begin(fcn_stream_t s);
+int  fcn_graph_end(fcn_stream_t s, fcn_graph_t* g);
+int  fcn_graph_launch(fcn_graph_t g, fcn_stream_t s);
+int  fcn_graph_destroy(fcn_graph_t g);
+
+/* ---- blob layout at the pycaffe boundary (blob.data is NCHW) ---- */
+/* dst[n,h,w,dst_coffset + c] = src[n,c,h,w]; dst channel stride dst_cstride */
+int  fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W,
+                          int dst_cstride, int dst_coffset, fcn_stream_t s);
+int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W,
+                          int src_cstride, int src_coffset, fcn_stream_t s);
+
+/* ---- Convolution (+bias, fused in-place ReLU / Sigmoid / Power shift / 3x3 s1 max-pool):
+ *      Caffe ConvolutionLayer::Forward_gpu, ReLULayer, SigmoidLayer, PowerLayer as run by
+ *      net.forward() (fcn_object_detector.py:87) over models/deploy.prototxt:8-2176 ---- */
+#define FCN_CONV_RELU      1   /* y = max(y, 0)                                  */
+#define FCN_CONV_SIGMOID2  2   /* y2 = sigmoid(y) is written as well (y2 != NULL) */
+#define FCN_CONV_POOL3     4   /* input is read through a 3x3 s1 p1 MAX pool      */
+typedef struct fcn_conv_desc {
+    const float* x;      /* NHWC input, channel stride x_cstride                           */
+    const float* w;      /* weights [Cout][kh][kw][Cin]  (OHWI, Cin contiguous)            */
+    const float* bias;   /* [Cout] or NULL                                                 */
+    float*       y;      /* NHWC output; element (m, n) at y[m*y_cstride + y_coffset + n]  */
+    float*       y2;     /* second output for FCN_CONV_SIGMOID2 (same indexing via y2_*)   */
+    int32_t N, H, W, Cin, x_cstride;
+    int32_t Cout, kh, kw, pad, stride, OH, OW;
+    int32_t y_cstride, y_coffset, y2_cstride, y2_coffset;
+    int32_t flags;
+    float   in_shift;    /* added to every in-bounds input element (Power layer, shift) */
+} fcn_conv_desc;
+/* one problem */
+int  fcn_conv2d_fwd_f32(const fcn_conv_desc* h_desc, fcn_stream_t s);
+/* n independent problems in ONE launch (the branches of an inception module).  prepare() validates
+ * and uploads the problems into d_workspace (fcn_conv2d_group_workspace_bytes(n) bytes, owned by
+ * the caller, alive as long as the group is used) with a synchronous copy - call it at plan time,
+ * not inside a graph capture; the launch itself is a pure kernel launch and can be captured. */
+typedef struct fcn_conv_group {
+    void*   d_probs;
+    int32_t n;
+    int32_t cfg;          /* tile configuration chosen by prepare() */
+    int32_t total_tiles;
+} fcn_conv_group;
+size_t fcn_conv2d_group_workspace_bytes(int n);
+int  fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, fcn_conv_group* h_out);
+int  fcn_conv2d_fwd_group_f32(const fcn_conv_group* h_group, fcn_stream_t s);
+
+/* ---- Pooling / LRN / pointwise: Caffe PoolingLayer, LRNLayer, EltwiseLayer ---- */
+/* MAX pool, ceil-mode output size computed by the caller (OH, OW), window clipped to the
+ * image, first maximum in raster order wins; idx (may be NULL) receives iy*W+ix per output */
+int  fcn_maxpool_fwd_f32(const float* x, float* y, int32_t* idx, int N, int H, int W, int C,
+                         int x_cstride, int k, int stride, int pad, int OH, int OW,
+                         int y_cstride, int y_coffset, fcn_stream_t s);
+int  fcn_avepool_fwd_f32(const float* x, float* y, int N, int H, int W, int C, int x_cstride,
+                         int k, int stride, int pad, int OH, int OW, int y_cstride, int y_coffset,
+                         fcn_stream_t s);
+/* LRN ACROSS_CHANNELS: y = x * (k + alpha/n * sum x^2)^-beta ; scale (may be NULL) keeps the base */
+int  fcn_lrn_fwd_f32(const float* x, float* y, float* scale, int pixels, int C, int x_cstride,
+                     int y_cstride, int local_size, float alpha, float beta, float k, fcn_stream_t s);
+int  fcn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, fcn_stream_t s);
+int  fcn_sigmoid_fwd_f32(const float* x, float* y, size_t count, fcn_stream_t s);
+int  fcn_power_fwd_f32(const float* x, float* y, size_t count, float power, float scale, float shift, fcn_stream_t s);
+#define FCN_ELT_PROD 0
+#define FCN_ELT_SUM  1
+#define FCN_ELT_MAX  2
+/* y = a (op) b over `count` contiguous floats; SUM uses coefficients ca, cb */
+int  fcn_eltwise_fwd_f32(const float* a, const float* b, float* y, size_t count, int op,
+                         float ca, float cb, fcn_stream_t s);
+/* copies C channels of every pixel between strided NHWC buffers (Concat / Slice fallback) */
+int  fcn_copy_channels_f32(const float* src, float* dst, int pixels, int C, int src_cstride,
+                           int src_coffset, int dst_cstride, int dst_coffset, fcn_stream_t s);
+/* grouped bilinear-style Deconvolution, group == channels, one filter [k][k] per channel:
+ * Caffe DeconvolutionLayer with `group: C` as in train/fcn_bbox/train_val.prototxt:544-565 */
+int  fcn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* bias, float* y,
+                                  int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
+                                  int OH, int OW, int y_cstride, int y_coffset, fcn_stream_t s);
+
+/* ---- inference pre-processing: demean_rgb_image + cv.resize + HWC->CHW
+ *      (fcn_object_detector.py:79-82, 407-413) ---- */
+/* h/w x 3 uint8 BGR frame -> NHWC float32 (C padded to dst_cstride) in [0,1]:
+ * (px - mean[c] - min) / (max - min) over the whole frame, then bilinear resize to (H, W).
+ * d_minmax is a 32-byte device scratch (per-channel uint8 min and max, as int32). */
+int  fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride,
+                         float* d_minmax, fcn_stream_t s);
+
+/* ---- DetectNet post-processing: gridbox_to_boxes + vote_boxes -> cv.groupRectangles
+ *      (fcn_object_detector.py:337-394; OpenCV 3 objdetect groupRectangles/partition) ---- */
+#define FCN_RECT_ROUND_NEAREST_EVEN 0  /* OpenCV vector<Rect> converter: saturate_cast<int>(double) = cvRound */
+#define FCN_RECT_ROUND_TRUNCATE     1  /* C (int) cast                                                          */
+typedef struct fcn_detect_params {
+    int32_t num_classes;     /* C : coverage channels decoded                                  */
+    int32_t gy, gx;          /* grid                                                            */
+    int32_t cell_w, cell_h;  /* im_sz / grid (integer division, fcn_object_detector.py:368-369) */
+    int32_t cvg_cstride, cvg_coffset;   /* NHWC coverage map: cvg[(y*gx+x)*cvg_cstride + cvg_coffset + c] */
+    int32_t box_cstride, box_coffset;   /* NHWC bbox map, channels 4c..4c+3 of class c                     */
+    float   prob_thresh;     /* ~detection_threshold (0.5)   */
+    int32_t group_thresh;    /* ~min_boxes (3)               */
+    double  eps;             /* ~nms_eps (0.2); OpenCV takes it as a double */
+    int32_t min_height;      /* 20: keep if rect[3]-rect[1] >= min_height (fcn_object_detector.py:346) */
+    int32_t round_mode;      /* FCN_RECT_ROUND_*             */
+    int32_t max_out;         /* capacity of the output arrays per (image, class) slot */
+} fcn_detect_params;
+/* One workgroup per (image, class); slot = image * num_classes + class.  Outputs per slot:
+ * out_rects[slot][max_out][4] int32 (x, y, w, h exactly as groupRectangles returns them, in its
+ * cluster order), out_weights[slot][max_out] int32 (cluster size n; the reference's confidence is
+ * log(n)), out_count[slot] int32 (may exceed max_out: then only max_out entries were stored).
+ * Concatenating the slots of one image in class order reproduces the reference's nested loops
+ * (fcn_object_detector.py:104-118).  Grids up to 4096 cells.  d_workspace:
+ * fcn_detect_workspace_bytes() bytes; image strides are in floats. */
+size_t fcn_detect_workspace_bytes(const fcn_detect_params* h_p, int batch);
+int  fcn_detect_decode_group(const float* cvg, const float* bbox, int batch,
+                             size_t cvg_image_stride, size_t box_image_stride,
+                             const fcn_detect_params* h_p, void* d_workspace,
+                             int32_t* out_rects, int32_t* out_weights,
+                             int32_t* out_count, fcn_stream_t s);
+
+/* ---- DetectNet target generation: ArgumentationEngine.bounding_box_parameterized_labels
+ *      (argumentation_engine.py:69-109, 26-55, 272-292) ---- */
+/* rects: [total][4] int32 (x, y, w, h); labels: [total] int32; rect_offsets: [batch+1] int32 prefix.
+ * Outputs are NCHW float32 exactly as the Python layer's tops (data_argumentation_layer.py:67-72):
+ * foreground (batch, C, gy, gx); bbox/size/obj/cvg_block (batch, 4C, gy, gx). */
+int  fcn_gen_targets(const int32_t* rects, const int32_t* labels, const int32_t* rect_offsets, int batch,
+                     int num_classes, int gy, int gx, int stride, double iou_thresh,
+                     float* foreground, float* bbox, float* size, float* obj, float* cvg_block,
+                     fcn_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCNHIP_H_ */

@@ -1,0 +1,268 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Parity unpinned (see below).
+
+CPU restatement (numpy / OpenBLAS) of the Caffe layer semantics that the
+reference's hot path executes inside an external, un-vendored NVIDIA-Caffe
+install (reference: scripts/fcn_object_detector.py:87 ``net.forward()`` on
+models/deploy.prototxt; train/train.sh:25-28 ``caffe train``).  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this package; the shipped package ``fcn_object_detector_amd`` never does.
+
+PARITY UNPINNED: the reference has no tests, golden vectors or fixtures
+ and neither Caffe nor OpenCV can be run here, so this file
+restates the *published* BVLC/NVIDIA-Caffe algorithms layer by layer — the same
+schedule Caffe's CPU path runs (im2col + sgemm per conv, separate bias add,
+ReLU pass, ceil-mode pooling, across-channel LRN, concat copy).  Its layer ops
+are cross-checked against torch CPU functional ops in tests/test_oracle.py.
+
+All tensors are NCHW float32, like pycaffe blobs.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# shape rules
+# --------------------------------------------------------------------------
+
+def conv_out(h: int, k: int, p: int, s: int) -> int:
+    """Caffe ConvolutionLayer::compute_output_shape: floor((H + 2p - k) / s) + 1."""
+    return (h + 2 * p - k) // s + 1
+
+
+def pool_out(h: int, k: int, p: int, s: int) -> int:
+    """Caffe PoolingLayer::Reshape: ceil((H + 2p - k) / s) + 1, minus one if the
+    last window would start in the bottom/right padding."""
+    o = int(math.ceil((h + 2 * p - k) / float(s))) + 1
+    if p > 0 and (o - 1) * s >= h + p:
+        o -= 1
+    return o
+
+
+def deconv_out(h: int, k: int, p: int, s: int) -> int:
+    """Caffe DeconvolutionLayer::compute_output_shape: s (H - 1) + k - 2p."""
+    return s * (h - 1) + k - 2 * p
+
+
+# --------------------------------------------------------------------------
+# forward ops
+# --------------------------------------------------------------------------
+
+def im2col(x: np.ndarray, kh: int, kw: int, ph: int, pw: int, sh: int, sw: int) -> np.ndarray:
+    """(C,H,W) -> (C*kh*kw, OH*OW), zero padding, row order (c, r, q) as Caffe's im2col_cpu."""
+    c, h, w = x.shape
+    oh, ow = conv_out(h, kh, ph, sh), conv_out(w, kw, pw, sw)
+    xp = np.zeros((c, h + 2 * ph, w + 2 * pw), dtype=x.dtype)
+    xp[:, ph:ph + h, pw:pw + w] = x
+    s0, s1, s2 = xp.strides
+    win = np.lib.stride_tricks.as_strided(
+        xp, shape=(c, kh, kw, oh, ow), strides=(s0, s1, s2, s1 * sh, s2 * sw), writeable=False)
+    return np.ascontiguousarray(win).reshape(c * kh * kw, oh * ow)
+
+
+def conv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], pad: int, stride: int, group: int = 1) -> np.ndarray:
+    """Caffe Convolution forward: per image, per group: W_g (Cout/g, Cin/g*kh*kw) @ im2col; then + bias."""
+    n, cin, h, wd = x.shape
+    cout, cin_g, kh, kw = w.shape
+    assert cin_g * group == cin and cout % group == 0
+    oh, ow = conv_out(h, kh, pad, stride), conv_out(wd, kw, pad, stride)
+    y = np.empty((n, cout, oh, ow), dtype=F32)
+    cog = cout // group
+    for i in range(n):
+        for g in range(group):
+            col = im2col(x[i, g * cin_g:(g + 1) * cin_g], kh, kw, pad, pad, stride, stride)
+            wg = w[g * cog:(g + 1) * cog].reshape(cog, cin_g * kh * kw)
+            y[i, g * cog:(g + 1) * cog] = (wg @ col).reshape(cog, oh, ow)
+    if b is not None:
+        y += b.reshape(1, cout, 1, 1)
+    return y
+
+
+def deconv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], pad: int, stride: int, group: int = 1) -> np.ndarray:
+    """Caffe Deconvolution forward: col = W_g^T @ x_g, then col2im (scatter-add).
+    Weight blob shape (Cin, Cout/g, kh, kw)."""
+    n, cin, h, wd = x.shape
+    cin_w, cog, kh, kw = w.shape
+    assert cin_w == cin and cin % group == 0
+    cout = cog * group
+    cig = cin // group
+    oh, ow = deconv_out(h, kh, pad, stride), deconv_out(wd, kw, pad, stride)
+    y = np.zeros((n, cout, oh + 2 * pad, ow + 2 * pad), dtype=F32)
+    for i in range(n):
+        for g in range(group):
+            wg = w[g * cig:(g + 1) * cig].reshape(cig, cog * kh * kw)
+            col = (wg.T @ x[i, g * cig:(g + 1) * cig].reshape(cig, h * wd)).reshape(cog, kh, kw, h, wd)
+            for r in range(kh):
+                for q in range(kw):
+                    y[i, g * cog:(g + 1) * cog, r:r + stride * h:stride, q:q + stride * wd:stride] += col[:, r, q]
+    y = y[:, :, pad:pad + oh, pad:pad + ow]
+    if b is not None:
+        y = y + b.reshape(1, cout, 1, 1)
+    return np.ascontiguousarray(y, dtype=F32)
+
+
+def relu(x: np.ndarray, negative_slope: float = 0.0) -> np.ndarray:
+    return np.maximum(x, 0) + F32(negative_slope) * np.minimum(x, 0) if negative_slope else np.maximum(x, 0)
+
+
+def sigmoid(x: np.ndarray) -> np.ndarray:
+    """Caffe SigmoidLayer: 0.5 * tanh(0.5 x) + 0.5 (== 1 / (1 + exp(-x)))."""
+    return (0.5 * np.tanh(0.5 * x.astype(np.float64)) + 0.5).astype(F32)
+
+
+def power(x: np.ndarray, power_: float = 1.0, scale: float = 1.0, shift: float = 0.0) -> np.ndarray:
+    """Caffe PowerLayer: (shift + scale * x) ^ power."""
+    y = x * F32(scale) + F32(shift)
+    return y if power_ == 1.0 else np.power(y, F32(power_))
+
+
+def max_pool(x: np.ndarray, k: int, s: int, p: int, return_index: bool = False):
+    """Caffe PoolingLayer MAX: window clipped to the image, first maximum in raster order wins
+    (`>` compare, initial -FLT_MAX)."""
+    n, c, h, w = x.shape
+    oh, ow = pool_out(h, k, p, s), pool_out(w, k, p, s)
+    y = np.full((n, c, oh, ow), -np.finfo(F32).max, dtype=F32)
+    idx = np.full((n, c, oh, ow), -1, dtype=np.int64)
+    for r in range(k):
+        for q in range(k):
+            # output positions whose window element (r,q) falls inside the image
+            oy = np.arange(oh)
+            ox = np.arange(ow)
+            iy = oy * s - p + r
+            ix = ox * s - p + q
+            vy = (iy >= 0) & (iy < h)
+            vx = (ix >= 0) & (ix < w)
+            if not vy.any() or not vx.any():
+                continue
+            oy, iy, ox, ix = oy[vy], iy[vy], ox[vx], ix[vx]
+            cand = x[:, :, iy[:, None], ix[None, :]]
+            cur = y[:, :, oy[:, None], ox[None, :]]
+            take = cand > cur
+            y[:, :, oy[:, None], ox[None, :]] = np.where(take, cand, cur)
+            if return_index:
+                flat = (iy[:, None] * w + ix[None, :])[None, None]
+                ci = idx[:, :, oy[:, None], ox[None, :]]
+                idx[:, :, oy[:, None], ox[None, :]] = np.where(take, flat, ci)
+    return (y, idx) if return_index else y
+
+
+def ave_pool(x: np.ndarray, k: int, s: int, p: int) -> np.ndarray:
+    """Caffe PoolingLayer AVE: divisor is the window area clipped to H+p (includes padding),
+    the sum runs over the part inside the image."""
+    n, c, h, w = x.shape
+    oh, ow = pool_out(h, k, p, s), pool_out(w, k, p, s)
+    y = np.zeros((n, c, oh, ow), dtype=F32)
+    for py in range(oh):
+        hs = py * s - p
+        he = min(hs + k, h + p)
+        for px in range(ow):
+            ws = px * s - p
+            we = min(ws + k, w + p)
+            size = (he - hs) * (we - ws)
+            a, b_, c_, d = max(hs, 0), min(he, h), max(ws, 0), min(we, w)
+            y[:, :, py, px] = x[:, :, a:b_, c_:d].sum(axis=(2, 3), dtype=F32) / F32(size)
+    return y
+
+
+def lrn_across(x: np.ndarray, local_size: int, alpha: float, beta: float, k: float = 1.0,
+               return_scale: bool = False):
+    """Caffe LRNLayer ACROSS_CHANNELS: scale = k + alpha/n * sum_{c' in window} x^2 (zero padded),
+    y = x * scale^-beta."""
+    n, c, h, w = x.shape
+    pre = (local_size - 1) // 2
+    sq = np.zeros((n, c + local_size - 1, h, w), dtype=F32)
+    sq[:, pre:pre + c] = x * x
+    acc = np.zeros_like(x)
+    for j in range(local_size):
+        acc += sq[:, j:j + c]
+    scale = F32(k) + F32(alpha / local_size) * acc
+    y = (x * np.power(scale, F32(-beta))).astype(F32)
+    return (y, scale) if return_scale else y
+
+
+def softmax(x: np.ndarray, axis: int = 1) -> np.ndarray:
+    m = x.max(axis=axis, keepdims=True)
+    e = np.exp(x - m)
+    return (e / e.sum(axis=axis, keepdims=True)).astype(F32)
+
+
+def eltwise(xs: Sequence[np.ndarray], op: str = "SUM", coeff: Optional[Sequence[float]] = None) -> np.ndarray:
+    if op == "PROD":
+        y = xs[0] * xs[1]
+        for t in xs[2:]:
+            y = y * t
+        return y.astype(F32)
+    if op == "SUM":
+        cf = list(coeff) if coeff else [1.0] * len(xs)
+        y = F32(cf[0]) * xs[0]
+        for c_, t in zip(cf[1:], xs[1:]):
+            y = y + F32(c_) * t
+        return y.astype(F32)
+    if op == "MAX":
+        y = xs[0]
+        for t in xs[1:]:
+            y = np.maximum(y, t)
+        return y.astype(F32)
+    raise ValueError(op)
+
+
+# --------------------------------------------------------------------------
+# losses (forward value, and gradient w.r.t. the first bottom for loss_weight w)
+# --------------------------------------------------------------------------
+
+def l1_loss(a: np.ndarray, b: np.ndarray) -> float:
+    """NVIDIA-Caffe L1LossLayer: sum |a - b| / num."""
+    return float(np.abs(a.astype(np.float64) - b).sum() / a.shape[0])
+
+
+def l1_loss_grad(a: np.ndarray, b: np.ndarray, w: float = 1.0) -> np.ndarray:
+    return (np.sign(a - b) * F32(w / a.shape[0])).astype(F32)
+
+
+def euclidean_loss(a: np.ndarray, b: np.ndarray) -> float:
+    """Caffe EuclideanLossLayer: sum (a - b)^2 / (2 num)."""
+    d = a.astype(np.float64) - b
+    return float((d * d).sum() / (2.0 * a.shape[0]))
+
+
+def euclidean_loss_grad(a: np.ndarray, b: np.ndarray, w: float = 1.0) -> np.ndarray:
+    return ((a - b) * F32(w / a.shape[0])).astype(F32)
+
+
+def softmax_loss(x: np.ndarray, label: np.ndarray, normalize: bool = True,
+                 ignore_label: Optional[int] = None) -> float:
+    """Caffe SoftmaxWithLoss (legacy `normalize` flag): -sum log p[label] / (count_valid if normalize else N)."""
+    p = softmax(x, 1).astype(np.float64)
+    n, c = x.shape[:2]
+    lab = label.reshape(n, -1).astype(np.int64)
+    pr = p.reshape(n, c, -1)
+    loss, cnt = 0.0, 0
+    for i in range(n):
+        for j in range(lab.shape[1]):
+            l_ = lab[i, j]
+            if ignore_label is not None and l_ == ignore_label:
+                continue
+            loss -= math.log(max(pr[i, l_, j], np.finfo(F32).tiny))
+            cnt += 1
+    return loss / (max(cnt, 1) if normalize else n)
+
+
+# --------------------------------------------------------------------------
+# fillers (Caffe filler.hpp)
+# --------------------------------------------------------------------------
+
+def bilinear_filler(shape: Tuple[int, int, int, int]) -> np.ndarray:
+    """Caffe BilinearFiller: f = ceil(k/2), c = (2f - 1 - f%2) / (2f), w[y,x] = (1-|x/f-c|)(1-|y/f-c|)."""
+    n, c, kh, kw = shape
+    assert kh == kw
+    f = int(math.ceil(kw / 2.0))
+    cc = (2 * f - 1 - f % 2) / (2.0 * f)
+    xs = np.arange(kw)
+    k1 = 1 - np.abs(xs / f - cc)
+    ker = np.outer(k1, k1).astype(F32)
+    return np.broadcast_to(ker, shape).copy()

@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PYCAFFE = os.path.join(ROOT, "fcn_object_detector_amd", "python")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MODELS = os.path.join(ROOT, "tests", "golden", "nets")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available() -> bool:
+    try:
+        from fcn_object_detector_amd import lib as L
+        import ctypes as C
+        n = C.c_int(0)
+        if L.load().fcn_device_count(C.byref(n)) != 0:
+            return False
+        return n.value > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """GPU tests fail loudly (not skip) when selected with -m gpu but the HIP library/device is missing."""
+    from fcn_object_detector_amd import lib as L
+    L.load()
+    if not _gpu_available():
+        pytest.fail("no HIP device visible — -m gpu tests must run on the MI355X box")
+    L.call("fcn_init", 0)
+    return True
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))

@@ -1,0 +1,137 @@
+"""Bit-exact GPU parity of decode + groupRectangles, target generation and pre-processing vs the oracle (-m gpu)."""
+import numpy as np
+import pytest
+
+from fcn_object_detector_amd import lib as L
+from fcn_object_detector_amd import models, proto
+from fcn_object_detector_amd.detector import FCNObjectDetector, HeadMapping, detect_from_maps, generate_targets
+from fcn_object_detector_amd.engine import Engine
+from fcn_object_detector_amd.netspec import NetSpec, fill_params
+from oracle import detect_ref as D
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_maps(rng, n, c, gy, gx, stride, n_obj=3, noise=0.08):
+    """Coverage blobs around a few objects + box regressions pointing at them with jitter (what a trained head emits)."""
+    cvg = (rng.random((n, c, gy, gx)) * noise).astype(np.float32)
+    bb = (rng.standard_normal((n, 4 * c, gy, gx)) * 2).astype(np.float32)
+    for i in range(n):
+        for _ in range(n_obj):
+            k = int(rng.integers(0, c))
+            w, h = rng.integers(3 * stride, 9 * stride, 2)
+            x0 = int(rng.integers(0, gx * stride - w)); y0 = int(rng.integers(0, gy * stride - h))
+            for cy in range(y0 // stride, min((y0 + h) // stride + 1, gy)):
+                for cx in range(x0 // stride, min((x0 + w) // stride + 1, gx)):
+                    cvg[i, k, cy, cx] = 0.5 + 0.5 * rng.random()
+                    j = rng.standard_normal(4) * 2.5
+                    bb[i, 4 * k:4 * k + 4, cy, cx] = [x0 - cx * stride + j[0], y0 - cy * stride + j[1],
+                                                     x0 + w - cx * stride + j[2], y0 + h - cy * stride + j[3]]
+    return cvg, bb
+
+
+def check(cvg, bb, im, stride, **kw):
+    got = detect_from_maps(cvg, bb, im, im, **{k: v for k, v in kw.items() if k != "mode"},
+                           round_mode=L.RECT_ROUND_TRUNCATE if kw.get("mode") == "trunc" else L.RECT_ROUND_NEAREST_EVEN)
+    total = 0
+    for i in range(len(cvg)):
+        rdet, rlab = D.detect(cvg[i], bb[i], im, im, stride, kw.get("prob_thresh", 0.5), kw.get("min_boxes", 3), kw.get("eps", 0.2),
+                              "trunc" if kw.get("mode") == "trunc" else "nearest_even", fast=True)
+        assert np.array_equal(got[i][1], rlab)
+        assert np.array_equal(got[i][0], rdet)          # ints and log(n) bit-for-bit
+        total += len(rdet)
+    return total
+
+
+@pytest.mark.parametrize("c,grid,stride", [(4, 28, 16), (10, 56, 8), (1, 28, 16)])
+def test_detect_random_scenes(gpu, c, grid, stride):
+    rng = np.random.default_rng(100 + c)
+    n_det = 0
+    for trial in range(6):
+        cvg, bb = synth_maps(rng, 2, c, grid, grid, stride, n_obj=4)
+        n_det += check(cvg, bb, grid * stride, stride)
+        n_det += check(cvg, bb, grid * stride, stride, mode="trunc")
+    assert n_det > 10                      # the scenes really produce clusters
+
+
+def test_detect_thresholds_and_eps(gpu):
+    rng = np.random.default_rng(7)
+    cvg, bb = synth_maps(rng, 1, 3, 28, 28, 16, n_obj=5)
+    for kw in (dict(prob_thresh=0.3), dict(prob_thresh=0.75, min_boxes=1), dict(eps=0.05), dict(eps=0.6, min_boxes=2),
+               dict(min_boxes=0), dict(min_boxes=10)):
+        check(cvg, bb, 448, 16, **kw)
+
+
+def test_detect_edge_cases(gpu):
+    z = np.zeros((1, 2, 28, 28), np.float32)
+    zb = np.zeros((1, 8, 28, 28), np.float32)
+    assert check(z, zb, 448, 16) == 0                                   # nothing above threshold
+    one = z.copy(); one[0, 0, 0, 0] = 1.0
+    assert check(one, zb, 448, 16) == 0                                 # one candidate, all-zero box: `.any()` early-out
+    full = np.ones((1, 1, 56, 56), np.float32)                          # all 3136 cells positive: worst case O(M^2)
+    rng = np.random.default_rng(9)
+    fb = (rng.standard_normal((1, 4, 56, 56)) * 6).astype(np.float32)
+    fb[0, 2:] += 40
+    check(full, fb, 448, 8)
+    # half-way coordinates exercise round-half-even vs truncation
+    half = np.zeros((1, 1, 28, 28), np.float32); hb = np.zeros((1, 4, 28, 28), np.float32)
+    half[0, 0, 4, 4:9] = 0.9
+    for i, cx in enumerate(range(4, 9)):
+        hb[0, :, 4, cx] = [10.5 - 16 * i, 3.5, 90.5 - 16 * i, 61.5]
+    assert check(half, hb, 448, 16) == 1 and check(half, hb, 448, 16, mode="trunc") == 1
+
+
+def test_targets_kats_and_random(gpu):
+    fg, bl, sl, ol, cl = generate_targets([[(100, 120, 80, 60)]], [[0]], 448, 448, 16, 1)
+    assert int(fg.sum()) == 28 and bl[0, :, 8, 7].tolist() == [-12.0, -8.0, 68.0, 52.0]
+    out = generate_targets([[(40, 64, 120, 200), (300, 310, 64, 48)]], [[3, 10]], 448, 448, 8, 11)
+    assert [int(out[0][0, c].sum()) for c in range(11)] == [0, 0, 0, 375, 0, 0, 0, 0, 0, 0, 63]
+    assert out[1].sum() == 7260.0 and out[4].sum() == 1752
+    rng = np.random.default_rng(42)
+    for (im, stride, C, batch) in [(448, 16, 1, 8), (288, 8, 11, 4), (224, 16, 3, 5)]:
+        rects, labels = [], []
+        for b in range(batch):
+            n = int(rng.integers(0, 4))                                    # includes images without boxes
+            rs = []
+            for _ in range(n):
+                w, h = rng.integers(8, im // 2, 2)
+                rs.append((int(rng.integers(-10, im - w + 10)), int(rng.integers(-10, im - h + 10)), int(w), int(h)))
+            rects.append(rs); labels.append([int(v) for v in rng.integers(0, C, n)])
+        got = generate_targets(rects, labels, im, im, stride, C)
+        for b in range(batch):
+            ref = D.bounding_box_parameterized_labels(im, im, rects[b], labels[b], stride, C)
+            for g, r in zip(got, ref):
+                assert np.array_equal(g[b], r.astype(np.float32))          # bit-exact incl. later-rect-overwrites
+
+
+def test_targets_overlapping_rects_last_wins(gpu):
+    rects = [[(100, 100, 120, 120), (130, 110, 100, 90)]]
+    got = generate_targets(rects, [[0, 0]], 448, 448, 16, 1)
+    ref = D.bounding_box_parameterized_labels(448, 448, rects[0], [0, 0], 16, 1)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g[0], r.astype(np.float32))
+    with pytest.raises(IndexError):
+        generate_targets(rects, [[0, 5]], 448, 448, 16, 1)
+
+
+@pytest.mark.parametrize("h,w", [(448, 448), (480, 640), (300, 517)])
+def test_node_pipeline_matches_oracle(gpu, h, w):
+    """uint8 frame -> device pre-processing -> forward -> device decode/group == oracle on the same frame."""
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(1, 448, 448, 4))
+    spec = NetSpec(msg, "TEST"); spec.infer()
+    params = fill_params(spec, seed=1234)
+    eng = Engine(NetSpec(msg, "TEST"), params=params, device=0)
+    det = FCNObjectDetector(eng, 0.5, 3, 0.2, HeadMapping.detectnet_deploy())
+    frame = np.random.default_rng(h).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    boxes, labels = det.run_detector(frame)
+    blob = D.preprocess_frame(frame, 448, 448)
+    got = eng.read_blob("data")[0]
+    assert np.abs(got - blob).max() <= 2e-7                                # pre-processing parity (f64 math, f32 store)
+    # post-processing is checked bit-exactly on the maps the GPU produced
+    cvg, bb = eng.read_blob("coverage")[0], eng.read_blob("bboxes")[0]
+    rdet, rlab = D.detect(cvg, bb, 448, 448, 16, 0.5, 3, 0.2, fast=True)
+    rbox = np.asarray(rdet, dtype=np.int64).reshape(-1, 5)
+    if len(rbox):
+        rbox = D.resize_detection(frame.shape, rbox, 448, 448)
+    assert np.array_equal(boxes, rbox) and np.array_equal(labels, rlab)
+    eng.close()

@@ -1,0 +1,245 @@
+"""GPU parity of every HIP kernel family against the CPU oracle, through the C ABI (run with -m gpu).
+Tolerance: 1e-3 relative (north_star) is the bar; the f32 matrix-core path is expected within 1e-4."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from fcn_object_detector_amd import lib as L
+from fcn_object_detector_amd.engine import DeviceBuffer
+from gpu_util import conv_desc, dev_from, dev_to, nchw, nhwc, pack_ohwi
+from oracle import caffe_ref as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def run_conv(x, w, b, pad, stride, flags=0, in_shift=0.0, y_cstride=None, y_coffset=0, x_cstride=None, want_y2=False):
+    n, cin, h, wd = x.shape
+    cout, _, k, _ = w.shape
+    oh, ow = R.conv_out(h, k, pad, stride), R.conv_out(wd, k, pad, stride)
+    cin4 = (cin + 3) // 4 * 4
+    xcs = x_cstride or cin4
+    ycs = y_cstride or cout
+    xd = dev_from(nhwc(x, xcs))
+    wdv = dev_from(pack_ohwi(w))
+    bd = dev_from(b) if b is not None else None
+    yd = dev_from(np.full((n, oh, ow, ycs), -7.0, np.float32))
+    y2d = dev_from(np.zeros((n, oh, ow, cout), np.float32)) if want_y2 else None
+    d = conv_desc(xd, wdv, bd, yd, n, h, wd, cin4, xcs, cout, k, pad, stride, oh, ow, ycs, y_coffset, flags, in_shift,
+                  y2d, cout if want_y2 else 0, 0)
+    L.call("fcn_conv2d_fwd_f32", C.byref(d), None)
+    yfull = dev_to(yd, (n, oh, ow, ycs))
+    y = nchw(yfull, cout, y_coffset)
+    if want_y2:
+        return y, nchw(dev_to(y2d, (n, oh, ow, cout)), cout), yfull
+    return y, yfull
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, h, w, n
+    (3, 64, 7, 2, 3, 61, 45, 1),       # conv1 geometry (Cin 3 padded to 4), odd sizes
+    (64, 64, 1, 1, 0, 28, 28, 1),
+    (64, 192, 3, 1, 1, 23, 19, 1),
+    (16, 32, 5, 1, 2, 17, 28, 1),      # Cin 16: several taps per 32-wide k chunk
+    (24, 64, 5, 1, 2, 14, 14, 2),      # Cin 24: taps straddle chunk boundaries
+    (192, 48, 1, 1, 0, 9, 11, 1),
+    (112, 33, 3, 1, 1, 12, 7, 1),      # Cout not a multiple of 32
+    (832, 384, 1, 1, 0, 7, 7, 1),
+    (144, 288, 3, 1, 1, 28, 28, 1),    # real inception_4d/3x3
+    (1024, 4, 1, 1, 0, 28, 28, 1),     # coverage head
+    (8, 8, 3, 2, 0, 15, 15, 3),        # stride 2 without padding, batch 3
+]
+
+
+@pytest.mark.parametrize("cfg", ["0", "1", "2", "3", "4", "5", None])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_matches_oracle(gpu, monkeypatch, case, cfg):
+    cin, cout, k, s, p, h, w, n = case
+    if cfg is None:
+        monkeypatch.delenv("FCN_CONV_CFG", raising=False)
+    else:
+        monkeypatch.setenv("FCN_CONV_CFG", cfg)
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    y, _ = run_conv(x, wt, b, p, s)
+    ref = R.conv2d(x, wt, b, p, s)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < TOL
+
+
+def test_conv_asymmetric_identity_layout(gpu):
+    """A = I check with an asymmetric weight matrix: catches a transposed C/D write."""
+    cin = cout = 64
+    x = np.zeros((1, cin, 8, 8), np.float32)
+    for i in range(64):
+        x[0, i, i // 8, i % 8] = 1.0                    # pixel i carries channel i
+    wt = (np.arange(cout * cin, dtype=np.float32).reshape(cout, cin, 1, 1) % 251) / 16.0
+    y, _ = run_conv(x, wt, None, 0, 1)
+    assert np.array_equal(y.reshape(cout, 64), wt.reshape(cout, cin))   # y[o, pixel i] = W[o, i]
+
+
+def test_conv_epilogue_relu_slice_and_shift(gpu):
+    rng = np.random.default_rng(5)
+    x = rng.random((1, 3, 20, 20)).astype(np.float32)
+    wt = rng.standard_normal((40, 3, 7, 7)).astype(np.float32) * 0.05
+    b = rng.standard_normal(40).astype(np.float32)
+    # Power(shift=-127) fused into the loader: padding stays zero AFTER the shift (models/deploy.prototxt:8-16)
+    y, yfull = run_conv(x, wt, b, 3, 2, flags=L.CONV_RELU, in_shift=-127.0, y_cstride=96, y_coffset=24)
+    ref = R.relu(R.conv2d(R.power(x, shift=-127.0), wt, b, 3, 2))
+    assert rel_err(y, ref) < TOL
+    assert np.all(yfull[..., :24] == -7.0) and np.all(yfull[..., 64:] == -7.0)      # neighbours of the slice untouched
+
+
+def test_conv_sigmoid_second_output(gpu):
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((2, 64, 6, 6)).astype(np.float32)
+    wt = rng.standard_normal((4, 64, 1, 1)).astype(np.float32) * 0.2
+    b = np.zeros(4, np.float32)
+    y, y2, _ = run_conv(x, wt, b, 0, 1, flags=L.CONV_SIGMOID2, want_y2=True)
+    ref = R.conv2d(x, wt, b, 0, 1)
+    assert rel_err(y, ref) < TOL and np.abs(y2 - R.sigmoid(ref)).max() < 1e-5
+
+
+def test_conv_fused_maxpool3_loader(gpu):
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((1, 48, 13, 10)).astype(np.float32)
+    wt = rng.standard_normal((32, 48, 1, 1)).astype(np.float32) * 0.1
+    b = rng.standard_normal(32).astype(np.float32)
+    y, _ = run_conv(x, wt, b, 0, 1, flags=L.CONV_POOL3 | L.CONV_RELU)
+    ref = R.relu(R.conv2d(R.max_pool(x, 3, 1, 1), wt, b, 0, 1))
+    assert rel_err(y, ref) < TOL
+
+
+def test_conv_group_launch(gpu):
+    """Four independent problems (an inception module's branch entries) in one launch."""
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((1, 192, 14, 14)).astype(np.float32)
+    xd = dev_from(nhwc(x))
+    couts, ks = [64, 96, 16, 32], [1, 1, 1, 3]
+    ws = [(rng.standard_normal((co, 192, k, k)) * 0.05).astype(np.float32) for co, k in zip(couts, ks)]
+    bs = [rng.standard_normal(co).astype(np.float32) for co in couts]
+    total = sum(couts)
+    yd = dev_from(np.zeros((1, 14, 14, total), np.float32))
+    keep, descs, off = [], [], 0
+    for wt, b, co, k in zip(ws, bs, couts, ks):
+        wd, bd = dev_from(pack_ohwi(wt)), dev_from(b)
+        keep += [wd, bd]
+        descs.append(conv_desc(xd, wd, bd, yd, 1, 14, 14, 192, 192, co, k, k // 2, 1, 14, 14, total, off, L.CONV_RELU))
+        off += co
+    arr = (L.ConvDesc * 4)(*descs)
+    lib = L.load()
+    wsd = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(4)), zero=False)
+    grp = L.ConvGroup()
+    L.call("fcn_conv2d_group_prepare", arr, 4, wsd.ptr, C.byref(grp))
+    L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+    y = nchw(dev_to(yd, (1, 14, 14, total)), total)
+    ref = np.concatenate([R.relu(R.conv2d(x, wt, b, k // 2, 1)) for wt, b, k in zip(ws, bs, ks)], axis=1)
+    assert rel_err(y, ref) < TOL
+
+
+def test_conv_rejects_bad_arguments(gpu):
+    lib = L.load()
+    xd = dev_from(np.zeros(64, np.float32))
+    d = conv_desc(xd, xd, None, xd, 1, 4, 4, 3, 3, 1, 1, 0, 1, 4, 4, 1)
+    assert lib.fcn_conv2d_fwd_f32(C.byref(d), None) == 2 and b"multiples of 4" in lib.fcn_last_error_string()
+    d = conv_desc(xd, xd, None, xd, 1, 4, 4, 4, 4, 1, 3, 1, 1, 5, 4, 1)
+    assert lib.fcn_conv2d_fwd_f32(C.byref(d), None) == 1           # wrong OH
+
+
+@pytest.mark.parametrize("k,s,p,h,w,c,cs", [(3, 2, 0, 28, 28, 64, 64), (3, 2, 0, 15, 21, 8, 12), (3, 1, 1, 9, 7, 12, 12),
+                                            (2, 2, 0, 8, 6, 5, 8), (3, 2, 1, 10, 11, 7, 8)])
+def test_maxpool_matches_oracle(gpu, k, s, p, h, w, c, cs):
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, c, h, w)).astype(np.float32)
+    x[0, :, 0, 0] = x[0, :, 0, 1]                         # ties: first maximum must win
+    oh, ow = R.pool_out(h, k, p, s), R.pool_out(w, k, p, s)
+    xd = dev_from(nhwc(x, cs))
+    yd = dev_from(np.zeros((2, oh, ow, cs + 4), np.float32))
+    idd = dev_from(np.zeros((2, oh, ow, c), np.int32))
+    off = 4 if c % 4 == 0 else 1
+    L.call("fcn_maxpool_fwd_f32", xd.ptr, yd.ptr, idd.ptr, 2, h, w, c, cs, k, s, p, oh, ow, cs + 4, off, None)
+    y = nchw(dev_to(yd, (2, oh, ow, cs + 4)), c, off)
+    idx = dev_to(idd, (2, oh, ow, c), np.int32).transpose(0, 3, 1, 2)
+    ref, ridx = R.max_pool(x, k, s, p, return_index=True)
+    assert np.array_equal(y, ref) and np.array_equal(idx, ridx)
+
+
+def test_avepool_matches_oracle(gpu):
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal((1, 6, 56, 56)).astype(np.float32)
+    for k, s, p in [(56, 56, 0), (28, 28, 0), (14, 14, 0), (8, 8, 0), (3, 2, 1)]:
+        oh = R.pool_out(56, k, p, s)
+        xd = dev_from(nhwc(x, 8))
+        yd = dev_from(np.zeros((1, oh, oh, 6), np.float32))
+        L.call("fcn_avepool_fwd_f32", xd.ptr, yd.ptr, 1, 56, 56, 6, 8, k, s, p, oh, oh, 6, 0, None)
+        y = nchw(dev_to(yd, (1, oh, oh, 6)), 6)
+        assert rel_err(y, R.ave_pool(x, k, s, p)) < 1e-5
+
+
+@pytest.mark.parametrize("c,ls", [(64, 5), (192, 5), (10, 5), (16, 3)])
+def test_lrn_matches_oracle(gpu, c, ls):
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((2, c, 5, 7)) * 40).astype(np.float32)
+    cs = (c + 3) // 4 * 4
+    xd = dev_from(nhwc(x, cs))
+    yd = dev_from(np.zeros((2, 5, 7, cs), np.float32))
+    sd = dev_from(np.zeros((2, 5, 7, c), np.float32))
+    L.call("fcn_lrn_fwd_f32", xd.ptr, yd.ptr, sd.ptr, 70, c, cs, cs, ls, 1e-4, 0.75, 1.0, None)
+    y = nchw(dev_to(yd, (2, 5, 7, cs)), c)
+    ref, scale = R.lrn_across(x, ls, 1e-4, 0.75, 1.0, return_scale=True)
+    assert rel_err(y, ref) < 1e-5
+    assert rel_err(nchw(dev_to(sd, (2, 5, 7, c)), c), scale) < 1e-6
+
+
+def test_layout_roundtrip(gpu):
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((3, 37, 9, 13)).astype(np.float32)
+    xd = dev_from(x)
+    yd = dev_from(np.zeros((3, 9, 13, 48), np.float32))
+    L.call("fcn_nchw_to_nhwc_f32", xd.ptr, yd.ptr, 3, 37, 9, 13, 48, 8, None)
+    y = dev_to(yd, (3, 9, 13, 48))
+    assert np.array_equal(y[..., 8:45], x.transpose(0, 2, 3, 1)) and np.all(y[..., :8] == 0) and np.all(y[..., 45:] == 0)
+    zd = dev_from(np.zeros_like(x))
+    L.call("fcn_nhwc_to_nchw_f32", yd.ptr, zd.ptr, 3, 37, 9, 13, 48, 8, None)
+    assert np.array_equal(dev_to(zd, x.shape), x)
+
+
+def test_unary_eltwise_copy(gpu):
+    rng = np.random.default_rng(13)
+    a = rng.standard_normal(1003).astype(np.float32)
+    b = rng.standard_normal(1003).astype(np.float32)
+    ad, bd, yd = dev_from(a), dev_from(b), dev_from(np.zeros(1003, np.float32))
+    L.call("fcn_relu_fwd_f32", ad.ptr, yd.ptr, 1003, 0.0, None)
+    assert np.array_equal(dev_to(yd, (1003,)), np.maximum(a, 0))
+    L.call("fcn_relu_fwd_f32", ad.ptr, yd.ptr, 1003, 0.1, None)
+    assert np.allclose(dev_to(yd, (1003,)), np.where(a > 0, a, np.float32(0.1) * a))
+    L.call("fcn_sigmoid_fwd_f32", ad.ptr, yd.ptr, 1003, None)
+    assert np.abs(dev_to(yd, (1003,)) - R.sigmoid(a)).max() < 1e-6
+    L.call("fcn_power_fwd_f32", ad.ptr, yd.ptr, 1003, 1.0, 2.0, -127.0, None)
+    assert np.array_equal(dev_to(yd, (1003,)), a * np.float32(2) + np.float32(-127))
+    for op, ref in [(L.ELT_PROD, a * b), (L.ELT_SUM, np.float32(0.5) * a + np.float32(2) * b), (L.ELT_MAX, np.maximum(a, b))]:
+        L.call("fcn_eltwise_fwd_f32", ad.ptr, bd.ptr, yd.ptr, 1003, op, 0.5, 2.0, None)
+        assert np.allclose(dev_to(yd, (1003,)), ref, rtol=1e-6, atol=1e-6)
+    src = rng.standard_normal((10, 12)).astype(np.float32)
+    sd, dd = dev_from(src), dev_from(np.zeros((10, 20), np.float32))
+    L.call("fcn_copy_channels_f32", sd.ptr, dd.ptr, 10, 5, 12, 3, 20, 9, None)
+    out = dev_to(dd, (10, 20))
+    assert np.array_equal(out[:, 9:14], src[:, 3:8]) and np.all(out[:, :9] == 0) and np.all(out[:, 14:] == 0)
+
+
+@pytest.mark.parametrize("c,k,s,p,h", [(44, 8, 4, 2, 14), (11, 4, 2, 1, 7), (11, 16, 8, 4, 5)])
+def test_depthwise_deconv_matches_oracle(gpu, c, k, s, p, h):
+    rng = np.random.default_rng(14)
+    x = rng.standard_normal((2, c, h, h)).astype(np.float32)
+    w = R.bilinear_filler((c, 1, k, k)) * rng.random((c, 1, 1, 1)).astype(np.float32)
+    oh = R.deconv_out(h, k, p, s)
+    cs = (c + 3) // 4 * 4
+    xd, wd = dev_from(nhwc(x, cs)), dev_from(w.reshape(c, k, k))
+    yd = dev_from(np.zeros((2, oh, oh, cs), np.float32))
+    L.call("fcn_deconv_depthwise_fwd_f32", xd.ptr, wd.ptr, None, yd.ptr, 2, h, h, c, cs, k, s, p, oh, oh, cs, 0, None)
+    y = nchw(dev_to(yd, (2, oh, oh, cs)), c)
+    assert rel_err(y, R.deconv2d(x, w, None, p, s, group=c)) < 1e-5

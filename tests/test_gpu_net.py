@@ -1,0 +1,129 @@
+"""End-to-end parity of the DetectNet GoogLeNet forward (reference models/deploy.prototxt) on the GPU vs the CPU oracle,
+through the engine and through the pycaffe-compatible front end (run with -m gpu)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PYCAFFE, rel_err
+from fcn_object_detector_amd import models, proto
+from fcn_object_detector_amd.engine import Engine
+from fcn_object_detector_amd.netspec import NetSpec, fill_params
+from oracle import detect_ref as D
+from oracle.net_ref import RefNet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north_star: 1e-3 relative fp32
+
+
+def build(batch, h, w, classes, seed=1234, **kw):
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(batch, h, w, classes))
+    spec = NetSpec(msg, "TEST")
+    spec.infer()
+    params = fill_params(spec, seed=seed)
+    return msg, params, Engine(NetSpec(msg, "TEST"), params=params, device=0, **kw)
+
+
+def oracle_forward(msg, params, x):
+    ref = RefNet(msg, "TEST", params)
+    ref.blobs["data"] = x
+    return ref.forward()
+
+
+def test_deploy_448_matches_oracle(gpu):
+    """BASELINE config 1/2: seeded fillers (default_rng(1234)), random uint8 frame (default_rng(0)) through the
+    reference pre-processing; coverage/bboxes and a sample of intermediate blobs within 1e-3 relative."""
+    msg, params, eng = build(1, 448, 448, 4)
+    frame = np.random.default_rng(0).integers(0, 256, (448, 448, 3), dtype=np.uint8)
+    x = D.preprocess_frame(frame, 448, 448)[None]
+    eng.host_array("data")[...] = x
+    out = eng.forward()
+    rb = oracle_forward(msg, params, x)
+    assert out["coverage"].shape == (1, 4, 28, 28) and out["bboxes"].shape == (1, 16, 28, 28)
+    for name in ("coverage", "bboxes"):
+        assert rel_err(out[name], rb[name]) < TOL, name
+    for name in ("transformed_data", "conv1/7x7_s2", "pool1/norm1", "conv2/norm2", "pool2/3x3_s2", "inception_3a/pool",
+                 "inception_3a/output", "inception_3b/5x5", "pool3/3x3_s2", "inception_4a/3x3_reduce", "inception_4e/output",
+                 "inception_5b/output", "pool5/drop_s1", "cvg/classifier"):
+        assert rel_err(eng.read_blob(name), rb[name]) < TOL, name
+    # eager launches and graph replay give identical bits; replay is deterministic
+    again = {k: v.copy() for k, v in eng.forward().items()}
+    eager = eng.forward(use_graph=False)
+    for name in again:
+        assert np.array_equal(again[name], out[name]) and np.array_equal(eager[name], out[name])
+    eng.close()
+
+
+@pytest.mark.parametrize("fuse,group", [(False, False), (True, False)])
+def test_unfused_plans_agree(gpu, fuse, group):
+    msg, params, eng = build(2, 96, 128, 3, fuse=fuse, group_convs=group)
+    x = np.random.default_rng(3).random((2, 3, 96, 128), dtype=np.float32)
+    eng.host_array("data")[...] = x
+    out = eng.forward()
+    rb = oracle_forward(msg, params, x)
+    for name in ("coverage", "bboxes"):
+        assert rel_err(out[name], rb[name]) < TOL
+    eng.close()
+
+
+def test_batch_and_odd_sizes(gpu):
+    msg, params, eng = build(3, 80, 112, 1)
+    x = np.random.default_rng(4).random((3, 3, 80, 112), dtype=np.float32)
+    eng.host_array("data")[...] = x
+    out = eng.forward()
+    rb = oracle_forward(msg, params, x)
+    assert out["coverage"].shape == (3, 1, 5, 7)
+    for name in ("coverage", "bboxes"):
+        assert rel_err(out[name], rb[name]) < TOL
+    t = eng.forward_resident(3)
+    assert t > 0
+    eng.close()
+
+
+def test_pycaffe_front_end(gpu, tmp_path):
+    """The reference's calling sequence (fcn_object_detector.py:68-69,82,87,317-328) against our `caffe` package."""
+    if PYCAFFE not in sys.path:
+        sys.path.insert(0, PYCAFFE)
+    import caffe
+    proto_path = str(tmp_path / "deploy.prototxt")
+    with open(proto_path, "w") as f:
+        f.write(models.googlenet_detectnet_deploy(1, 96, 128, 2))
+    msg = proto.parse_file(proto_path)
+    spec = NetSpec(msg, "TEST")
+    spec.infer()
+    params = fill_params(spec, seed=7)
+    weights = str(tmp_path / "snap.caffemodel")
+    proto.write_caffemodel(weights, [(l.name, l.type, params[l.name]) for l in spec.param_layers()])
+    with pytest.raises(IOError):
+        caffe.Net(proto_path, str(tmp_path / "missing.caffemodel"), caffe.TEST)
+    caffe.set_device(0)
+    caffe.set_mode_gpu()
+    net = caffe.Net(proto_path, weights, caffe.TEST)
+    tr = caffe.io.Transformer({"data": net.blobs["data"].data.shape})
+    tr.set_transpose("data", (2, 0, 1)); tr.set_raw_scale("data", 1); tr.set_channel_swap("data", (2, 1, 0))
+    shape = net.blobs["data"].data.shape
+    net.blobs["data"].reshape(1, 3, shape[2], shape[3])
+    img = np.random.default_rng(5).random((3, 96, 128))              # float64, like the node's cv_img
+    net.blobs["data"].data[0][...] = img
+    out = net.forward()
+    rb = oracle_forward(msg, params, img[None].astype(np.float32))
+    assert set(out) == {"coverage", "bboxes"}
+    assert rel_err(net.blobs["coverage"].data[0], rb["coverage"][0]) < TOL
+    assert rel_err(net.blobs["bboxes"].data[0], rb["bboxes"][0]) < TOL
+    assert rel_err(net.blobs["inception_4c/output"].data, rb["inception_4c/output"]) < TOL
+    # run from another thread, as the rospy subscriber callback does
+    import threading
+    res = {}
+
+    def worker():
+        caffe.set_device(0); caffe.set_mode_gpu()
+        res["o"] = {k: v.copy() for k, v in net.forward().items()}
+    th = threading.Thread(target=worker); th.start(); th.join()
+    assert np.array_equal(res["o"]["coverage"], out["coverage"])
+    # parameter edit through net.params is visible to the next forward
+    net.params["bbox/regressor"][1].data[...] = 3.0
+    out2 = net.forward()
+    assert np.allclose(out2["bboxes"], rb["bboxes"] + 3.0, rtol=1e-3, atol=1e-3)
+    net.save(str(tmp_path / "resaved.caffemodel"))
+    assert np.array_equal(proto.read_caffemodel(str(tmp_path / "resaved.caffemodel"))["bbox/regressor"][1], np.full(8, 3.0, np.float32))
