@@ -642,6 +642,11 @@ class Engine:
             op.run(stream)
 
     def _capture(self, with_io: bool) -> int:
+        if with_io:                      # nothing may allocate while the stream is capturing
+            for nm in list(self.inputs) + list(self.outputs):
+                self.host_array(nm)
+                if len(self.blobs[nm].shape) == 4:
+                    self._stage(nm)
         L.call("fcn_graph_begin", self.stream)
         try:
             if with_io:
