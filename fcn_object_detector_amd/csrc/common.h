@@ -35,6 +35,9 @@ inline hipStream_t as_stream(fcn_stream_t s) { return reinterpret_cast<hipStream
         if (!(cond)) return ::fcn::set_err(code, __VA_ARGS__); \
     } while (0)
 
+// conv_fwd.hip: the per-device 16-byte zero page that masked lanes load (allocated by fcn_init)
+const float* zero_page_for_current_device(int* rc);
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // grid for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, no more

@@ -38,7 +38,9 @@ int fcn_device_count(int* count) {
 
 int fcn_init(int device) {
     FCN_HIP(hipSetDevice(device));
-    return 0;
+    int rc = 0;
+    zero_page_for_current_device(&rc);   // first call per device allocates; later calls are a table lookup
+    return rc;
 }
 
 int fcn_device_name(char* h_buf, int len) {

@@ -7,11 +7,10 @@ Design:
   * activations live in HBM as NHWC float32 with a per-blob channel stride;
     Concat is free — the producers of an inception module write their channel
     slice of the concat buffer directly;
-  * ReLU (in place after a conv), the Sigmoid coverage head, the Power(shift)
-    input transform and the inception 3x3/s1 max-pool branch are fused into the
-    convolution kernel's prologue/epilogue;
-  * independent convolutions (inception branches, the two heads) are merged into
-    ONE grouped launch;
+  * ReLU (in place after a conv), the Sigmoid coverage head and the Power(shift)
+    input transform are fused into the convolution kernel's prologue/epilogue;
+  * layers are scheduled by dependency level and all convolutions of one level
+    (inception branches, the two heads) share ONE grouped launch;
   * the whole forward is captured once into a hipGraph and replayed per frame,
     so the per-frame host cost is one graph launch.
 Blob contents are exposed to Python as NCHW float32 (pycaffe layout); the
@@ -299,13 +298,12 @@ class Engine:
         self._upload_params(lay)
 
     # ------------------------------------------------------------------ plan
-    def _conv_desc(self, l: Layer, fused_relu: bool, sig_top: Optional[str], pool3_src: Optional[str]) -> L.ConvDesc:
+    def _conv_desc(self, l: Layer, fused_relu: bool, sig_top: Optional[str]) -> L.ConvDesc:
         p = l.sub("convolution_param")
         k, s, pad = kernel_stride_pad(p)
         if int(p.get("group", 1)) != 1:
             raise NotImplementedError("grouped Convolution (layer %s) is not used by the reference nets" % l.name)
-        src_name = pool3_src if pool3_src else l.bottoms[0]
-        xb, yb = self.blobs[src_name], self.blobs[l.tops[0]]
+        xb, yb = self.blobs[l.bottoms[0]], self.blobs[l.tops[0]]
         n, cin, h, w = xb.shape
         _, cout, oh, ow = yb.shape
         if xb.coffset % 4 or xb.cstride % 4:
@@ -324,61 +322,24 @@ class Engine:
             sb = self.blobs[sig_top]
             d.y2, d.y2_cstride, d.y2_coffset = sb.buf.ptr, sb.cstride, sb.coffset
             flags |= L.CONV_SIGMOID2
-        if pool3_src:
-            flags |= L.CONV_POOL3
         d.flags = flags
-        d.in_shift = self.blobs[l.bottoms[0]].lazy_shift if not pool3_src else 0.0
+        d.in_shift = xb.lazy_shift
         return d
 
+    def _range(self, name: str) -> Tuple[int, int, int]:
+        b = self.blobs[name]
+        return (b.buf.ptr, b.coffset, b.coffset + max(b.channels, 1))
+
     def _build_ops(self) -> None:
+        """Layer list -> tasks with read/write sets -> dependency levels -> launches.
+
+        Tasks on one level are mutually independent; all convolutions of a level share ONE grouped launch
+        (an inception module becomes {1x1, 3x3_reduce, 5x5_reduce} then {3x3, 5x5, pool_proj})."""
         spec, B = self.spec, self.blobs
         layers = spec.layers
-        skip = set()
-        pending: List[Tuple[Layer, L.ConvDesc, float, float]] = []   # convs not yet emitted (grouping window)
-        pending_reads: set = set()
-        pending_writes: set = set()
         lib = L.load()
-
-        def flush() -> None:
-            if not pending:
-                return
-            items = list(pending)
-            pending.clear()
-            pending_reads.clear()
-            pending_writes.clear()
-            name = "+".join(l.name for l, _, _, _ in items)
-            flops = sum(f for _, _, f, _ in items)
-            byts = sum(b for _, _, _, b in items)
-            if len(items) == 1:
-                desc = items[0][1]
-                self._keep.append(desc)
-                self.ops.append(Op("conv", name, lambda st, d=desc: L.check(lib.fcn_conv2d_fwd_f32(C.byref(d), st)), flops, byts))
-                return
-            arr = (L.ConvDesc * len(items))(*[d for _, d, _, _ in items])
-            ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(items))), zero=False)
-            grp = L.ConvGroup()
-            L.call("fcn_conv2d_group_prepare", arr, len(items), ws.ptr, C.byref(grp))
-            self._keep.extend([arr, ws, grp])
-            self.ops.append(Op("conv_group", name, lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
-
-        def root_of(name: str) -> Tuple[int, int, int]:
-            b = B[name]
-            return (b.buf.ptr, b.coffset, b.channels)
-
-        def overlaps(a: Tuple[int, int, int], b: Tuple[int, int, int]) -> bool:
-            return a[0] == b[0] and a[1] < b[1] + b[2] and b[1] < a[1] + a[2]
-
-        def depends_on_pending(reads: Sequence[str], writes: Sequence[str]) -> bool:
-            for r in reads:
-                rr = root_of(r)
-                if any(overlaps(rr, w) for w in pending_writes):
-                    return True
-            for wname in writes:
-                ww = root_of(wname)
-                if any(overlaps(ww, w) for w in pending_writes) or any(overlaps(ww, r) for r in pending_reads):
-                    return True
-            return False
-
+        skip = set()
+        tasks: List[dict] = []
         for li, l in enumerate(layers):
             if l.name in skip:
                 continue
@@ -389,8 +350,7 @@ class Engine:
                 top = l.tops[0]
                 fused_relu, sig_top = False, None
                 if self.fuse:
-                    # in-place ReLU directly after this conv
-                    for nxt in layers[li + 1:]:
+                    for nxt in layers[li + 1:]:          # in-place ReLU directly after this conv
                         if top in nxt.bottoms or top in nxt.tops:
                             if nxt.type == "ReLU" and nxt.bottoms == [top] and nxt.tops == [top] and \
                                     float(nxt.sub("relu_param").get("negative_slope", 0.0)) == 0.0:
@@ -403,82 +363,79 @@ class Engine:
                                 len(self.producers.get(top, [])) == 1:
                             sig_top = cons[0].tops[0]
                             skip.add(cons[0].name)
-                # 3x3/s1/p1 MAX pool feeding only this 1x1 conv -> fused into the loader
-                pool3_src = None
-                if self.fuse:
-                    prods = self.producers.get(l.bottoms[0], [])
-                    if len(prods) == 1 and prods[0].type == "Pooling" and len(self.consumers.get(l.bottoms[0], [])) == 1 \
-                            and l.bottoms[0] not in self.outputs:
-                        pl = prods[0]
-                        pp = pl.sub("pooling_param")
-                        pk, ps, ppad = kernel_stride_pad(pp) if not bool(pp.get("global_pooling", False)) else (0, 0, 0)
-                        ck, cs, cpad = kernel_stride_pad(l.sub("convolution_param"))
-                        if str(pp.get("pool", "MAX")) == "MAX" and (pk, ps, ppad) == (3, 1, 1) and (ck, cs, cpad) == (1, 1, 0) \
-                                and pl.name in self._fused_pools:
-                            pool3_src = pl.bottoms[0]
-                desc = self._conv_desc(l, fused_relu, sig_top, pool3_src)
+                desc = self._conv_desc(l, fused_relu, sig_top)
                 n, cin, h, w = B[l.bottoms[0]].shape
                 _, cout, oh, ow = B[top].shape
                 k = desc.kh
-                flops = 2.0 * n * cout * oh * ow * cin * k * k
-                byts = 4.0 * (n * cin * h * w + n * cout * oh * ow + cout * cin * k * k + cout)
-                reads = [pool3_src or l.bottoms[0]]
-                writes = [top] + ([sig_top] if sig_top else [])
-                if not self.group_convs or len(pending) >= 8 or depends_on_pending(reads, writes):
-                    flush()
-                pending.append((l, desc, flops, byts))
-                pending_reads.update(root_of(r) for r in reads)
-                pending_writes.update(root_of(wn) for wn in writes)
-                self._conv_layer_meta[l.name] = dict(relu=fused_relu, sigmoid_top=sig_top, pool3=pool3_src)
-                if not self.group_convs:
-                    flush()
+                tasks.append(dict(kind="conv", layer=l, desc=desc,
+                                  flops=2.0 * n * cout * oh * ow * cin * k * k,
+                                  bytes=4.0 * (n * cin * h * w + n * cout * oh * ow + cout * cin * k * k + cout),
+                                  reads=[self._range(l.bottoms[0])],
+                                  writes=[self._range(top)] + ([self._range(sig_top)] if sig_top else [])))
+                self._conv_layer_meta[l.name] = dict(relu=fused_relu, sigmoid_top=sig_top)
                 continue
-            if t == "Pooling" and l.name in self._fused_pools:
-                # materialised lazily only if somebody reads the blob; the consumer conv pools on the fly
-                continue
-            # any non-conv layer: make sure convs it depends on are emitted first
-            if t in ("Concat",) and l.name not in self.copy_concats:
+            if t == "Concat" and l.name not in self.copy_concats:
                 continue      # producers already wrote their slices
             if t == "Slice":
                 continue      # tops are views of the bottom
-            if t == "Dropout" and spec.phase == "TEST":
-                if l.tops[0] == l.bottoms[0] or l.tops[0] in self.alias:
-                    continue
+            if t == "Dropout" and spec.phase == "TEST" and (l.tops[0] == l.bottoms[0] or l.tops[0] in self.alias):
+                continue
             if t == "Power" and l.tops[0] in self.shift:
                 continue      # folded into the consumer convolutions' loaders
-            flush()
-            self._emit_simple(l)
-        flush()
+            ops = self._emit_simple(l)
+            tasks.append(dict(kind="op", layer=l, ops=ops, reads=[self._range(b) for b in l.bottoms],
+                              writes=[self._range(tp) for tp in l.tops]))
 
-    # pools that are only consumed by a 1x1 conv and can be fused into its loader
-    @property
-    def _fused_pools(self) -> set:
-        if hasattr(self, "_fused_pools_cache"):
-            return self._fused_pools_cache
-        out = set()
-        if self.fuse:
-            for l in self.spec.layers:
-                if l.type != "Pooling":
-                    continue
-                pp = l.sub("pooling_param")
-                if bool(pp.get("global_pooling", False)) or str(pp.get("pool", "MAX")) != "MAX":
-                    continue
-                if kernel_stride_pad(pp) != (3, 1, 1):
-                    continue
-                top = l.tops[0]
-                cons = self.consumers.get(top, [])
-                if len(cons) != 1 or cons[0].type != "Convolution" or top in self.outputs or top in self.alias:
-                    continue
-                if kernel_stride_pad(cons[0].sub("convolution_param")) != (1, 1, 0):
-                    continue
-                if self.spec.phase == "TRAIN":
-                    continue   # backward needs the pooled activations and their argmax
-                out.add(l.name)
-        self._fused_pools_cache = out
-        return out
+        def hit(a, b) -> bool:
+            return any(x[0] == y[0] and x[1] < y[2] and y[1] < x[2] for x in a for y in b)
 
-    def _emit_simple(self, l: Layer) -> None:
+        levels: List[int] = []
+        for i, ti in enumerate(tasks):
+            lv = 0
+            if self.group_convs:
+                for j in range(i):
+                    tj = tasks[j]
+                    if hit(ti["reads"], tj["writes"]) or hit(ti["writes"], tj["writes"]) or hit(ti["writes"], tj["reads"]):
+                        lv = max(lv, levels[j] + 1)
+            else:
+                lv = i            # strict layer order, one launch per layer
+            levels.append(lv)
+        order = sorted(range(len(tasks)), key=lambda i: (levels[i], 0 if tasks[i]["kind"] == "op" else 1, i))
+
+        def emit_convs(items: List[dict]) -> None:
+            for base in range(0, len(items), 16):
+                chunk = items[base:base + 16]
+                name = "+".join(it["layer"].name for it in chunk)
+                flops = sum(it["flops"] for it in chunk)
+                byts = sum(it["bytes"] for it in chunk)
+                if len(chunk) == 1:
+                    desc = chunk[0]["desc"]
+                    self._keep.append(desc)
+                    self.ops.append(Op("conv", name, lambda st, d=desc: L.check(lib.fcn_conv2d_fwd_f32(C.byref(d), st)), flops, byts))
+                    continue
+                arr = (L.ConvDesc * len(chunk))(*[it["desc"] for it in chunk])
+                ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(chunk))), zero=False)
+                grp = L.ConvGroup()
+                L.call("fcn_conv2d_group_prepare", arr, len(chunk), ws.ptr, C.byref(grp))
+                self._keep.extend([arr, ws, grp])
+                self.ops.append(Op("conv_group", name, lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
+
+        pending: List[dict] = []
+        cur = None
+        for i in order:
+            if levels[i] != cur:
+                emit_convs(pending)
+                pending, cur = [], levels[i]
+            if tasks[i]["kind"] == "conv":
+                pending.append(tasks[i])
+            else:
+                self.ops.extend(tasks[i]["ops"])
+        emit_convs(pending)
+        self.levels = max(levels) + 1 if levels else 0
+
+    def _emit_simple(self, l: Layer) -> List[Op]:
         B, lib, t = self.blobs, L.load(), l.type
+        out: List[Op] = []
         if t == "Pooling":
             xb, yb = B[l.bottoms[0]], B[l.tops[0]]
             pp = l.sub("pooling_param")
@@ -490,10 +447,10 @@ class Engine:
                 k, s, pad = kernel_stride_pad(pp)
             byts = 4.0 * (xb.pixels * c + yb.pixels * c)
             if str(pp.get("pool", "MAX")) == "MAX":
-                self.ops.append(Op("maxpool", l.name, lambda st: L.check(lib.fcn_maxpool_fwd_f32(
+                out.append(Op("maxpool", l.name, lambda st: L.check(lib.fcn_maxpool_fwd_f32(
                     xb.ptr, yb.buf.ptr, None, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)), 0.0, byts))
             else:
-                self.ops.append(Op("avepool", l.name, lambda st: L.check(lib.fcn_avepool_fwd_f32(
+                out.append(Op("avepool", l.name, lambda st: L.check(lib.fcn_avepool_fwd_f32(
                     xb.ptr, yb.buf.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)), 0.0, byts))
         elif t == "LRN":
             xb, yb = B[l.bottoms[0]], B[l.tops[0]]
@@ -503,7 +460,7 @@ class Engine:
             if yb.coffset != 0:
                 raise NotImplementedError("LRN into a channel slice")
             ls, al, be, kk = int(p.get("local_size", 5)), float(p.get("alpha", 1.0)), float(p.get("beta", 0.75)), float(p.get("k", 1.0))
-            self.ops.append(Op("lrn", l.name, lambda st: L.check(lib.fcn_lrn_fwd_f32(
+            out.append(Op("lrn", l.name, lambda st: L.check(lib.fcn_lrn_fwd_f32(
                 xb.ptr, yb.ptr, None, xb.pixels, xb.channels, xb.cstride, yb.cstride, ls, al, be, kk, st)),
                 0.0, 8.0 * xb.pixels * xb.channels))
         elif t in ("ReLU", "Sigmoid", "Power"):
@@ -520,12 +477,12 @@ class Engine:
                 p = l.sub("power_param")
                 pw, sc, sh = float(p.get("power", 1.0)), float(p.get("scale", 1.0)), float(p.get("shift", 0.0))
                 fn = lambda st: L.check(lib.fcn_power_fwd_f32(xb.ptr, yb.ptr, count, pw, sc, sh, st))
-            self.ops.append(Op(t.lower(), l.name, fn, 0.0, 8.0 * count))
+            out.append(Op(t.lower(), l.name, fn, 0.0, 8.0 * count))
         elif t == "Dropout":
             if self.spec.phase != "TEST":
                 raise NotImplementedError("Dropout in TRAIN phase is handled by the training engine")
             xb, yb = B[l.bottoms[0]], B[l.tops[0]]
-            self.ops.append(Op("copy", l.name, lambda st: L.check(lib.fcn_copy_channels_f32(
+            out.append(Op("copy", l.name, lambda st: L.check(lib.fcn_copy_channels_f32(
                 xb.buf.ptr, yb.buf.ptr, xb.pixels, xb.channels, xb.cstride, xb.coffset, yb.cstride, yb.coffset, st))))
         elif t == "Concat":
             off = 0
@@ -533,7 +490,7 @@ class Engine:
             for bn in l.bottoms:
                 xb = B[bn]
                 o = off
-                self.ops.append(Op("copy", l.name + ":" + bn, lambda st, xb=xb, o=o: L.check(lib.fcn_copy_channels_f32(
+                out.append(Op("copy", l.name + ":" + bn, lambda st, xb=xb, o=o: L.check(lib.fcn_copy_channels_f32(
                     xb.buf.ptr, yb.buf.ptr, xb.pixels, xb.channels, xb.cstride, xb.coffset, yb.cstride, yb.coffset + o, st)),
                     0.0, 8.0 * xb.pixels * xb.channels))
                 off += xb.channels
@@ -551,7 +508,7 @@ class Engine:
             a = srcs[0]
             for i, b in enumerate(srcs[1:], start=1):
                 ca = coeff[0] if i == 1 else 1.0
-                self.ops.append(Op("eltwise", l.name, lambda st, a=a, b=b, ca=ca, cb=coeff[i]: L.check(lib.fcn_eltwise_fwd_f32(
+                out.append(Op("eltwise", l.name, lambda st, a=a, b=b, ca=ca, cb=coeff[i]: L.check(lib.fcn_eltwise_fwd_f32(
                     a.ptr, b.ptr, yb.ptr, count, op, ca, cb, st)), 0.0, 12.0 * count))
                 a = yb
         elif t == "Deconvolution":
@@ -564,11 +521,12 @@ class Engine:
                 raise NotImplementedError("Deconvolution %s: only group == channels == num_output" % l.name)
             wdev = self.params_dev[l.name][0].ptr
             bdev = self.params_dev[l.name][1].ptr if len(self.params_dev[l.name]) > 1 else None
-            self.ops.append(Op("deconv", l.name, lambda st: L.check(lib.fcn_deconv_depthwise_fwd_f32(
+            out.append(Op("deconv", l.name, lambda st: L.check(lib.fcn_deconv_depthwise_fwd_f32(
                 xb.ptr, wdev, bdev, yb.buf.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)),
                 2.0 * yb.pixels * c * (k / s) ** 2, 4.0 * (xb.pixels + yb.pixels) * c))
         else:
             raise NotImplementedError("layer type %r (layer %s) has no forward kernel yet" % (t, l.name))
+        return out
 
     # ------------------------------------------------------------------ host <-> device
     def _stage(self, name: str) -> DeviceBuffer:
@@ -610,17 +568,6 @@ class Engine:
         L.check(lib.fcn_nhwc_to_nchw_f32(b.buf.ptr, st.ptr, n, c, h, w, b.cstride, b.coffset, stream))
         L.check(lib.fcn_memcpy_d2h_async(host.ctypes.data, st.ptr, host.nbytes, stream))
 
-    def _materialize_fused_pool(self, name: str) -> bool:
-        """A pool blob whose kernel was folded into its consumer conv is computed on demand."""
-        for l in self.spec.layers:
-            if l.type == "Pooling" and l.name in self._fused_pools and l.tops[0] == name:
-                xb, yb = self.blobs[l.bottoms[0]], self.blobs[name]
-                n, c, h, w = xb.shape
-                L.call("fcn_maxpool_fwd_f32", xb.ptr, yb.buf.ptr, None, n, h, w, c, xb.cstride, 3, 1, 1, h, w,
-                       yb.cstride, yb.coffset, self.stream)
-                return True
-        return False
-
     def read_blob(self, name: str) -> np.ndarray:
         """Synchronised NCHW float32 host copy of a blob (pycaffe ``net.blobs[name].data``)."""
         with self.lock:
@@ -628,7 +575,6 @@ class Engine:
             b = self.blobs[name]
             host = self.host_array(name)
             if not b.host_valid:
-                self._materialize_fused_pool(name)
                 self._enqueue_download(name, self.stream)
                 L.call("fcn_stream_sync", self.stream)
                 if b.lazy_shift:

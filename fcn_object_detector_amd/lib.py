@@ -48,7 +48,7 @@ class DetectParams(C.Structure):
     ]
 
 
-CONV_RELU, CONV_SIGMOID2, CONV_POOL3 = 1, 2, 4
+CONV_RELU, CONV_SIGMOID2 = 1, 2
 ELT_PROD, ELT_SUM, ELT_MAX = 0, 1, 2
 RECT_ROUND_NEAREST_EVEN, RECT_ROUND_TRUNCATE = 0, 1
 

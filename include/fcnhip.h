@@ -83,12 +83,11 @@ int  fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int
 int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W,
                           int src_cstride, int src_coffset, fcn_stream_t s);
 
-/* ---- Convolution (+bias, fused in-place ReLU / Sigmoid / Power shift / 3x3 s1 max-pool):
+/* ---- Convolution (+bias, fused in-place ReLU / Sigmoid / Power shift):
  *      Caffe ConvolutionLayer::Forward_gpu, ReLULayer, SigmoidLayer, PowerLayer as run by
  *      net.forward() (fcn_object_detector.py:87) over models/deploy.prototxt:8-2176 ---- */
 #define FCN_CONV_RELU      1   /* y = max(y, 0)                                  */
 #define FCN_CONV_SIGMOID2  2   /* y2 = sigmoid(y) is written as well (y2 != NULL) */
-#define FCN_CONV_POOL3     4   /* input is read through a 3x3 s1 p1 MAX pool      */
 typedef struct fcn_conv_desc {
     const float* x;      /* NHWC input, channel stride x_cstride                           */
     const float* w;      /* weights [Cout][kh][kw][Cin]  (OHWI, Cin contiguous)            */

@@ -104,16 +104,6 @@ def test_conv_sigmoid_second_output(gpu):
     assert rel_err(y, ref) < TOL and np.abs(y2 - R.sigmoid(ref)).max() < 1e-5
 
 
-def test_conv_fused_maxpool3_loader(gpu):
-    rng = np.random.default_rng(7)
-    x = rng.standard_normal((1, 48, 13, 10)).astype(np.float32)
-    wt = rng.standard_normal((32, 48, 1, 1)).astype(np.float32) * 0.1
-    b = rng.standard_normal(32).astype(np.float32)
-    y, _ = run_conv(x, wt, b, 0, 1, flags=L.CONV_POOL3 | L.CONV_RELU)
-    ref = R.relu(R.conv2d(R.max_pool(x, 3, 1, 1), wt, b, 0, 1))
-    assert rel_err(y, ref) < TOL
-
-
 def test_conv_group_launch(gpu):
     """Four independent problems (an inception module's branch entries) in one launch."""
     rng = np.random.default_rng(8)
