@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""GPU micro-benchmark: one convolution problem (or a group) across all tile configurations.
+usage: python tools/conv_sweep.py  [--shapes name]   (run on the GPU box)"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fcn_object_detector_amd import lib as L  # noqa: E402
+from fcn_object_detector_amd.engine import DeviceBuffer  # noqa: E402
+from gpu_util import conv_desc, dev_from  # noqa: E402
+
+# (name, [(Cin, Cout, k, pad, stride, H, W), ...])  problems sharing one launch
+SHAPES = [
+    ("conv1", [(4, 64, 7, 3, 2, 448, 448)]),
+    ("conv2_3x3", [(64, 192, 3, 1, 1, 112, 112)]),
+    ("3a_A", [(192, 64, 1, 0, 1, 56, 56), (192, 96, 1, 0, 1, 56, 56), (192, 16, 1, 0, 1, 56, 56)]),
+    ("3b_B", [(128, 192, 3, 1, 1, 56, 56), (32, 96, 5, 2, 1, 56, 56), (256, 64, 1, 0, 1, 56, 56)]),
+    ("4a_A", [(480, 192, 1, 0, 1, 28, 28), (480, 96, 1, 0, 1, 28, 28), (480, 16, 1, 0, 1, 28, 28)]),
+    ("4a_B", [(96, 208, 3, 1, 1, 28, 28), (16, 48, 5, 2, 1, 28, 28), (480, 64, 1, 0, 1, 28, 28)]),
+    ("4e_3x3", [(160, 320, 3, 1, 1, 28, 28)]),
+    ("5b_A", [(832, 384, 1, 0, 1, 28, 28), (832, 192, 1, 0, 1, 28, 28), (832, 48, 1, 0, 1, 28, 28)]),
+    ("5b_B", [(192, 384, 3, 1, 1, 28, 28), (48, 128, 5, 2, 1, 28, 28), (832, 128, 1, 0, 1, 28, 28)]),
+    ("heads", [(1024, 4, 1, 0, 1, 28, 28), (1024, 16, 1, 0, 1, 28, 28)]),
+    # K scaling at M=784, N=320 (3x3): separates the fixed cost from the per-chunk cost
+    ("k288", [(32, 320, 3, 1, 1, 28, 28)]),
+    ("k576", [(64, 320, 3, 1, 1, 28, 28)]),
+    ("k1440", [(160, 320, 3, 1, 1, 28, 28)]),
+    ("k2880", [(320, 320, 3, 1, 1, 28, 28)]),
+    ("k5760", [(640, 320, 3, 1, 1, 28, 28)]),
+    # same K, 1x1 (no halo / tap logic): K = Cin
+    ("p1440", [(1440, 320, 1, 0, 1, 28, 28)]),
+]
+
+
+def main():
+    want = sys.argv[1:] or None
+    L.call("fcn_init", 0)
+    lib = L.load()
+    sp = C.c_void_p()
+    L.call("fcn_stream_create", C.byref(sp))
+    st = sp.value
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.call("fcn_event_create", C.byref(e0))
+    L.call("fcn_event_create", C.byref(e1))
+    rng = np.random.default_rng(0)
+    for name, probs in SHAPES:
+        if want and name not in want:
+            continue
+        keep, descs, flops = [], [], 0.0
+        for (cin, cout, k, pad, s, h, w) in probs:
+            oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+            x = dev_from(rng.standard_normal((1, h, w, cin)).astype(np.float32))
+            wt = dev_from(rng.standard_normal((cout, k, k, cin)).astype(np.float32) * 0.05)
+            b = dev_from(np.zeros(cout, np.float32))
+            y = dev_from(np.zeros((1, oh, ow, cout), np.float32))
+            keep += [x, wt, b, y]
+            descs.append(conv_desc(x, wt, b, y, 1, h, w, cin, cin, cout, k, pad, s, oh, ow, cout, 0, L.CONV_RELU | int(os.environ.get('FCN_DBG', '0'), 0)))
+            flops += 2.0 * oh * ow * cout * cin * k * k
+        arr = (L.ConvDesc * len(descs))(*descs)
+        ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(descs))), zero=False)
+        line = "%-10s %6.3f GFLOP |" % (name, flops / 1e9)
+        for cfg in ["auto", "0", "1", "2", "3", "4", "5", "6", "7"]:
+            if cfg == "auto":
+                os.environ.pop("FCN_CONV_CFG", None)
+            else:
+                os.environ["FCN_CONV_CFG"] = cfg
+            grp = L.ConvGroup()
+            L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, C.byref(grp))
+            for _ in range(3):
+                L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
+            L.call("fcn_event_record", e0, st)
+            reps = 30
+            for _ in range(reps):
+                L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
+            L.call("fcn_event_record", e1, st)
+            L.call("fcn_event_sync", e1)
+            ms = C.c_float()
+            L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+            us = ms.value / reps * 1e3
+            line += " %s:c%d/%dt %6.1fus %5.1fTF |" % (cfg if cfg != "auto" else "A", grp.cfg, grp.total_tiles, us, flops / us / 1e6)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()
