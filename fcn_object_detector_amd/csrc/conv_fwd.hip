@@ -8,26 +8,31 @@
 //   k = (r*kw + q)*Cin + c ,  A[m][k] = x[img][oy*s-p+r][ox*s-p+q][c]  (0 outside the image)
 //
 // Data layout: activations NHWC (channel-contiguous, so an A-row segment of 4 consecutive k is one
-// 16-byte load), weights OHWI = [Cout][kh][kw][Cin] (a Wt row is K contiguous floats).  Both tiles
-// are staged global -> registers -> LDS as [row][BK k + 4 pad] floats; the pad makes the
-// ds_read_b128 fragment reads bank-conflict free (row stride = 4 mod 64 dwords: 16 rows hit 16
-// distinct 4-dword slots of the 64-bank row).  Each wave accumulates 32x32 output tiles with
-// v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = the chip's f32 peak).  A k-step of 8 uses
-// one b128 read per operand: lanes 0-31 hold k+0..3, lanes 32-63 hold k+4..7, and MFMA j consumes
-// element j of both fragments, so A and B see the same k permutation.
+// 16-byte load), weights OHWI = [Cout][kh][kw][Cin] (a Wt row is K contiguous floats).  Each wave
+// accumulates 32x32 output tiles with v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD = the
+// chip's f32 peak).  A k-step of 8 uses one ds_read_b128 per operand: lanes 0-31 hold k+0..3, lanes
+// 32-63 hold k+4..7, and MFMA j consumes element j of both fragments, so A and B see the same k
+// permutation.
 //
 // Pipeline (per workgroup, chunk = BK consecutive k):
-//   * STAGES chunks are in flight global -> registers (chunk c in register set c % STAGES); every
-//     load is unconditional (masked lanes read a zero page) so hipcc waits with a counted vmcnt(N);
-//   * three LDS buffers: iteration c reads the fragments of chunk c+1 into registers (consumed by the
-//     MFMAs of iteration c+1), runs the MFMAs of chunk c from registers, and writes chunk c+2 — the
-//     LDS round trip and the one barrier per chunk hide behind the MFMA stream;
+//   * both tiles are staged HBM/L2 -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction,
+//     no VGPR round trip, no ds_write: LDS stores run at ~1/3 of the LDS read rate and were the limiter
+//     of the register-staged version) into a ring of NBUF slots, NBUF-1 chunks in flight;
+//   * every lane always loads — lanes outside the image / tile / K read a 16-byte zero page — so halo and
+//     tail arrive as zeros and each chunk is a fixed number of instructions: one counted
+//     s_waitcnt vmcnt(N) + one raw s_barrier per chunk, never vmcnt(0) inside the loop;
+//   * LDS rows are unpadded (LDS-DMA writes lane-linearly); bank conflicts are avoided by XOR-swizzling
+//     the 16-byte slots of a row with the row index, applied to the source address on the way in and
+//     to the slot index on the way out;
+//   * small tiles keep the fragments of the next chunk in registers (PF) so the LDS read latency hides
+//     behind the MFMAs of the current chunk;
 //   * small-M layers (28x28 grid, M = 784) cannot fill 256 CUs with large tiles, so the tile shape is
 //     a template parameter chosen per launch, down to one 32x32 tile per workgroup whose 4 waves
 //     split each chunk's k range (WAVES_K) and reduce through LDS at the end.
 // Several independent problems (the branches of an inception module) share ONE launch
 // (fcn_conv2d_fwd_group_f32).
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 
@@ -76,55 +81,66 @@ struct ConvP {
     int Cout, kh, kw, pad, stride, OH, OW;
     int y_cstride, y_coffset, y2_cstride, y2_coffset;
     int flags;
-    float in_shift;
+    float in_shift;   // unused by the kernel (kept so the struct mirrors fcn_conv_desc)
+    int kw_magic;
     int M, K, tiles_m, tiles_n, tile_end;  // tile_end: exclusive prefix end of this problem's tiles in a group launch
     const float* zero_page;               // 16 zero bytes in HBM: what out-of-image / out-of-tile lanes load
 };
 
-constexpr int kTapSlots = 64;    // filter taps (kh*kw <= 63) + sentinels
 
-template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int STAGES, bool PF>
+template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 struct Cfg {
     static constexpr int BM = 32 * WTM * WAVES_M;
     static constexpr int BN = 32 * WTN * WAVES_N;
-    static constexpr int NT = 64 * WAVES_M * WAVES_N * WAVES_K;
-    static constexpr int SEGS = BK / 4;                 // 16-byte segments per staged row
-    static constexpr int ROWS_PER_PASS = NT / SEGS;     // rows the workgroup stages per load instruction
-    static constexpr int A_IT = BM / ROWS_PER_PASS;
-    static constexpr int B_IT = BN / ROWS_PER_PASS;
-    static constexpr int LDS_ROW = BK + 4;              // floats per staged row
+    static constexpr int NW = WAVES_M * WAVES_N * WAVES_K;   // waves per workgroup
+    static constexpr int NT = 64 * NW;
+    static constexpr int SEGS = BK / 4;                 // 16-byte slots per staged row
+    static constexpr int RPI = 256 / BK;                // rows one LDS-DMA wave-instruction (1 KiB) fills
+    static constexpr int STEP = RPI * NW;               // rows between two consecutive instructions of one wave
+    static constexpr int IA = BM / STEP;                // A-row instructions per wave per chunk
+    static constexpr int IB = BN / STEP;                // B-row instructions per wave per chunk
+    static constexpr int INST = IA + IB;
+    static constexpr int D = NBUF - 1;                  // chunks in flight
     static constexpr int KS = BK / 8 / WAVES_K;         // k-steps of 8 each wave runs per chunk
-    static constexpr int NBUF = 3;
-    static constexpr int STAGE_FLOATS = NBUF * (BM + BN) * LDS_ROW;
+    static constexpr int BUF_FLOATS = (BM + BN) * BK;   // one ring slot: A rows then B rows, unpadded
+    static constexpr int RING_FLOATS = NBUF * BUF_FLOATS;
     static constexpr int RED_FLOATS = WAVES_M * WAVES_N * (WAVES_K - 1) * WTM * WTN * 16 * 64;
-    static constexpr int STAGE_OR_RED_FLOATS = STAGE_FLOATS > RED_FLOATS ? STAGE_FLOATS : RED_FLOATS;
-    static constexpr int LDS_FLOATS = STAGE_OR_RED_FLOATS + 2 * kTapSlots;   // + the tap table (int2 per slot)
-    static_assert(BK % 8 == 0 && (BK / 8) % WAVES_K == 0, "each wave needs whole k-steps of a chunk");
-    static_assert(NT % SEGS == 0 && BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile rows must divide over the threads");
-    static_assert(A_IT >= 1 && B_IT >= 1, "tile too small for the workgroup");
+    static constexpr int RING_OR_RED_FLOATS = RING_FLOATS > RED_FLOATS ? RING_FLOATS : RED_FLOATS;
+    static constexpr int LDS_FLOATS = RING_OR_RED_FLOATS;
+    static_assert(BK == 32 || BK == 64, "row swizzle is defined for 8 or 16 slots per row");
+    static_assert((BK / 8) % WAVES_K == 0, "each wave needs whole k-steps of a chunk");
+    static_assert(STEP % 16 == 0, "a lane's rows must agree mod 16 so that its swizzle (and k position) is the same for all of them");
+    static_assert(BM % STEP == 0 && BN % STEP == 0, "A / B rows must split into whole wave-instructions");
     static_assert(WAVES_K == 1 || WAVES_K == 2 || WAVES_K == 4, "K split over 1, 2 or 4 waves");
-    static_assert(STAGES >= 4 && STAGES <= 8 && STAGES % 2 == 0, "4, 6 or 8 k-chunks in flight (even: fragment parity is static)");
-    static_assert(STAGES * A_IT <= 32, "shift_mask holds one bit per staged A segment");
+    static_assert(WTM <= 2 && WTN <= 2, "fragment reads are written out for at most 2x2 MFMA tiles per wave");
+    static_assert(NBUF >= 3 && INST * (D - 1) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(!PF || NBUF >= 4, "fragment prefetch needs chunk c+1 landed while c+2.. are in flight");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "exceeds the CU's 160 KiB LDS");
 };
 
-// explicit global-address-space accesses: a pointer picked from a struct in memory (group launch) or
-// selected against the zero page would otherwise be "generic" and compile to flat_load, which cannot be
-// waited on with a counted vmcnt
-typedef const v4f __attribute__((address_space(1))) * gv4f_ptr;
-typedef float __attribute__((address_space(1))) * gf_ptr;
-__device__ __forceinline__ v4f ld4(const float* p) { return *(gv4f_ptr)(p); }
+// swizzle of the 16-byte slots of staged row r: slot s of the LDS row holds k-segment s ^ swz(r).  An LDS-DMA
+// wave-instruction writes 1 KiB lane-linearly, so the permutation is applied to the SOURCE address on the way in
+// and to the slot index on the way out; 16 consecutive rows then hit 16 distinct 16-byte slots of the 256-byte
+// bank row and every ds_read_b128 fragment read is conflict-free.
+template <int SEGS>
+__device__ __forceinline__ int swz(int row) { return SEGS == 8 ? (row >> 1) & 7 : row & 15; }
 
-template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int STAGES, bool PF>
+typedef float __attribute__((address_space(1))) * gf_ptr;
+typedef const void __attribute__((address_space(1))) * gvoid_cptr;
+typedef void __attribute__((address_space(3))) * lds_ptr;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem) {
-    using C = Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, STAGES, PF>;
-    constexpr int BM = C::BM, BN = C::BN, NT = C::NT, A_IT = C::A_IT, B_IT = C::B_IT, SEGS = C::SEGS, RPP = C::ROWS_PER_PASS;
-    constexpr int LDS_ROW = C::LDS_ROW, KS = C::KS, NBUF = C::NBUF;
-    constexpr int BUF_FLOATS = (BM + BN) * LDS_ROW;
+    using C = Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>;
+    constexpr int BM = C::BM, SEGS = C::SEGS, RPI = C::RPI, STEP = C::STEP, IA = C::IA, IB = C::IB, INST = C::INST;
+    constexpr int D = C::D, KS = C::KS, BUF_FLOATS = C::BUF_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base goes through M0)
     const int wk = wid % WAVES_K;
     const int wn = (wid / WAVES_K) % WAVES_N;
     const int wm = wid / (WAVES_K * WAVES_N);
@@ -132,81 +148,68 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const int tile_m = tile / p.tiles_n;
     const int tile_n = tile - tile_m * p.tiles_n;
     const int m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
+    const int n0 = tile_n * C::BN;
 
-    // ---- tap table: (kr, kq) and the element offset of every filter tap, plus "outside" sentinels ----
-    // One ds_read_b64 per chunk replaces the divisions / multiplies of the k -> (r, q, c) decode.
-    int2* s_tap = reinterpret_cast<int2*>(smem + C::STAGE_OR_RED_FLOATS);   // [kTapSlots]
-    const int taps = p.kh * p.kw;
-    for (int t = tid; t < kTapSlots; t += NT) {
-        int2 e;
-        if (t < taps) {
-            const int kr = t / p.kw, kq = t - kr * p.kw;
-            e.x = (kr << 16) | kq;
-            e.y = (kr * p.W + kq) * p.x_cstride;
-        } else {
-            e.x = 0x4000 << 16;   // row far below the image: every bounds test fails
-            e.y = 0;
-        }
-        s_tap[t] = e;
-    }
-
-    // ---- per-thread loader state -------------------------------------------------------------
-    const int seg = tid % SEGS;     // which 16-byte segment of the BK-float k-chunk
-    const int row0 = tid / SEGS;    // first staged row of this thread; further rows every RPP
-    // k position of this thread's segment, kept as (tap, channel) and advanced by BK per chunk without branches
-    int kc = seg * 4;
+    // ---- loader state: this lane stages slot (lane % SEGS) of rows STEP*i + RPI*wid + lane / SEGS ------------
+    const int lrow = RPI * wid + lane / SEGS;                  // row of instruction 0
+    const int lseg = (lane % SEGS) ^ swz<SEGS>(lrow);          // k-segment this lane fetches (same for all its rows)
+    // k position of that segment, kept as (tap, channel) and advanced by BK per chunk without branches
+    int kc = lseg * 4;
     int kt = kc / p.Cin;
     kc -= kt * p.Cin;
     const int bk_taps = BK / p.Cin, bk_rem = BK - bk_taps * p.Cin;
-    int a_iy0[A_IT], a_ix0[A_IT], a_off[A_IT];   // window origin and its element offset (32-bit: validated on the host)
+    int a_iy0[IA], a_ix0[IA], a_off[IA];   // window origin and its element offset (32-bit: validated on the host)
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int m = m0 + row0 + it * RPP;
+    for (int i = 0; i < IA; ++i) {
+        const int m = m0 + STEP * i + lrow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int ox = mm % p.OW;
         const int t = mm / p.OW;
         const int oy = t % p.OH;
         const int img = t / p.OH;
-        a_iy0[it] = ok ? oy * p.stride - p.pad : -(1 << 20);   // rows past M never pass the bounds test
-        a_ix0[it] = ox * p.stride - p.pad;
-        a_off[it] = ((img * p.H + a_iy0[it]) * p.W + a_ix0[it]) * p.x_cstride;
+        a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);   // rows past M never pass the bounds test
+        a_ix0[i] = ox * p.stride - p.pad;
+        a_off[i] = ((img * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.x_cstride;
     }
-    int b_off[B_IT];   // element offset of this thread's segment in weight row n; negative = row past Cout
+    int b_off[IB];   // element offset of this lane's segment in weight row n; negative = row past Cout
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        const int n = n0 + row0 + it * RPP;
-        b_off[it] = n < p.Cout ? n * p.K + seg * 4 : -1;
+    for (int i = 0; i < IB; ++i) {
+        const int n = n0 + STEP * i + lrow;
+        b_off[i] = n < p.Cout ? n * p.K + lseg * 4 : -1;
     }
-    int kb = seg * 4;   // this segment's k index in the current chunk (weights are zero past K)
+    int kb = lseg * 4;   // this segment's k index (weights are zero past K)
+    const int taps = p.kh * p.kw;
+    // the zero page pointer is laundered into VGPRs so that "in bounds ? source : zero page" stays a plain select
+    // (one LDS-DMA instruction per row group) instead of two exec-masked instructions
+    unsigned long long zp_bits = reinterpret_cast<unsigned long long>(p.zero_page);
+    asm volatile("" : "+v"(zp_bits));
+    const float* zero_page = reinterpret_cast<const float*>(zp_bits);
+    const int lds_wave_base = RPI * wid * BK;   // float offset of instruction 0's 1 KiB piece inside a ring slot
 
-    v4f a_reg[STAGES][A_IT], b_reg[STAGES][B_IT];
-    unsigned shift_mask = 0;   // bit (set * A_IT + it): that staged segment is inside the image (gets in_shift)
-    const bool has_shift = p.in_shift != 0.f;
-    const float* zero_page = p.zero_page;
-    __syncthreads();           // tap table visible
-
-    const bool dbg_noload = (p.flags & 0x200) != 0, dbg_nomfma = (p.flags & 0x100) != 0, dbg_nolds = (p.flags & 0x400) != 0;
-    auto load_chunk = [&](const int set) {
-        if (dbg_noload) return;
-        const int2 tp = s_tap[min(kt, kTapSlots - 1)];
-        const int kr = tp.x >> 16, kq = tp.x & 0xffff;
-        const int koff = tp.y + kc;
+    // Issue the LDS-DMA of one chunk (INST x global_load_lds_dwordx4 per wave) into ring slot `buf`.  Every lane
+    // always loads: lanes outside the image / tile / K read the zero page, so padding arrives as zeros and the
+    // number of outstanding instructions per chunk is a constant the vmcnt waits can count on.
+    auto issue_chunk = [&](const int buf) {
+        const int kr = (kt * p.kw_magic) >> 16;            // kt / kw (magic = ceil(65536 / kw), exact for kt < 8192)
+        const int kq = kt - kr * p.kw;
+        const int koff = (kr * p.W + kq) * p.x_cstride + kc;
+        const bool k_ok = kt < taps;
+        float* dst = smem + buf * BUF_FLOATS + lds_wave_base;
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const bool ok = (unsigned)(a_iy0[it] + kr) < (unsigned)p.H && (unsigned)(a_ix0[it] + kq) < (unsigned)p.W;
-            a_reg[set][it] = ld4(ok ? p.x + (a_off[it] + koff) : zero_page);
-            if (has_shift) {
-                const unsigned bit = 1u << (set * A_IT + it);
-                shift_mask = ok ? (shift_mask | bit) : (shift_mask & ~bit);
-            }
+        for (int i = 0; i < IA; ++i) {
+            const bool ok = k_ok && (unsigned)(a_iy0[i] + kr) < (unsigned)p.H && (unsigned)(a_ix0[i] + kq) < (unsigned)p.W;
+            unsigned long long src = reinterpret_cast<unsigned long long>(ok ? p.x + (a_off[i] + koff) : zero_page);
+            asm volatile("" : "+v"(src));    // one select, one DMA (keeps hipcc from forking the load into two exec-masked copies)
+            __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(dst + STEP * i * BK), 16, 0, 0);
         }
         const bool kb_ok = kb < p.K;
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            b_reg[set][it] = ld4((kb_ok && b_off[it] >= 0) ? p.w + b_off[it] : zero_page);
-            b_off[it] += b_off[it] >= 0 ? BK : 0;
+        for (int i = 0; i < IB; ++i) {
+            unsigned long long src = reinterpret_cast<unsigned long long>((kb_ok && b_off[i] >= 0) ? p.w + b_off[i] : zero_page);
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(dst + (BM + STEP * i) * BK), 16, 0, 0);
+            b_off[i] += b_off[i] >= 0 ? BK : 0;
         }
         kb += BK;
         // advance by one chunk: BK = bk_taps * Cin + bk_rem
@@ -215,20 +218,6 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         const bool wrap = kc >= p.Cin;
         kc -= wrap ? p.Cin : 0;
         kt += wrap ? 1 : 0;
-    };
-
-    auto store_chunk = [&](const int set, const int buf) {
-        if (dbg_nolds) return;
-        float* sA = smem + buf * BUF_FLOATS;
-        float* sB = sA + BM * LDS_ROW;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            v4f v = a_reg[set][it];
-            if (has_shift) v += (shift_mask >> (set * A_IT + it)) & 1u ? p.in_shift : 0.f;
-            *reinterpret_cast<v4f*>(&sA[(row0 + it * RPP) * LDS_ROW + seg * 4]) = v;
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) *reinterpret_cast<v4f*>(&sB[(row0 + it * RPP) * LDS_ROW + seg * 4]) = b_reg[set][it];
     };
 
     f32x16 acc[WTM][WTN];
@@ -240,97 +229,122 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nchunks = (p.K + BK - 1) / BK;
-    // this lane's fragment origin inside a staged tile: row (lane & 31), k offset 4 * (lane >> 5), wave's k-steps
-    const int frag_a = (wm * WTM * 32 + (lane & 31)) * LDS_ROW + 4 * (lane >> 5) + wk * KS * 8;
-    const int frag_b = (BM + wn * WTN * 32 + (lane & 31)) * LDS_ROW + 4 * (lane >> 5) + wk * KS * 8;
+    // Fragment reads are inline asm: hipcc cannot tell an LDS-DMA in flight from the ds_read of a slot that landed
+    // long ago and would drain vmcnt to 0 in front of every compiler-generated LDS read of this array.
+    // Addressing: row (lane & 31) of a 32-row tile, k-segment 2*step + (lane >> 5), de-swizzled per lane.
+    const int fswz = swz<SEGS>(lane & 31);
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+    unsigned fa[KS], fb[KS];           // byte address of this lane's fragment inside ring slot 0, per k-step
+#pragma unroll
+    for (int st = 0; st < KS; ++st) {
+        const int slot4 = ((2 * (wk * KS + st) + (lane >> 5)) ^ fswz) * 4;
+        fa[st] = lds0 + 4u * ((wm * WTM * 32 + (lane & 31)) * BK + slot4);
+        fb[st] = lds0 + 4u * ((BM + wn * WTN * 32 + (lane & 31)) * BK + slot4);
+    }
 
-    // PF: fragments of the chunk being multiplied and of the next one live in registers, so the LDS round trip
-    // of chunk c+1 hides behind the MFMAs of chunk c.  Large tiles (already >= 2048 MFMA cycles per barrier)
-    // read their fragments just in time instead and keep the registers for accumulators.
+    // PF: the fragments of the chunk being multiplied and of the next one live in registers, so the LDS read
+    // latency of chunk c+1 hides behind the MFMAs of chunk c.  Large tiles (>= 2048 MFMA cycles per barrier) read
+    // their fragments just in time instead and keep the registers for accumulators.
     v4f af[PF ? 2 : 1][PF ? KS : 1][WTM], bf[PF ? 2 : 1][PF ? KS : 1][WTN];
-    auto read_frags = [&](const int par, const int buf) {
-        if (!PF || dbg_nolds) return;
-        const float* base = smem + buf * BUF_FLOATS;
+    auto ds_read = [](v4f& dst, unsigned addr, auto off) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value));
+    };
+    auto frags_landed = [&](const int par, const int st0, const int st1) {   // wait for the reads, pinning the registers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int st = 0; st < KS; ++st) {
+        for (int st = st0; st < st1; ++st) {
 #pragma unroll
-            for (int i = 0; i < WTM; ++i) af[par][st][i] = *reinterpret_cast<const v4f*>(base + frag_a + i * 32 * LDS_ROW + st * 8);
+            for (int i = 0; i < WTM; ++i) asm volatile("" : "+v"(af[par][st][i]));
 #pragma unroll
-            for (int j = 0; j < WTN; ++j) bf[par][st][j] = *reinterpret_cast<const v4f*>(base + frag_b + j * 32 * LDS_ROW + st * 8);
+            for (int j = 0; j < WTN; ++j) asm volatile("" : "+v"(bf[par][st][j]));
         }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto read_step = [&](const int par, const int fst, const int st, const unsigned slot_bytes) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) {
+            if (i == 0) ds_read(af[par][fst][0], fa[st] + slot_bytes, std::integral_constant<int, 0>{});
+            if (i == 1) ds_read(af[par][fst][WTM > 1 ? 1 : 0], fa[st] + slot_bytes, std::integral_constant<int, 32 * BK * 4>{});
+        }
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+            if (j == 0) ds_read(bf[par][fst][0], fb[st] + slot_bytes, std::integral_constant<int, 0>{});
+            if (j == 1) ds_read(bf[par][fst][WTN > 1 ? 1 : 0], fb[st] + slot_bytes, std::integral_constant<int, 32 * BK * 4>{});
+        }
+    };
+    auto read_frags = [&](const int par, const int buf) {
+        const unsigned slot_bytes = (unsigned)buf * (BUF_FLOATS * 4);
+#pragma unroll
+        for (int st = 0; st < KS; ++st) read_step(par, st, st, slot_bytes);
+    };
+    auto mfma_step = [&](const int par, const int fst) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[par][fst][i][e], bf[par][fst][j][e], acc[i][j], 0, 0, 0);
     };
     auto mfma_chunk = [&](const int par, const int buf_cur) {
-        if (dbg_nomfma) return;
-        const float* base = smem + buf_cur * BUF_FLOATS;
+        if (PF) {
 #pragma unroll
-        for (int st = 0; st < KS; ++st) {
-            if (!PF) {
+            for (int st = 0; st < KS; ++st) mfma_step(par, st);
+        } else {
+            const unsigned slot_bytes = (unsigned)buf_cur * (BUF_FLOATS * 4);
 #pragma unroll
-                for (int i = 0; i < WTM; ++i) af[0][0][i] = *reinterpret_cast<const v4f*>(base + frag_a + i * 32 * LDS_ROW + st * 8);
-#pragma unroll
-                for (int j = 0; j < WTN; ++j) bf[0][0][j] = *reinterpret_cast<const v4f*>(base + frag_b + j * 32 * LDS_ROW + st * 8);
+            for (int st = 0; st < KS; ++st) {
+                read_step(0, 0, st, slot_bytes);
+                frags_landed(0, 0, 1);
+                mfma_step(0, 0);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WTN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[PF ? par : 0][PF ? st : 0][i][e], bf[PF ? par : 0][PF ? st : 0][j][e],
-                                                                          acc[i][j], 0, 0, 0);
         }
     };
 
-    // ---- prologue: chunks 0 .. STAGES-1 in flight; chunks 0 and 1 staged; fragments of chunk 0 read ----
+    // ---- prologue: chunks 0 .. D-1 in flight (chunks past K are all-zero, so the counts below never change) ----
+    int buf_issue = 0;                 // ring slot of the next chunk to issue
+    auto next = [](int b) { return b + 1 == NBUF ? 0 : b + 1; };
 #pragma unroll
-    for (int s = 0; s < STAGES; ++s)
-        if (s < nchunks) load_chunk(s);
-    store_chunk(0, 0);
-    if (1 < nchunks) store_chunk(1, 1);
-    __syncthreads();
-    read_frags(0, 0);
+    for (int c = 0; c < D; ++c) {
+        issue_chunk(buf_issue);
+        buf_issue = next(buf_issue);
+    }
+    int buf_cur = 0;                   // ring slot of chunk c
+    if (PF) {
+        wait_vmcnt<INST*(D - 1)>();   // chunk 0 landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();  // ... and everybody else's
+        asm volatile("" ::: "memory");
+        read_frags(0, 0);
+    }
 
-    // LDS buffer of chunk c is c % 3, tracked incrementally (uniform scalars)
-    int buf_cur = 0;           // buffer holding chunk c
-    int buf_next = 1 % NBUF;   // buffer holding chunk c + 1
-    int buf_fill = 2 % NBUF;   // buffer that receives chunk c + 2
-    auto rotate = [&]() {
-        buf_cur = buf_next;
-        buf_next = buf_fill;
-        buf_fill = buf_fill + 1 == NBUF ? 0 : buf_fill + 1;
-    };
-
-    // ---- steady state: no conditionals; every iteration refills the register set it drained two chunks ago ----
-    int ch = 0;
-    const int n_main = nchunks > STAGES ? (nchunks - STAGES) / STAGES : 0;
-    for (int g = 0; g < n_main; ++g) {
+    // ---- main loop: one counted wait + one barrier per chunk -------------------------------------------------
+    // Iteration c: [PF] chunk c+1 (else chunk c) has landed -> barrier -> refill the slot chunk c-1 vacated with
+    // chunk c+D -> [PF] read the fragments of chunk c+1 -> MFMAs of chunk c.
+    for (int c0 = 0; c0 < nchunks; c0 += 2) {
 #pragma unroll
-        for (int s = 0; s < STAGES; ++s, ++ch) {
-            load_chunk(s);                               // chunk ch + STAGES into the set chunk ch left
-            read_frags((s + 1) & 1, buf_next);           // fragments of chunk ch + 1 (used next iteration)
-            mfma_chunk(s & 1, buf_cur);                  // chunk ch
-            store_chunk((s + 2) % STAGES, buf_fill);     // chunk ch + 2 -> LDS
-            rotate();
-            __syncthreads();
+        for (int u = 0; u < 2; ++u) {      // unrolled by 2: the fragment parity is a compile-time constant
+            if (c0 + u < nchunks) {
+                wait_vmcnt<INST*(D - 1 - (PF ? 1 : 0))>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_chunk(buf_issue);
+                buf_issue = next(buf_issue);
+                if (PF) {
+                    frags_landed(u & 1, 0, KS);                 // read one iteration ago: no stall
+                    read_frags((u + 1) & 1, next(buf_cur));     // in flight behind the MFMAs below
+                }
+                mfma_chunk(u & 1, buf_cur);
+                buf_cur = next(buf_cur);
+            }
         }
     }
-    // ---- tail: the last STAGES .. 2*STAGES-1 chunks (ch is a multiple of STAGES here) ----
-#pragma unroll
-    for (int t = 0; t < 2 * STAGES; ++t) {
-        const int c = ch + t;
-        if (c < nchunks) {
-            if (c + STAGES < nchunks) load_chunk(t % STAGES);
-            if (c + 1 < nchunks) read_frags((t + 1) & 1, buf_next);
-            mfma_chunk(t & 1, buf_cur);
-            if (c + 2 < nchunks) store_chunk((t + 2) % STAGES, buf_fill);
-            rotate();
-            __syncthreads();
-        }
-    }
+    wait_vmcnt<0>();                   // the all-zero chunks issued past K must land before the ring is reused
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     // ---- K-split reduction across the wk waves of one (wm, wn) -------------------------------
     if (WAVES_K > 1) {
-        float* red = smem;  // staging is dead after the loop's last barrier
+        float* red = smem;
         if (wk > 0) {
             float* dst = red + ((size_t)((wm * WAVES_N + wn) * (WAVES_K - 1) + (wk - 1)) * WTM * WTN * 16) * 64 + lane;
 #pragma unroll
@@ -382,39 +396,39 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     }
 }
 
-template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int STAGES, bool PF>
+template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const ConvP* __restrict__ probs, int nprob) {
-    __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, STAGES, PF>::LDS_FLOATS];
+    __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
     int tile = blockIdx.x;
     int pi = 0, begin = 0;
     while (pi + 1 < nprob && tile >= probs[pi].tile_end) { begin = probs[pi].tile_end; ++pi; }
     const ConvP p = probs[pi];
-    conv_body<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, STAGES, PF>(p, tile - begin, smem);
+    conv_body<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(p, tile - begin, smem);
 }
 
-template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int STAGES, bool PF>
+template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_one(ConvP p) {
-    __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, STAGES, PF>::LDS_FLOATS];
-    conv_body<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, STAGES, PF>(p, blockIdx.x, smem);
+    __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
+    conv_body<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(p, blockIdx.x, smem);
 }
 
 // ---- host side -------------------------------------------------------------------------------
 
-// tile configurations: X(index, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, STAGES, fragment prefetch)
-#define FCN_CONV_CONFIGS(X)             \
-    X(0, 2, 2, 2, 2, 1, 32, 4, false)   \
-    X(1, 2, 1, 2, 2, 1, 32, 4, false)   \
-    X(2, 1, 1, 2, 2, 1, 32, 4, true)    \
-    X(3, 1, 1, 4, 1, 1, 32, 4, true)    \
-    X(4, 1, 1, 2, 1, 2, 64, 4, true)    \
-    X(5, 1, 1, 1, 1, 4, 128, 4, true)   \
-    X(6, 1, 1, 2, 2, 1, 64, 4, false)   \
-    X(7, 1, 1, 1, 1, 4, 64, 4, true)
+// tile configurations: X(index, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, ring slots, fragment prefetch)
+#define FCN_CONV_CONFIGS(X)            \
+    X(0, 2, 2, 2, 2, 1, 32, 4, false)  \
+    X(1, 2, 1, 2, 2, 1, 32, 4, false)  \
+    X(2, 1, 1, 2, 2, 1, 32, 4, true)   \
+    X(3, 1, 1, 4, 1, 1, 32, 4, true)   \
+    X(4, 1, 1, 2, 1, 2, 64, 4, true)   \
+    X(5, 1, 1, 1, 1, 4, 64, 4, true)   \
+    X(6, 1, 1, 2, 2, 1, 64, 4, true)   \
+    X(7, 1, 1, 1, 1, 4, 64, 6, true)
 
-struct TileCfg { int bm, bn, bk, mfma_per_barrier; };
+struct TileCfg { int bm, bn, bk; bool prefetch; };
 constexpr int kNumCfg = 8;
 constexpr TileCfg kCfgs[kNumCfg] = {
-#define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, A * B * 4 * Cfg<A, B, C_, D, E, F, G, H>::KS},
+#define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
     FCN_CONV_CONFIGS(X)
 #undef X
 };
@@ -430,9 +444,10 @@ int validate(const fcn_conv_desc& d) {
                 FCN_E_ARG, "conv: OH/OW (%d,%d) do not match floor((H+2p-k)/s)+1", d.OH, d.OW);
     FCN_REQUIRE(d.OH > 0 && d.OW > 0, FCN_E_ARG, "conv: empty output");
     FCN_REQUIRE(d.y_cstride >= d.y_coffset + d.Cout && d.y_coffset >= 0, FCN_E_ARG, "conv: output slice exceeds y_cstride");
-    FCN_REQUIRE(d.kh * d.kw < kTapSlots, FCN_E_UNSUPPORTED, "conv: kernel window %dx%d exceeds %d taps", d.kh, d.kw, kTapSlots - 1);
+    FCN_REQUIRE(d.kh * d.kw < 4096, FCN_E_UNSUPPORTED, "conv: kernel window %dx%d too large", d.kh, d.kw);
     FCN_REQUIRE((long long)d.N * d.H * d.W * d.x_cstride < (1ll << 31) && (long long)d.Cout * d.kh * d.kw * d.Cin < (1ll << 31),
                 FCN_E_UNSUPPORTED, "conv: tensor too large for 32-bit element offsets");
+    FCN_REQUIRE(d.in_shift == 0.f, FCN_E_UNSUPPORTED, "conv: in_shift is applied by the producer of the input (fcn_nchw_to_nhwc_f32 / fcn_preprocess_bgr8)");
     if (d.flags & FCN_CONV_SIGMOID2)
         FCN_REQUIRE(d.y2 && d.y2_cstride >= d.y2_coffset + d.Cout, FCN_E_ARG, "conv: FCN_CONV_SIGMOID2 needs y2");
     FCN_REQUIRE((long long)d.N * d.OH * d.OW < (1ll << 31), FCN_E_UNSUPPORTED, "conv: problem too large for int32 indexing");
@@ -444,37 +459,40 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.x_cstride = d.x_cstride;
     p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw; p.pad = d.pad; p.stride = d.stride; p.OH = d.OH; p.OW = d.OW;
     p.y_cstride = d.y_cstride; p.y_coffset = d.y_coffset; p.y2_cstride = d.y2_cstride; p.y2_coffset = d.y2_coffset;
-    p.flags = d.flags; p.in_shift = d.in_shift;
+    p.flags = d.flags; p.in_shift = 0.f;
     p.M = d.N * d.OH * d.OW;
     p.K = d.kh * d.kw * d.Cin;
     p.tiles_m = p.tiles_n = p.tile_end = 0;
+    p.kw_magic = (65536 + d.kw - 1) / d.kw;
     p.zero_page = zero_page;
 }
 
-// Cost model fitted to tools/conv_sweep.py on MI355X: a workgroup pays a fixed pipeline fill plus, per
-// k-chunk, its MFMA time and one barrier / LDS round trip; workgroups run in rounds of 256 (one per CU).
+// Heuristic used when the caller does not autotune (cfg_request = -1).  Fitted to tools/conv_sweep.py on
+// MI355X: a CU's vector-memory path sustains ~12 B/clk into LDS whatever the source, so a workgroup's chunk
+// costs about max(MFMA cycles, staged bytes / 12) plus a barrier; workgroups run in rounds over 256 CUs.
 int choose_cfg(const ConvP* ps, int n) {
     const char* force = getenv("FCN_CONV_CFG");
     if (force && force[0] >= '0' && force[0] < '0' + kNumCfg) return force[0] - '0';
     int best = 0;
     double best_cost = 1e300;
     for (int c = 0; c < kNumCfg; ++c) {
+        const double bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = kCfgs[c].bk;
+        const double mf = bm * bn * bk / 128.0, ld = (bm + bn) * bk * 4.0 / 12.0;
+        const double per_chunk = (mf > ld ? mf : ld) + 150.0 + (kCfgs[c].prefetch ? 0.0 : 200.0 * bk / 8.0);
         long long tiles = 0;
-        double longest = 0;   // cycles of the slowest workgroup
-        double total = 0;     // cycles summed over workgroups
+        double work = 0, longest = 0;
         for (int i = 0; i < n; ++i) {
             const long long t = (long long)cdiv(ps[i].M, kCfgs[c].bm) * cdiv(ps[i].Cout, kCfgs[c].bn);
             const int chunks = cdiv(ps[i].K, kCfgs[c].bk);
-            const double per_chunk = 64.0 * kCfgs[c].mfma_per_barrier + 350.0;   // MFMA issue + sync overhead
-            const double wg = 4000.0 + chunks * per_chunk;
             tiles += t;
-            total += t * wg;
-            if (wg > longest) longest = wg;
+            work += (double)t * chunks;
+            if (chunks > longest) longest = chunks;
         }
-        // one workgroup per CU per round; with fewer tiles than CUs the slowest tile sets the time
         const double rounds = (double)((tiles + 255) / 256);
-        const double avg = total / (double)tiles;
-        const double cost = rounds <= 1.0 ? longest : rounds * avg + (longest - avg);
+        const double avg = work / (double)tiles;
+        double cyc = tiles <= 256 ? longest * per_chunk : rounds * avg * per_chunk;
+        if (cyc < longest * per_chunk) cyc = longest * per_chunk;
+        const double cost = 9000.0 + cyc;
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
     return best;
@@ -535,8 +553,11 @@ int fcn_conv2d_fwd_f32(const fcn_conv_desc* h_desc, fcn_stream_t s) {
 
 size_t fcn_conv2d_group_workspace_bytes(int n) { return sizeof(ConvP) * (size_t)(n > 0 ? n : 0); }
 
-int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, fcn_conv_group* h_out) {
+int fcn_conv2d_num_configs(void) { return kNumCfg; }
+
+int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out) {
     FCN_REQUIRE(h_descs && h_out && d_workspace && n > 0 && n <= 16, FCN_E_ARG, "fcn_conv2d_group_prepare: need 1..16 problems, workspace, out");
+    FCN_REQUIRE(cfg_request >= -1 && cfg_request < kNumCfg, FCN_E_ARG, "fcn_conv2d_group_prepare: tile configuration %d out of range", cfg_request);
     ConvP ps[16];
     int zrc = 0;
     const float* zp = zero_page_for_current_device(&zrc);
@@ -546,7 +567,7 @@ int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_worksp
         if (rc) return rc;
         fill(ps[i], h_descs[i], zp);
     }
-    const int cfg = choose_cfg(ps, n);
+    const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
     const int total = plan_tiles_cfg(cfg, ps, n);
     FCN_HIP(hipMemcpy(d_workspace, ps, sizeof(ConvP) * n, hipMemcpyHostToDevice));
     h_out->d_probs = d_workspace;

@@ -23,7 +23,7 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 // NCHW <-> NHWC (pycaffe boundary).  32x32 LDS tile transpose over (C, H*W) per image.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                           int C, int HW, int dst_cstride, int dst_coffset) {
+                                                           int C, int HW, int dst_cstride, int dst_coffset, float shift) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int p = p0 + i, c = c0 + tx;
-        if (p < HW && c < C) d[(size_t)p * dst_cstride + dst_coffset + c] = tile[tx][i];
+        if (p < HW && c < C) d[(size_t)p * dst_cstride + dst_coffset + c] = tile[tx][i] + shift;
     }
 }
 
@@ -300,13 +300,14 @@ int launch_unary(int op, const float* x, float* y, size_t count, float a, float 
 
 extern "C" {
 
-int fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int dst_cstride, int dst_coffset, fcn_stream_t s) {
+int fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int dst_cstride, int dst_coffset, float shift,
+                         fcn_stream_t s) {
     FCN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, FCN_E_ARG, "nchw_to_nhwc: bad args");
     FCN_REQUIRE(dst_coffset >= 0 && dst_cstride >= dst_coffset + C, FCN_E_ARG, "nchw_to_nhwc: slice exceeds dst_cstride");
     FCN_REQUIRE(N <= 65535, FCN_E_UNSUPPORTED, "nchw_to_nhwc: batch too large");
     const int HW = H * W;
     dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, dst_cstride, dst_coffset);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, dst_cstride, dst_coffset, shift);
     FCN_LAUNCH_CHECK("nchw_to_nhwc");
     return 0;
 }

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__
 }
 
 __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restrict__ frame, int h, int w, float* __restrict__ dst, int H,
-                                                          int W, int cstride, const int* __restrict__ mm) {
+                                                          int W, int cstride, float shift, const int* __restrict__ mm) {
     double gmin = 1e300, gmax = -1e300;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
             const double s11 = ((double)frame[((size_t)sy1 * w + sx1) * 3 + c] - m - gmin) / range;
             const double r0 = s00 * a0 + s01 * a1;
             const double r1 = s10 * a0 + s11 * a1;
-            dst[(size_t)t * cstride + c] = (float)(r0 * b0 + r1 * b1);
+            dst[(size_t)t * cstride + c] = (float)(r0 * b0 + r1 * b1) + shift;   // blob value rounded to f32 first, as Caffe's Power layer sees it
         }
     }
 }
@@ -92,14 +92,15 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
 
 extern "C" {
 
-int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride, float* d_minmax, fcn_stream_t s) {
+int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
+                        fcn_stream_t s) {
     FCN_REQUIRE(frame && dst && d_minmax && h > 0 && w > 0 && H > 0 && W > 0 && dst_cstride >= 3, FCN_E_ARG, "preprocess: bad args");
     hipStream_t st = as_stream(s);
     int* mm = reinterpret_cast<int*>(d_minmax);
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(64), 0, st, mm);
     hipLaunchKernelGGL(minmax_kernel, dim3(stream_grid((long long)h * w, 256)), dim3(256), 0, st, frame, (long long)h * w, mm);
     hipLaunchKernelGGL(resize_norm_kernel, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, st, frame, h, w, dst, H, W, dst_cstride,
-                       mm);
+                       shift, mm);
     FCN_LAUNCH_CHECK("preprocess_bgr8");
     return 0;
 }

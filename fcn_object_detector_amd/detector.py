@@ -211,7 +211,7 @@ class FCNObjectDetector:
             data = eng.blobs["data"]
             L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, frame.ctypes.data, frame.nbytes, eng.stream)
             L.call("fcn_preprocess_bgr8", self._frame_dev.ptr, h, w, data.ptr, self.im_height, self.im_width, data.cstride,
-                   self._minmax.ptr, eng.stream)
+                   data.upload_shift, self._minmax.ptr, eng.stream)
             eng.forward_resident(1)
             self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
             dets, labels = self.decoder.fetch(eng.stream)[0]

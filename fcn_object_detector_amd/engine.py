@@ -96,7 +96,8 @@ class Blob:
         self.buf: Optional[DeviceBuffer] = None
         self.coffset = 0
         self.cstride = 0
-        self.lazy_shift = 0.0          # value added when the blob is read back (fused Power layer)
+        self.lazy_shift = 0.0          # value added when the blob is read back (Power layer folded into the upload)
+        self.upload_shift = 0.0        # value added while the blob is uploaded (device copy = host + upload_shift)
         self.host: Optional[np.ndarray] = None
         self.pinned: Optional[PinnedArray] = None
         self.host_valid = False        # host copy reflects the device contents
@@ -136,11 +137,12 @@ class Engine:
 
     def __init__(self, spec: NetSpec, data_shapes: Optional[Dict[str, Tuple[int, ...]]] = None,
                  params: Optional[Dict[str, List[np.ndarray]]] = None, device: int = 0,
-                 fuse: bool = True, group_convs: bool = True):
+                 fuse: bool = True, group_convs: bool = True, autotune: bool = True):
         self.spec = spec
         self.device = device
         self.fuse = fuse
         self.group_convs = group_convs
+        self.autotune = autotune
         L.call("fcn_init", device)
         sp = C.c_void_p()
         L.call("fcn_stream_create", C.byref(sp))
@@ -200,11 +202,13 @@ class Engine:
             elif l.type == "Dropout" and spec.phase == "TEST" and l.tops[0] != l.bottoms[0]:
                 alias[l.tops[0]] = (l.bottoms[0], 0)       # identity at test time: share the view
             elif l.type == "Power" and self.fuse and l.tops[0] != l.bottoms[0]:
+                # Power(shift) directly on a net input that nothing else reads: the upload adds the shift, the
+                # device buffer holds the transformed blob and both names share it
                 p = l.sub("power_param")
-                cons = consumers.get(l.tops[0], [])
-                if (float(p.get("power", 1.0)) == 1.0 and float(p.get("scale", 1.0)) == 1.0 and cons
-                        and all(q.type == "Convolution" for q in cons)):
-                    alias[l.tops[0]] = (l.bottoms[0], 0)
+                bot = l.bottoms[0]
+                if (float(p.get("power", 1.0)) == 1.0 and float(p.get("scale", 1.0)) == 1.0 and bot in data_tops
+                        and bot not in alias and len(consumers.get(bot, [])) == 1 and len(self.shapes[bot]) == 4):
+                    alias[l.tops[0]] = (bot, 0)
                     shift[l.tops[0]] = float(p.get("shift", 0.0))
             elif l.type == "Slice":
                 n, c, h, w = self.shapes[l.bottoms[0]]
@@ -239,7 +243,9 @@ class Engine:
                     raise RuntimeError("alias cycle at blob %s" % name)
             b, r = self.blobs[name], self.blobs[root]
             b.buf, b.coffset, b.cstride = r.buf, r.coffset + off, r.cstride
-            b.lazy_shift = total_shift
+            if total_shift:
+                r.upload_shift = total_shift      # device copy of the input = host value + shift
+                r.lazy_shift = -total_shift       # reading the input back undoes it
         for nm in self.inputs:
             if nm in self.blobs:
                 self.blobs[nm].is_input = True
@@ -323,7 +329,7 @@ class Engine:
             d.y2, d.y2_cstride, d.y2_coffset = sb.buf.ptr, sb.cstride, sb.coffset
             flags |= L.CONV_SIGMOID2
         d.flags = flags
-        d.in_shift = xb.lazy_shift
+        d.in_shift = 0.0
         return d
 
     def _range(self, name: str) -> Tuple[int, int, int]:
@@ -408,17 +414,15 @@ class Engine:
                 name = "+".join(it["layer"].name for it in chunk)
                 flops = sum(it["flops"] for it in chunk)
                 byts = sum(it["bytes"] for it in chunk)
-                if len(chunk) == 1:
-                    desc = chunk[0]["desc"]
-                    self._keep.append(desc)
-                    self.ops.append(Op("conv", name, lambda st, d=desc: L.check(lib.fcn_conv2d_fwd_f32(C.byref(d), st)), flops, byts))
-                    continue
                 arr = (L.ConvDesc * len(chunk))(*[it["desc"] for it in chunk])
                 ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(chunk))), zero=False)
                 grp = L.ConvGroup()
-                L.call("fcn_conv2d_group_prepare", arr, len(chunk), ws.ptr, C.byref(grp))
+                cfg = self._pick_conv_cfg(arr, len(chunk), ws) if self.autotune else -1
+                L.call("fcn_conv2d_group_prepare", arr, len(chunk), ws.ptr, cfg, C.byref(grp))
                 self._keep.extend([arr, ws, grp])
-                self.ops.append(Op("conv_group", name, lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
+                kind = "conv_group" if len(chunk) > 1 else "conv"
+                self.ops.append(Op(kind, "%s [cfg%d %dwg]" % (name, grp.cfg, grp.total_tiles),
+                                   lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
 
         pending: List[dict] = []
         cur = None
@@ -432,6 +436,32 @@ class Engine:
                 self.ops.extend(tasks[i]["ops"])
         emit_convs(pending)
         self.levels = max(levels) + 1 if levels else 0
+
+    def _pick_conv_cfg(self, arr, n: int, ws: DeviceBuffer) -> int:
+        """Plan-time autotune of one grouped launch: time every tile configuration on the device, keep the fastest."""
+        lib = L.load()
+        if not hasattr(self, "_tune_events"):
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            L.call("fcn_event_create", C.byref(e0))
+            L.call("fcn_event_create", C.byref(e1))
+            self._tune_events = (e0, e1)
+        e0, e1 = self._tune_events
+        best, best_ms = -1, 1e30
+        grp = L.ConvGroup()
+        for cfg in range(int(lib.fcn_conv2d_num_configs())):
+            L.call("fcn_conv2d_group_prepare", arr, n, ws.ptr, cfg, C.byref(grp))
+            for _ in range(2):
+                L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))
+            L.call("fcn_event_record", e0, self.stream)
+            for _ in range(6):
+                L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))
+            L.call("fcn_event_record", e1, self.stream)
+            L.call("fcn_event_sync", e1)
+            ms = C.c_float()
+            L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+            if ms.value < best_ms:
+                best, best_ms = cfg, ms.value
+        return best
 
     def _emit_simple(self, l: Layer) -> List[Op]:
         B, lib, t = self.blobs, L.load(), l.type
@@ -554,7 +584,7 @@ class Engine:
         n, c, h, w = b.shape
         st = self._stage(name)
         L.check(lib.fcn_memcpy_h2d_async(st.ptr, host.ctypes.data, host.nbytes, stream))
-        L.check(lib.fcn_nchw_to_nhwc_f32(st.ptr, b.buf.ptr, n, c, h, w, b.cstride, b.coffset, stream))
+        L.check(lib.fcn_nchw_to_nhwc_f32(st.ptr, b.buf.ptr, n, c, h, w, b.cstride, b.coffset, b.upload_shift, stream))
 
     def _enqueue_download(self, name: str, stream: Optional[int]) -> None:
         b = self.blobs[name]

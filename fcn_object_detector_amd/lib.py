@@ -82,11 +82,12 @@ PROTOTYPES = {
     "fcn_graph_end": (_i, [_vp, C.POINTER(_vp)]),
     "fcn_graph_launch": (_i, [_vp, _vp]),
     "fcn_graph_destroy": (_i, [_vp]),
-    "fcn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "fcn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fcn_conv2d_fwd_f32": (_i, [C.POINTER(ConvDesc), _vp]),
     "fcn_conv2d_group_workspace_bytes": (_sz, [_i]),
-    "fcn_conv2d_group_prepare": (_i, [C.POINTER(ConvDesc), _i, _vp, C.POINTER(ConvGroup)]),
+    "fcn_conv2d_num_configs": (_i, []),
+    "fcn_conv2d_group_prepare": (_i, [C.POINTER(ConvDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),
     "fcn_conv2d_fwd_group_f32": (_i, [C.POINTER(ConvGroup), _vp]),
     "fcn_maxpool_fwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "fcn_avepool_fwd_f32": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
@@ -97,7 +98,7 @@ PROTOTYPES = {
     "fcn_eltwise_fwd_f32": (_i, [_vp, _vp, _vp, _sz, _i, _f, _f, _vp]),
     "fcn_copy_channels_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fcn_deconv_depthwise_fwd_f32": (_i, [_vp, _vp, _vp, _vp] + [_i] * 12 + [_vp]),
-    "fcn_preprocess_bgr8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "fcn_preprocess_bgr8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp]),
     "fcn_detect_workspace_bytes": (_sz, [C.POINTER(DetectParams), _i]),
     "fcn_detect_decode_group": (_i, [_vp, _vp, _i, _sz, _sz, C.POINTER(DetectParams), _vp, _vp, _vp, _vp, _vp]),
     "fcn_gen_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -77,14 +77,15 @@ int  fcn_graph_launch(fcn_graph_t g, fcn_stream_t s);
 int  fcn_graph_destroy(fcn_graph_t g);
 
 /* ---- blob layout at the pycaffe boundary (blob.data is NCHW) ---- */
-/* dst[n,h,w,dst_coffset + c] = src[n,c,h,w]; dst channel stride dst_cstride */
+/* dst[n,h,w,dst_coffset + c] = src[n,c,h,w] + shift; dst channel stride dst_cstride.  `shift` lets the
+ * upload of the net input absorb a following Power(shift) layer (models/deploy.prototxt:8-16). */
 int  fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W,
-                          int dst_cstride, int dst_coffset, fcn_stream_t s);
+                          int dst_cstride, int dst_coffset, float shift, fcn_stream_t s);
 int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W,
                           int src_cstride, int src_coffset, fcn_stream_t s);
 
-/* ---- Convolution (+bias, fused in-place ReLU / Sigmoid / Power shift):
- *      Caffe ConvolutionLayer::Forward_gpu, ReLULayer, SigmoidLayer, PowerLayer as run by
+/* ---- Convolution (+bias, fused in-place ReLU / Sigmoid):
+ *      Caffe ConvolutionLayer::Forward_gpu, ReLULayer, SigmoidLayer as run by
  *      net.forward() (fcn_object_detector.py:87) over models/deploy.prototxt:8-2176 ---- */
 #define FCN_CONV_RELU      1   /* y = max(y, 0)                                  */
 #define FCN_CONV_SIGMOID2  2   /* y2 = sigmoid(y) is written as well (y2 != NULL) */
@@ -98,7 +99,7 @@ typedef struct fcn_conv_desc {
     int32_t Cout, kh, kw, pad, stride, OH, OW;
     int32_t y_cstride, y_coffset, y2_cstride, y2_coffset;
     int32_t flags;
-    float   in_shift;    /* added to every in-bounds input element (Power layer, shift) */
+    float   in_shift;    /* reserved, must be 0 (a Power(shift) input transform is applied by the producer of x) */
 } fcn_conv_desc;
 /* one problem */
 int  fcn_conv2d_fwd_f32(const fcn_conv_desc* h_desc, fcn_stream_t s);
@@ -113,7 +114,10 @@ typedef struct fcn_conv_group {
     int32_t total_tiles;
 } fcn_conv_group;
 size_t fcn_conv2d_group_workspace_bytes(int n);
-int  fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, fcn_conv_group* h_out);
+/* cfg_request: -1 = built-in heuristic, 0 .. fcn_conv2d_num_configs()-1 = that tile configuration (the engine
+ * times every configuration once per launch at plan time and keeps the fastest) */
+int  fcn_conv2d_num_configs(void);
+int  fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out);
 int  fcn_conv2d_fwd_group_f32(const fcn_conv_group* h_group, fcn_stream_t s);
 
 /* ---- Pooling / LRN / pointwise: Caffe PoolingLayer, LRNLayer, EltwiseLayer ---- */
@@ -149,10 +153,11 @@ int  fcn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* b
 /* ---- inference pre-processing: demean_rgb_image + cv.resize + HWC->CHW
  *      (fcn_object_detector.py:79-82, 407-413) ---- */
 /* h/w x 3 uint8 BGR frame -> NHWC float32 (C padded to dst_cstride) in [0,1]:
- * (px - mean[c] - min) / (max - min) over the whole frame, then bilinear resize to (H, W).
+ * (px - mean[c] - min) / (max - min) over the whole frame, then bilinear resize to (H, W), then + shift
+ * (the net's Power(shift) input transform, models/deploy.prototxt:8-16; pass 0 to get the blob itself).
  * d_minmax is a 32-byte device scratch (per-channel uint8 min and max, as int32). */
 int  fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride,
-                         float* d_minmax, fcn_stream_t s);
+                         float shift, float* d_minmax, fcn_stream_t s);
 
 /* ---- DetectNet post-processing: gridbox_to_boxes + vote_boxes -> cv.groupRectangles
  *      (fcn_object_detector.py:337-394; OpenCV 3 objdetect groupRectangles/partition) ---- */

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def run_conv(x, w, b, pad, stride, flags=0, in_shift=0.0, y_cstride=None, y_coffset=0, x_cstride=None, want_y2=False):
+def run_conv(x, w, b, pad, stride, flags=0, y_cstride=None, y_coffset=0, x_cstride=None, want_y2=False):
     n, cin, h, wd = x.shape
     cout, _, k, _ = w.shape
     oh, ow = R.conv_out(h, k, pad, stride), R.conv_out(wd, k, pad, stride)
@@ -27,7 +27,7 @@ def run_conv(x, w, b, pad, stride, flags=0, in_shift=0.0, y_cstride=None, y_coff
     bd = dev_from(b) if b is not None else None
     yd = dev_from(np.full((n, oh, ow, ycs), -7.0, np.float32))
     y2d = dev_from(np.zeros((n, oh, ow, cout), np.float32)) if want_y2 else None
-    d = conv_desc(xd, wdv, bd, yd, n, h, wd, cin4, xcs, cout, k, pad, stride, oh, ow, ycs, y_coffset, flags, in_shift,
+    d = conv_desc(xd, wdv, bd, yd, n, h, wd, cin4, xcs, cout, k, pad, stride, oh, ow, ycs, y_coffset, flags, 0.0,
                   y2d, cout if want_y2 else 0, 0)
     L.call("fcn_conv2d_fwd_f32", C.byref(d), None)
     yfull = dev_to(yd, (n, oh, ow, ycs))
@@ -82,14 +82,13 @@ def test_conv_asymmetric_identity_layout(gpu):
     assert np.array_equal(y.reshape(cout, 64), wt.reshape(cout, cin))   # y[o, pixel i] = W[o, i]
 
 
-def test_conv_epilogue_relu_slice_and_shift(gpu):
+def test_conv_epilogue_relu_slice(gpu):
     rng = np.random.default_rng(5)
-    x = rng.random((1, 3, 20, 20)).astype(np.float32)
+    x = rng.random((1, 3, 20, 20)).astype(np.float32) - np.float32(127.0)      # Power(shift=-127)'d input, zero padding after it
     wt = rng.standard_normal((40, 3, 7, 7)).astype(np.float32) * 0.05
     b = rng.standard_normal(40).astype(np.float32)
-    # Power(shift=-127) fused into the loader: padding stays zero AFTER the shift (models/deploy.prototxt:8-16)
-    y, yfull = run_conv(x, wt, b, 3, 2, flags=L.CONV_RELU, in_shift=-127.0, y_cstride=96, y_coffset=24)
-    ref = R.relu(R.conv2d(R.power(x, shift=-127.0), wt, b, 3, 2))
+    y, yfull = run_conv(x, wt, b, 3, 2, flags=L.CONV_RELU, y_cstride=96, y_coffset=24)
+    ref = R.relu(R.conv2d(x, wt, b, 3, 2))
     assert rel_err(y, ref) < TOL
     assert np.all(yfull[..., :24] == -7.0) and np.all(yfull[..., 64:] == -7.0)      # neighbours of the slice untouched
 
@@ -124,7 +123,7 @@ def test_conv_group_launch(gpu):
     lib = L.load()
     wsd = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(4)), zero=False)
     grp = L.ConvGroup()
-    L.call("fcn_conv2d_group_prepare", arr, 4, wsd.ptr, C.byref(grp))
+    L.call("fcn_conv2d_group_prepare", arr, 4, wsd.ptr, -1, C.byref(grp))
     L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
     y = nchw(dev_to(yd, (1, 14, 14, total)), total)
     ref = np.concatenate([R.relu(R.conv2d(x, wt, b, k // 2, 1)) for wt, b, k in zip(ws, bs, ks)], axis=1)
@@ -190,7 +189,10 @@ def test_layout_roundtrip(gpu):
     x = rng.standard_normal((3, 37, 9, 13)).astype(np.float32)
     xd = dev_from(x)
     yd = dev_from(np.zeros((3, 9, 13, 48), np.float32))
-    L.call("fcn_nchw_to_nhwc_f32", xd.ptr, yd.ptr, 3, 37, 9, 13, 48, 8, None)
+    L.call("fcn_nchw_to_nhwc_f32", xd.ptr, yd.ptr, 3, 37, 9, 13, 48, 8, -127.0, None)
+    y = dev_to(yd, (3, 9, 13, 48))
+    assert np.array_equal(y[..., 8:45], x.transpose(0, 2, 3, 1) + np.float32(-127.0))
+    L.call("fcn_nchw_to_nhwc_f32", xd.ptr, yd.ptr, 3, 37, 9, 13, 48, 8, 0.0, None)
     y = dev_to(yd, (3, 9, 13, 48))
     assert np.array_equal(y[..., 8:45], x.transpose(0, 2, 3, 1)) and np.all(y[..., :8] == 0) and np.all(y[..., 45:] == 0)
     zd = dev_from(np.zeros_like(x))

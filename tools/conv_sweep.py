@@ -70,7 +70,7 @@ def main():
             else:
                 os.environ["FCN_CONV_CFG"] = cfg
             grp = L.ConvGroup()
-            L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, C.byref(grp))
+            L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, -1 if cfg == "auto" else int(cfg), C.byref(grp))
             for _ in range(3):
                 L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
             L.call("fcn_event_record", e0, st)
