@@ -141,9 +141,18 @@ def main() -> None:
                 sys.stderr.write("%-10s %-60s %8.2f us %7.2f TF/s %7.1f GB/s\n" % (k, n[:60], ms * 1e3, fl / ms / 1e9 if ms else 0,
                                                                                   by / ms / 1e6 if ms else 0))
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
+        traffic = None      # HBM bytes per conv launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
+        try:
+            pf = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_fetch.json")))["conv_fwd_hbm"]
+            pw = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_write.json")))["conv_fwd_hbm"]
+            traffic = round(pf["read_bytes_per_launch"] + pw["write_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "mfma", "kernel": "conv_fwd (f32 MFMA implicit GEMM; %d launches covering the 59 convolutions)" % len(conv),
                     "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "traffic_note": "HBM bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE (profiles/r01_bench_pmc_*.json); "
+                                    "algorithmic bytes per launch = %.0f" % (sum(o[4] for o in conv) / max(len(conv), 1)),
                     "avg_launch_us": round(conv_ms * 1e3 / max(len(conv), 1), 2), "launches_per_step": len(ops),
                     "sum_kernel_ms_per_step": round(all_ms, 4),
                     "whole_step_tflops": round(FWD_GFLOP * args.batch / ms_per_step, 3)}

@@ -417,7 +417,7 @@ class Engine:
                 arr = (L.ConvDesc * len(chunk))(*[it["desc"] for it in chunk])
                 ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(chunk))), zero=False)
                 grp = L.ConvGroup()
-                cfg = self._pick_conv_cfg(arr, len(chunk), ws) if self.autotune else -1
+                cfg = self._tuned_cfg(name, arr, len(chunk), ws) if self.autotune else -1
                 L.call("fcn_conv2d_group_prepare", arr, len(chunk), ws.ptr, cfg, C.byref(grp))
                 self._keep.extend([arr, ws, grp])
                 kind = "conv_group" if len(chunk) > 1 else "conv"
@@ -436,6 +436,33 @@ class Engine:
                 self.ops.extend(tasks[i]["ops"])
         emit_convs(pending)
         self.levels = max(levels) + 1 if levels else 0
+
+    def _tuned_cfg(self, name: str, arr, n: int, ws: DeviceBuffer) -> int:
+        """Autotuned tile configuration of one grouped launch, remembered in $FCN_TUNE_CACHE (JSON) when that is set so
+        that a profiled run replays the plan of an earlier run without the tuning launches."""
+        import json
+        import os
+        path = os.environ.get("FCN_TUNE_CACHE")
+        if path and not hasattr(self, "_tune_cache"):
+            try:
+                with open(path) as f:
+                    self._tune_cache = json.load(f)
+            except (OSError, ValueError):
+                self._tune_cache = {}
+        cache = getattr(self, "_tune_cache", None)
+        key = "%s|%s" % (name, "x".join(str(d) for d in self.shapes.get(self.inputs[0], ())) if self.inputs else "")
+        ncfg = int(L.load().fcn_conv2d_num_configs())
+        if cache is not None and key in cache and 0 <= int(cache[key]) < ncfg:
+            return int(cache[key])
+        cfg = self._pick_conv_cfg(arr, n, ws)
+        if cache is not None:
+            cache[key] = cfg
+            try:
+                with open(path, "w") as f:
+                    json.dump(cache, f, indent=0, sort_keys=True)
+            except OSError:
+                pass
+        return cfg
 
     def _pick_conv_cfg(self, arr, n: int, ws: DeviceBuffer) -> int:
         """Plan-time autotune of one grouped launch: time every tile configuration on the device, keep the fastest."""
