@@ -1,0 +1,111 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle):
+CPU tests keep the oracle from drifting away from them; -m gpu tests hold the HIP path to the same vectors."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+from fcn_object_detector_amd import models, proto
+from fcn_object_detector_amd.netspec import NetSpec, fill_params
+from oracle import caffe_ref as R
+from oracle import detect_ref as D
+from oracle.net_ref import RefNet
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def test_oracle_reproduces_layer_fixtures():
+    g = load("layers")
+    assert np.allclose(R.relu(R.conv2d(g["conv_x"], g["conv_w"], g["conv_b"], 1, 1)), g["conv_y"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(R.conv2d(g["conv7_x"], g["conv7_w"], None, 3, 2), g["conv7_y"], rtol=1e-5, atol=1e-4)
+    y, idx = R.max_pool(g["pool_x"], 3, 2, 0, return_index=True)
+    assert np.array_equal(y, g["pool_y"]) and np.array_equal(idx, g["pool_idx"])
+    assert np.array_equal(R.max_pool(g["pool_x"], 3, 1, 1), g["pool31_y"])
+    assert np.allclose(R.lrn_across(g["lrn_x"], 5, 1e-4, 0.75, 1.0), g["lrn_y"], rtol=1e-6)
+    assert np.allclose(R.deconv2d(g["deconv_x"], R.bilinear_filler((4, 1, 8, 8)), None, 2, 4, group=4), g["deconv_y"], rtol=1e-6, atol=1e-6)
+
+
+def test_oracle_reproduces_net_detect_target_fixtures():
+    g = load("net_64x96")
+    assert np.array_equal(D.preprocess_frame(g["frame"], 96, 64)[None], g["data"])
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(1, 64, 96, 2))
+    spec = NetSpec(msg, "TEST"); spec.infer()
+    ref = RefNet(msg, "TEST", fill_params(spec, seed=1234))
+    ref.blobs["data"] = g["data"]
+    b = ref.forward()
+    assert rel_err(b["coverage"], g["coverage"]) < 1e-5 and rel_err(b["bboxes"], g["bboxes"]) < 1e-5
+    d = load("detect")
+    det, lab = D.detect(d["cvg"][0], d["bbox"][0], 448, 448, 16, 0.5, 3, 0.2)
+    assert np.array_equal(det, d["det"]) and np.array_equal(lab, d["lab"]) and len(det) >= 3
+    det, lab = D.detect(d["cvg"][0], d["bbox"][0], 448, 448, 16, 0.5, 3, 0.2, round_mode="trunc")
+    assert np.array_equal(det, d["det_trunc"]) and np.array_equal(lab, d["lab_trunc"])
+    t = load("targets")
+    offs = t["offsets"]
+    for i in range(3):
+        rects = [tuple(int(v) for v in r) for r in t["rects"][offs[i]:offs[i + 1]]]
+        labels = [int(v) for v in t["labels"][offs[i]:offs[i + 1]]]
+        out = D.bounding_box_parameterized_labels(448, 448, rects, labels, 16, 3)
+        for name, o in zip(("fg", "bbox", "size", "obj", "cvg"), out):
+            assert np.array_equal(o.astype(np.float32), t[name][i])
+
+
+@pytest.mark.gpu
+def test_hip_matches_layer_fixtures(gpu):
+    from fcn_object_detector_amd import lib as L
+    from gpu_util import conv_desc, dev_from, dev_to, nchw, nhwc, pack_ohwi
+    g = load("layers")
+    x, w, b = g["conv_x"], g["conv_w"], g["conv_b"]
+    xd, wd, bd = dev_from(nhwc(x)), dev_from(pack_ohwi(w)), dev_from(b)
+    yd = dev_from(np.zeros((1, 9, 11, 20), np.float32))
+    d = conv_desc(xd, wd, bd, yd, 1, 9, 11, 12, 12, 20, 3, 1, 1, 9, 11, 20, 0, L.CONV_RELU)
+    L.call("fcn_conv2d_fwd_f32", C.byref(d), None)
+    assert rel_err(nchw(dev_to(yd, (1, 9, 11, 20)), 20), g["conv_y"]) < 1e-4
+    x7, w7 = g["conv7_x"], g["conv7_w"]
+    xd, wd = dev_from(nhwc(x7, 4)), dev_from(pack_ohwi(w7))
+    yd = dev_from(np.zeros((1, 11, 9, 8), np.float32))
+    d = conv_desc(xd, wd, None, yd, 1, 21, 17, 4, 4, 8, 7, 3, 2, 11, 9, 8)
+    L.call("fcn_conv2d_fwd_f32", C.byref(d), None)
+    assert rel_err(nchw(dev_to(yd, (1, 11, 9, 8)), 8), g["conv7_y"]) < 1e-4
+    p = g["pool_x"]
+    xd = dev_from(nhwc(p))
+    yd, idd = dev_from(np.zeros((2, 7, 7, 8), np.float32)), dev_from(np.zeros((2, 7, 7, 8), np.int32))
+    L.call("fcn_maxpool_fwd_f32", xd.ptr, yd.ptr, idd.ptr, 2, 15, 14, 8, 8, 3, 2, 0, 7, 7, 8, 0, None)
+    assert np.array_equal(nchw(dev_to(yd, (2, 7, 7, 8)), 8), g["pool_y"])
+    assert np.array_equal(dev_to(idd, (2, 7, 7, 8), np.int32).transpose(0, 3, 1, 2), g["pool_idx"])
+    l = g["lrn_x"]
+    xd, yd = dev_from(nhwc(l)), dev_from(np.zeros((1, 5, 6, 16), np.float32))
+    L.call("fcn_lrn_fwd_f32", xd.ptr, yd.ptr, None, 30, 16, 16, 16, 5, 1e-4, 0.75, 1.0, None)
+    assert rel_err(nchw(dev_to(yd, (1, 5, 6, 16)), 16), g["lrn_y"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_matches_net_detect_target_fixtures(gpu):
+    from fcn_object_detector_amd import lib as L
+    from fcn_object_detector_amd.detector import FCNObjectDetector, HeadMapping, detect_from_maps, generate_targets
+    from fcn_object_detector_amd.engine import Engine
+    g = load("net_64x96")
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(1, 64, 96, 2))
+    spec = NetSpec(msg, "TEST"); spec.infer()
+    eng = Engine(NetSpec(msg, "TEST"), params=fill_params(spec, seed=1234), device=0)
+    FCNObjectDetector(eng, mapping=HeadMapping.detectnet_deploy()).run_detector(g["frame"])      # device pre-processing
+    assert np.abs(eng.read_blob("data") - g["data"]).max() <= 4e-6
+    assert rel_err(eng.read_blob("coverage"), g["coverage"]) < 1e-3 and rel_err(eng.read_blob("bboxes"), g["bboxes"]) < 1e-3
+    assert rel_err(eng.read_blob("pool3/3x3_s2")[:, :16], g["pool3"]) < 1e-3
+    assert abs(float(eng.read_blob("inception_4c/output").astype(np.float64).sum()) - g["inc4c_sum"][0]) < 1e-3 * abs(g["inc4c_sum"][0])
+    eng.close()
+    d = load("detect")
+    det, lab = detect_from_maps(d["cvg"], d["bbox"], 448, 448)[0]
+    assert np.array_equal(det, d["det"]) and np.array_equal(lab, d["lab"])
+    det, lab = detect_from_maps(d["cvg"], d["bbox"], 448, 448, round_mode=L.RECT_ROUND_TRUNCATE)[0]
+    assert np.array_equal(det, d["det_trunc"]) and np.array_equal(lab, d["lab_trunc"])
+    t = load("targets")
+    offs = t["offsets"]
+    rects = [[tuple(int(v) for v in r) for r in t["rects"][offs[i]:offs[i + 1]]] for i in range(3)]
+    labels = [[int(v) for v in t["labels"][offs[i]:offs[i + 1]]] for i in range(3)]
+    out = generate_targets(rects, labels, 448, 448, 16, 3)
+    for name, o in zip(("fg", "bbox", "size", "obj", "cvg"), out):
+        assert np.array_equal(o, t[name])
