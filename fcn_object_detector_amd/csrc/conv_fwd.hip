@@ -374,6 +374,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
     const bool do_sig2 = (p.flags & FCN_CONV_SIGMOID2) != 0 && p.y2 != nullptr;
+    const bool do_accum = (p.flags & FCN_CONV_ACCUM) != 0;
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
         const int n = n0 + (wn * WTN + j) * 32 + (lane & 31);
@@ -387,8 +388,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 const int m = mrow + (r & 3) + 8 * (r >> 2);
                 if (m < p.M) {
                     float v = acc[i][j][r] + bv;
+                    gf_ptr dst = (gf_ptr)(p.y + (size_t)m * p.y_cstride + p.y_coffset + n);
+                    if (do_accum) v += *dst;
                     if (do_relu) v = fmaxf(v, 0.f);
-                    *(gf_ptr)(p.y + (size_t)m * p.y_cstride + p.y_coffset + n) = v;
+                    *dst = v;
                     if (do_sig2) *(gf_ptr)(p.y2 + (size_t)m * p.y2_cstride + p.y2_coffset + n) = 1.f / (1.f + expf(-v));
                 }
             }

@@ -1,0 +1,543 @@
+// Backward pass, losses and solver updates for gfx950.
+//
+// Stands in for the part of the reference's hot path that runs inside `caffe train`
+// (reference: train/train.sh:25-28; program = models/train_val.prototxt:53-72,2237-2281 and the
+// solver settings of train/*/solver.prototxt): Net::Backward of every layer type of the DetectNet
+// training net, the NVIDIA-Caffe L1Loss / EuclideanLoss layers, Dropout in TRAIN phase, and
+// SGDSolver / AdamSolver::ComputeUpdateValue with L2 regularisation and per-blob lr_mult / decay_mult.
+//
+//   * weight gradient  dW[n][k] = sum_m dY[m][n] * A[m][k]   (k = (r*kw+q)*Cin + c, same order as the weights):
+//     an MFMA GEMM whose REDUCTION runs over the pixels m.  Both operands are staged pixel-major with LDS-DMA
+//     (dY rows and im2col rows are channel-contiguous in NHWC) and read with ds_read_b32 — lane (i, p) of the
+//     32x32x2 MFMA reads element i of pixel row p, i.e. a transposed-operand read that is conflict-free because
+//     32 consecutive lanes walk 32 consecutive floats.  Pixels are split over `splits` workgroups per tile; the
+//     partial slabs are summed in a fixed order (bit-reproducible, no float atomics).  The bias gradient (column
+//     sums of dY) rides along in the workgroups of the first k-tile.
+//   * data gradient = the forward convolution kernel run on dY with the flipped / transposed filter bank
+//     (fcn_conv_weights_flip_f32), accumulating into the bottom's gradient when the blob fans out.
+//   * everything else is HBM-bound NHWC pointwise work, 16 bytes per lane where the shapes allow.
+#include <math.h>
+
+#include "common.h"
+
+using namespace fcn;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+typedef const void __attribute__((address_space(1))) * gvoid_cptr;
+typedef void __attribute__((address_space(3))) * lds_ptr;
+typedef float __attribute__((address_space(1))) * gf_ptr;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------
+struct WgradP {
+    const float* x;      // NHWC input of the layer
+    const float* dy;     // NHWC gradient of the layer's output (view: dy_cstride, dy_coffset folded into the pointer)
+    float* dw_part;      // [splits][Cout][K] partial slabs
+    float* db_part;      // [splits][Cout] or nullptr
+    const float* zero_page;
+    int N, H, W, Cin, x_cstride;
+    int Cout, kh, kw, pad, stride, OH, OW;
+    int dy_cstride;
+    int M, K;
+    int tiles_n, tiles_k, splits, chunks_per_split;   // chunk = 32 pixels
+    unsigned ow_magic, ohw_magic;                      // ceil(2^32 / OW), ceil(2^32 / (OH*OW)) for the pixel decode
+    int kw_magic;
+};
+
+constexpr int WG_BP = 32;      // pixels per chunk
+constexpr int WG_BN = 64;      // output channels per workgroup
+constexpr int WG_BK = 64;      // weight k-indices per workgroup
+constexpr int WG_NBUF = 4;
+constexpr int WG_BUF_FLOATS = WG_BP * (WG_BN + WG_BK);
+
+// 256 threads = 4 waves as 2 (cout) x 2 (k); each wave owns a 32x32 tile of dW.
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
+    __shared__ __attribute__((aligned(16))) float smem[WG_NBUF * WG_BUF_FLOATS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid >> 1, wkk = wid & 1;
+
+    int b = blockIdx.x;
+    const int split = b % p.splits;
+    b /= p.splits;
+    const int tile_k = b % p.tiles_k;
+    const int tile_n = b / p.tiles_k;
+    const int n0 = tile_n * WG_BN;
+    const int k0 = tile_k * WG_BK;
+
+    // ---- loader: one LDS-DMA instruction = 1 KiB = 4 pixel rows x 64 floats; 4 waves x 2 instructions cover the
+    //      32 x 64 dY tile, another 2 per wave the 32 x 64 im2col tile.  Lane -> (row = lane / 16, slot = lane % 16).
+    const int lrow = lane >> 4, lslot = lane & 15;
+    // dY source column (fixed for the kernel)
+    const int dy_col = n0 + lslot * 4;
+    const bool dy_col_ok = dy_col < p.Cout;          // Cout is padded to 4 in the gradient buffer (cstride), columns past it read zeros
+    // im2col source: k index of this lane's segment -> (tap, channel), fixed for the kernel
+    const int kidx = k0 + lslot * 4;
+    const int ktap = kidx / p.Cin;
+    const int kch = kidx - ktap * p.Cin;
+    const int kr = (ktap * p.kw_magic) >> 16;
+    const int kq = ktap - kr * p.kw;
+    const bool k_ok = kidx < p.K;
+    unsigned long long zp_bits = reinterpret_cast<unsigned long long>(p.zero_page);
+    asm volatile("" : "+v"(zp_bits));
+    const float* zero_page = reinterpret_cast<const float*>(zp_bits);
+
+    const int chunk0 = split * p.chunks_per_split;
+    const int total_chunks = (p.M + WG_BP - 1) / WG_BP;
+    int nchunks = total_chunks - chunk0;
+    if (nchunks > p.chunks_per_split) nchunks = p.chunks_per_split;
+    if (nchunks < 0) nchunks = 0;
+    const int ohw = p.OH * p.OW;
+
+    int issue_chunk_idx = chunk0;
+    auto issue_chunk = [&](const int buf) {
+        float* dst = smem + buf * WG_BUF_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 16 * i + 4 * wid + lrow;            // pixel row inside the chunk
+            const int m = issue_chunk_idx * WG_BP + row;
+            const bool m_ok = m < p.M && issue_chunk_idx < chunk0 + nchunks;
+            // dY[m][n0 + 4*slot ..]
+            unsigned long long src = reinterpret_cast<unsigned long long>((m_ok && dy_col_ok) ? p.dy + (size_t)m * p.dy_cstride + dy_col : zero_page);
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(dst + (16 * i + 4 * wid) * WG_BN), 16, 0, 0);
+            // im2col row m, k segment
+            const int mm = m_ok ? m : 0;
+            const int img = (int)__umulhi((unsigned)mm, p.ohw_magic);
+            const int rem = mm - img * ohw;
+            const int oy = (int)__umulhi((unsigned)rem, p.ow_magic);
+            const int ox = rem - oy * p.OW;
+            const int iy = oy * p.stride - p.pad + kr;
+            const int ix = ox * p.stride - p.pad + kq;
+            const bool ok = m_ok && k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            unsigned long long srcx = reinterpret_cast<unsigned long long>(
+                ok ? p.x + ((size_t)(img * p.H + iy) * p.W + ix) * p.x_cstride + kch : zero_page);
+            asm volatile("" : "+v"(srcx));
+            __builtin_amdgcn_global_load_lds((gvoid_cptr)srcx, (lds_ptr)(dst + WG_BP * WG_BN + (16 * i + 4 * wid) * WG_BK), 16, 0, 0);
+        }
+        ++issue_chunk_idx;
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bsum = 0.f;   // bias gradient partial of channel n0 + tid (threads 0..63 of the k-tile-0 workgroups)
+    const bool do_bias = p.db_part != nullptr && tile_k == 0;
+
+    constexpr int D = WG_NBUF - 1;
+    constexpr int INST = 4;     // LDS-DMA instructions per wave per chunk
+    int buf_issue = 0, buf_cur = 0;
+    auto next = [](int v) { return v + 1 == WG_NBUF ? 0 : v + 1; };
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        issue_chunk(buf_issue);
+        buf_issue = next(buf_issue);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+    const unsigned a_addr = lds0 + 4u * ((lane >> 5) * WG_BN + wn * 32 + (lane & 31));
+    const unsigned b_addr = lds0 + 4u * (WG_BP * WG_BN + (lane >> 5) * WG_BK + wkk * 32 + (lane & 31));
+
+    for (int c = 0; c < nchunks; ++c) {
+        wait_vmcnt<INST*(D - 1)>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_chunk(buf_issue);
+        buf_issue = next(buf_issue);
+        const unsigned slot = (unsigned)buf_cur * (WG_BUF_FLOATS * 4);
+        float av[16], bv[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {       // pixel pair s: rows 2s, 2s+1
+            asm volatile("ds_read_b32 %0, %1" : "=v"(av[s]) : "v"(a_addr + slot + 4u * (2 * s * WG_BN)));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(bv[s]) : "v"(b_addr + slot + 4u * (2 * s * WG_BK)));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            asm volatile("" : "+v"(av[s]));
+            asm volatile("" : "+v"(bv[s]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+        if (do_bias && tid < WG_BN) {
+            const float* col = smem + buf_cur * WG_BUF_FLOATS + tid;
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < WG_BP; ++r) t += col[r * WG_BN];
+            bsum += t;
+        }
+        buf_cur = next(buf_cur);
+    }
+    wait_vmcnt<0>();
+
+    // dW partial slab [split][cout][k]: C/D map col = lane & 31 (k), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
+    float* slab = p.dw_part + (size_t)split * p.Cout * p.K;
+    const int kcol = k0 + wkk * 32 + (lane & 31);
+    if (kcol < p.K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (n < p.Cout) *(gf_ptr)(slab + (size_t)n * p.K + kcol) = acc[r];
+        }
+    }
+    if (do_bias && tid < WG_BN && n0 + tid < p.Cout) p.db_part[(size_t)split * p.Cout + n0 + tid] = bsum;
+}
+
+// out[i] = sum_s parts[s][i] in a fixed order
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t count,
+                                                              int splits) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += parts[(size_t)k * count + i];
+        out[i] = s;
+    }
+}
+
+// wt[c][kh-1-r][kw-1-q][k] = w[k][r][q][c]   (w: [Cout][kh][kw][Cin4], wt: [Cin][kh][kw][Cout4], pads of wt zero)
+__global__ __launch_bounds__(256) void weights_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int kh, int kw,
+                                                           int Cin, int Cin4, int Cout4) {
+    const long long total = (long long)Cin * kh * kw * Cout4;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(t % Cout4);
+        long long u = t / Cout4;
+        const int q = (int)(u % kw);
+        u /= kw;
+        const int r = (int)(u % kh);
+        const int c = (int)(u / kh);
+        wt[t] = k < Cout ? w[(((size_t)k * kh + (kh - 1 - r)) * kw + (kw - 1 - q)) * Cin4 + c] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pointwise backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                                       size_t count) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_view_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                                            long long pixels, int C, int cstride) {
+    const long long total = pixels * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const size_t o = (size_t)(t / C) * cstride + (t % C);
+        dx[o] = y[o] > 0.f ? dy[o] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                                          size_t count, int accumulate) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const float g = dy[i] * y[i] * (1.f - y[i]);
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+// MAX pool backward in gather form: every input element sums the output gradients whose argmax it is
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx, float* __restrict__ dx,
+                                                          int N, int H, int W, int C, int dx_cstride, int dx_coffset, int k, int stride,
+                                                          int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate) {
+    const long long total = (long long)N * H * W * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        long long pix = t / C;
+        const int ix = (int)(pix % W);
+        pix /= W;
+        const int iy = (int)(pix % H);
+        const int n = (int)(pix / H);
+        // outputs whose window covers (iy, ix): oy*stride - pad <= iy < oy*stride - pad + k
+        const int oy_lo = max(0, (iy + pad - k + stride) / stride), oy_hi = min(OH - 1, (iy + pad) / stride);
+        const int ox_lo = max(0, (ix + pad - k + stride) / stride), ox_hi = min(OW - 1, (ix + pad) / stride);
+        const int me = iy * W + ix;
+        float g = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const size_t o = ((size_t)(n * OH + oy) * OW + ox);
+                if (idx[o * C + c] == me) g += dy[o * dy_cstride + dy_coffset + c];
+            }
+        float* d = dx + ((size_t)(n * H + iy) * W + ix) * dx_cstride + dx_coffset + c;
+        *d = accumulate ? *d + g : g;
+    }
+}
+
+// LRN backward: dX = dY*scale^-beta - (2 alpha beta / n) * X * sum_{window} (dY * Y / scale)
+__global__ __launch_bounds__(256) void lrn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ scale,
+                                                      const float* __restrict__ dy, float* __restrict__ dx, long long pixels, int C,
+                                                      int x_cstride, int y_cstride, int local_size, float ratio2ab, float beta, int accumulate) {
+    const long long total = pixels * C;
+    const int pre = (local_size - 1) / 2;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const long long pix = t / C;
+        const float* yp = y + (size_t)pix * y_cstride;
+        const float* dyp = dy + (size_t)pix * y_cstride;
+        const float* sp = scale + (size_t)pix * C;
+        float acc = 0.f;
+        // the window of outputs c' that contain input c: c' - pre <= c <= c' - pre + n - 1
+        for (int j = c - (local_size - 1 - pre); j <= c + pre; ++j)
+            if (j >= 0 && j < C) acc += dyp[j] * yp[j] / sp[j];
+        const float g = dyp[c] * powf(sp[c], -beta) - ratio2ab * x[(size_t)pix * x_cstride + c] * acc;
+        float* d = dx + (size_t)pix * x_cstride + c;
+        *d = accumulate ? *d + g : g;
+    }
+}
+
+// counter-based dropout mask (oracle/caffe_ref.py::dropout_hash): element index = NCHW linear index
+__device__ __forceinline__ unsigned dropout_hash(unsigned index, unsigned seed) {
+    unsigned x = index + seed * 0x9E3779B9u;
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
+                                                      int x_cstride, int x_coffset, int y_cstride, int y_coffset, unsigned thresh, float scale,
+                                                      unsigned seed) {
+    const long long total = (long long)N * H * W * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        long long pix = t / C;
+        const int w = (int)(pix % W);
+        long long u = pix / W;
+        const int h = (int)(u % H);
+        const int n = (int)(u / H);
+        const unsigned nchw = (unsigned)((((long long)n * C + c) * H + h) * W + w);
+        const bool keep = dropout_hash(nchw, seed) >= thresh;
+        y[(size_t)pix * y_cstride + y_coffset + c] = keep ? x[(size_t)pix * x_cstride + x_coffset + c] * scale : 0.f;
+    }
+}
+
+// losses: one 1024-thread workgroup, fixed summation order -> reproducible
+template <bool L1>
+__global__ __launch_bounds__(1024) void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ da,
+                                                    float* __restrict__ loss, long long pixels, int C, int cstride, float inv_num, float weight) {
+    __shared__ double part[1024];
+    double s = 0.0;
+    const long long total = pixels * C;
+    for (long long t = threadIdx.x; t < total; t += 1024) {
+        const size_t o = (size_t)(t / C) * cstride + (t % C);
+        const float d = a[o] - b[o];
+        s += L1 ? fabs((double)d) : (double)d * (double)d;
+        if (da) da[o] = L1 ? ((d > 0.f) - (d < 0.f)) * weight * inv_num : d * weight * inv_num;
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(L1 ? part[0] * inv_num : part[0] * inv_num * 0.5);
+}
+
+// solver: segments of one flat parameter buffer share a launch; per-segment lr / decay multipliers
+struct SolverSeg { unsigned long long offset, count; float lr_mult, decay_mult; };
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ hist,
+                                                  const SolverSeg* __restrict__ segs, int nseg, float rate, float momentum, float decay,
+                                                  float grad_scale) {
+    const int s = blockIdx.y;
+    if (s >= nseg) return;
+    const SolverSeg seg = segs[s];
+    if (seg.lr_mult == 0.f) return;
+    const float lr = rate * seg.lr_mult, wd = decay * seg.decay_mult;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < seg.count; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long o = seg.offset + i;
+        const float gi = g[o] * grad_scale + wd * w[o];
+        const float h = momentum * hist[o] + lr * gi;
+        hist[o] = h;
+        w[o] -= h;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   const SolverSeg* __restrict__ segs, int nseg, float rate_corr, float beta1, float beta2,
+                                                   float delta, float decay, float grad_scale) {
+    const int s = blockIdx.y;
+    if (s >= nseg) return;
+    const SolverSeg seg = segs[s];
+    if (seg.lr_mult == 0.f) return;
+    const float lr = rate_corr * seg.lr_mult, wd = decay * seg.decay_mult;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < seg.count; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long o = seg.offset + i;
+        const float gi = g[o] * grad_scale + wd * w[o];
+        const float mi = beta1 * m[o] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[o] + (1.f - beta2) * gi * gi;
+        m[o] = mi;
+        v[o] = vi;
+        w[o] -= lr * mi / (sqrtf(vi) + delta);
+    }
+}
+
+unsigned magic32(unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((0x100000000ull + d - 1) / d); }
+
+}  // namespace
+
+extern "C" {
+
+size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* d, int* h_splits) {
+    if (!d || d->Cout <= 0) return 0;
+    const long long M = (long long)d->N * d->OH * d->OW, K = (long long)d->kh * d->kw * d->Cin;
+    const int tiles = cdiv(d->Cout, WG_BN) * cdiv(K, WG_BK);
+    const int chunks = cdiv(M, WG_BP);
+    int splits = cdiv(1024, tiles);
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    if (splits > 256) splits = 256;
+    if (h_splits) *h_splits = splits;
+    return (size_t)splits * ((size_t)d->Cout * K + d->Cout);
+}
+
+// dW (OHWI, [Cout][kh][kw][Cin]) and db from the layer input x and the output gradient passed in desc->y / y_cstride /
+// y_coffset (desc->w and desc->bias are ignored).  d_workspace: fcn_conv2d_wgrad_workspace_floats() floats.
+int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_workspace, fcn_stream_t s) {
+    FCN_REQUIRE(d && d->x && d->y && dw && d_workspace, FCN_E_ARG, "wgrad: null");
+    FCN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0, FCN_E_ARG,
+                "wgrad: non-positive extent");
+    FCN_REQUIRE(d->Cin % 4 == 0 && d->x_cstride % 4 == 0 && d->y_cstride % 4 == 0 && d->y_coffset % 4 == 0, FCN_E_ALIGN,
+                "wgrad: channel counts / strides / offsets must be multiples of 4");
+    FCN_REQUIRE(d->OH == (d->H + 2 * d->pad - d->kh) / d->stride + 1 && d->OW == (d->W + 2 * d->pad - d->kw) / d->stride + 1, FCN_E_ARG,
+                "wgrad: OH/OW mismatch");
+    FCN_REQUIRE((long long)d->N * d->OH * d->OW < (1ll << 31) && (long long)d->N * d->H * d->W * d->x_cstride < (1ll << 31), FCN_E_UNSUPPORTED,
+                "wgrad: tensor too large");
+    FCN_REQUIRE(d->y_cstride >= d->y_coffset + d->Cout, FCN_E_ARG, "wgrad: gradient slice exceeds its channel stride");
+    int rc = 0;
+    const float* zp = zero_page_for_current_device(&rc);
+    if (rc) return rc;
+    int splits = 1;
+    fcn_conv2d_wgrad_workspace_floats(d, &splits);
+    WgradP p;
+    p.x = d->x;
+    p.dy = d->y + d->y_coffset;
+    p.zero_page = zp;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_cstride = d->x_cstride;
+    p.Cout = d->Cout; p.kh = d->kh; p.kw = d->kw; p.pad = d->pad; p.stride = d->stride; p.OH = d->OH; p.OW = d->OW;
+    p.dy_cstride = d->y_cstride;
+    p.M = d->N * d->OH * d->OW;
+    p.K = d->kh * d->kw * d->Cin;
+    p.tiles_n = cdiv(p.Cout, WG_BN);
+    p.tiles_k = cdiv(p.K, WG_BK);
+    p.splits = splits;
+    p.chunks_per_split = cdiv(cdiv(p.M, WG_BP), splits);
+    p.ow_magic = magic32((unsigned)p.OW);
+    p.ohw_magic = magic32((unsigned)(p.OH * p.OW));
+    p.kw_magic = (65536 + p.kw - 1) / p.kw;
+    p.dw_part = d_workspace;
+    p.db_part = db ? d_workspace + (size_t)splits * p.Cout * p.K : nullptr;
+    hipStream_t st = as_stream(s);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.tiles_n * p.tiles_k * splits), dim3(256), 0, st, p);
+    const size_t cnt = (size_t)p.Cout * p.K;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(stream_grid((long long)cnt, 256)), dim3(256), 0, st, p.dw_part, dw, cnt, splits);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, p.db_part, db, (size_t)p.Cout, splits);
+    FCN_LAUNCH_CHECK("conv_wgrad");
+    return 0;
+}
+
+int fcn_conv_weights_flip_f32(const float* w, float* wt, int Cout, int kh, int kw, int Cin, int Cin4, int Cout4, fcn_stream_t s) {
+    FCN_REQUIRE(w && wt && Cout > 0 && kh > 0 && kw > 0 && Cin > 0 && Cin4 >= Cin && Cout4 >= Cout, FCN_E_ARG, "weights_flip: bad args");
+    const long long total = (long long)Cin * kh * kw * Cout4;
+    hipLaunchKernelGGL(weights_flip_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(s), w, wt, Cout, kh, kw, Cin, Cin4, Cout4);
+    FCN_LAUNCH_CHECK("weights_flip");
+    return 0;
+}
+
+int fcn_relu_bwd_f32(const float* dy, const float* y, float* dx, int pixels, int C, int cstride, fcn_stream_t s) {
+    FCN_REQUIRE(dy && y && dx && pixels > 0 && C > 0 && cstride >= C, FCN_E_ARG, "relu_bwd: bad args");
+    hipStream_t st = as_stream(s);
+    if (cstride == C)
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, st, dy, y, dx, (size_t)pixels * C);
+    else
+        hipLaunchKernelGGL(relu_bwd_view_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, st, dy, y, dx, (long long)pixels, C,
+                           cstride);
+    FCN_LAUNCH_CHECK("relu_bwd");
+    return 0;
+}
+
+int fcn_sigmoid_bwd_f32(const float* y, const float* dy, float* dx, size_t count, int accumulate, fcn_stream_t s) {
+    FCN_REQUIRE(y && dy && dx, FCN_E_ARG, "sigmoid_bwd: null");
+    if (!count) return 0;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(stream_grid((long long)count, 256)), dim3(256), 0, as_stream(s), y, dy, dx, count, accumulate);
+    FCN_LAUNCH_CHECK("sigmoid_bwd");
+    return 0;
+}
+
+int fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, int H, int W, int C, int dx_cstride, int dx_coffset, int k,
+                        int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, fcn_stream_t s) {
+    FCN_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && OH > 0 && OW > 0, FCN_E_ARG, "maxpool_bwd: bad args");
+    FCN_REQUIRE(dx_cstride >= dx_coffset + C && dy_cstride >= dy_coffset + C, FCN_E_ARG, "maxpool_bwd: channel slice out of range");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((long long)N * H * W * C, 256)), dim3(256), 0, as_stream(s), dy, idx, dx, N, H, W, C,
+                       dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate);
+    FCN_LAUNCH_CHECK("maxpool_bwd");
+    return 0;
+}
+
+int fcn_lrn_bwd_f32(const float* x, const float* y, const float* scale, const float* dy, float* dx, int pixels, int C, int x_cstride,
+                    int y_cstride, int local_size, float alpha, float beta, int accumulate, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && scale && dy && dx && pixels > 0 && C > 0 && local_size > 0, FCN_E_ARG, "lrn_bwd: bad args");
+    hipLaunchKernelGGL(lrn_bwd_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, as_stream(s), x, y, scale, dy, dx,
+                       (long long)pixels, C, x_cstride, y_cstride, local_size, 2.f * alpha * beta / (float)local_size, beta, accumulate);
+    FCN_LAUNCH_CHECK("lrn_bwd");
+    return 0;
+}
+
+// y = x * mask * 1/(1-ratio) with the counter-based mask of seed `seed`; run on activations (forward) or gradients (backward)
+int fcn_dropout_f32(const float* x, float* y, int N, int C, int H, int W, int x_cstride, int x_coffset, int y_cstride, int y_coffset,
+                    float ratio, unsigned seed, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ratio >= 0.f && ratio < 1.f, FCN_E_ARG, "dropout: bad args");
+    FCN_REQUIRE((long long)N * C * H * W < (1ll << 32), FCN_E_UNSUPPORTED, "dropout: blob too large for the 32-bit counter");
+    double t = (double)ratio * 4294967296.0;
+    const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    hipLaunchKernelGGL(dropout_kernel, dim3(stream_grid((long long)N * C * H * W, 256)), dim3(256), 0, as_stream(s), x, y, N, C, H, W, x_cstride,
+                       x_coffset, y_cstride, y_coffset, thresh, 1.f / (1.f - ratio), seed);
+    FCN_LAUNCH_CHECK("dropout");
+    return 0;
+}
+
+// kind 0: L1Loss (NVIDIA Caffe): loss = sum|a-b| / num, da = sign(a-b) * weight / num
+// kind 1: EuclideanLoss:         loss = sum (a-b)^2 / (2 num), da = (a-b) * weight / num        (da may be NULL)
+int fcn_loss_f32(int kind, const float* a, const float* b, float* da, float* d_loss, int pixels, int C, int cstride, int num, float weight,
+                 fcn_stream_t s) {
+    FCN_REQUIRE(a && b && d_loss && pixels > 0 && C > 0 && cstride >= C && num > 0 && (kind == 0 || kind == 1), FCN_E_ARG, "loss: bad args");
+    hipStream_t st = as_stream(s);
+    if (kind == 0)
+        hipLaunchKernelGGL(loss_kernel<true>, dim3(1), dim3(1024), 0, st, a, b, da, d_loss, (long long)pixels, C, cstride, 1.f / (float)num, weight);
+    else
+        hipLaunchKernelGGL(loss_kernel<false>, dim3(1), dim3(1024), 0, st, a, b, da, d_loss, (long long)pixels, C, cstride, 1.f / (float)num, weight);
+    FCN_LAUNCH_CHECK("loss");
+    return 0;
+}
+
+int fcn_sgd_update_f32(float* w, const float* g, float* hist, const fcn_solver_seg* d_segs, int nseg, float rate, float momentum,
+                       float weight_decay, float grad_scale, fcn_stream_t s) {
+    FCN_REQUIRE(w && g && hist && d_segs && nseg > 0 && nseg <= 65535, FCN_E_ARG, "sgd_update: bad args");
+    hipLaunchKernelGGL(sgd_kernel, dim3(64, nseg), dim3(256), 0, as_stream(s), w, g, hist, reinterpret_cast<const SolverSeg*>(d_segs), nseg, rate,
+                       momentum, weight_decay, grad_scale);
+    FCN_LAUNCH_CHECK("sgd_update");
+    return 0;
+}
+
+int fcn_adam_update_f32(float* w, const float* g, float* m, float* v, const fcn_solver_seg* d_segs, int nseg, float rate, float beta1,
+                        float beta2, float delta, float weight_decay, int t, float grad_scale, fcn_stream_t s) {
+    FCN_REQUIRE(w && g && m && v && d_segs && nseg > 0 && nseg <= 65535 && t >= 1, FCN_E_ARG, "adam_update: bad args");
+    const double corr = sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+    hipLaunchKernelGGL(adam_kernel, dim3(64, nseg), dim3(256), 0, as_stream(s), w, g, m, v, reinterpret_cast<const SolverSeg*>(d_segs), nseg,
+                       (float)(rate * corr), beta1, beta2, delta, weight_decay, grad_scale);
+    FCN_LAUNCH_CHECK("adam_update");
+    return 0;
+}
+
+}  // extern "C"

@@ -39,6 +39,10 @@ class ConvGroup(C.Structure):
     _fields_ = [("d_probs", C.c_void_p), ("n", C.c_int32), ("cfg", C.c_int32), ("total_tiles", C.c_int32)]
 
 
+class SolverSeg(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("count", C.c_uint64), ("lr_mult", C.c_float), ("decay_mult", C.c_float)]
+
+
 class DetectParams(C.Structure):
     _fields_ = [
         ("num_classes", C.c_int32), ("gy", C.c_int32), ("gx", C.c_int32), ("cell_w", C.c_int32), ("cell_h", C.c_int32),
@@ -48,7 +52,7 @@ class DetectParams(C.Structure):
     ]
 
 
-CONV_RELU, CONV_SIGMOID2 = 1, 2
+CONV_RELU, CONV_SIGMOID2, CONV_ACCUM = 1, 2, 4
 ELT_PROD, ELT_SUM, ELT_MAX = 0, 1, 2
 RECT_ROUND_NEAREST_EVEN, RECT_ROUND_TRUNCATE = 0, 1
 
@@ -102,6 +106,17 @@ PROTOTYPES = {
     "fcn_detect_workspace_bytes": (_sz, [C.POINTER(DetectParams), _i]),
     "fcn_detect_decode_group": (_i, [_vp, _vp, _i, _sz, _sz, C.POINTER(DetectParams), _vp, _vp, _vp, _vp, _vp]),
     "fcn_gen_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fcn_conv2d_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc), C.POINTER(_i)]),
+    "fcn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "fcn_conv_weights_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_relu_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fcn_sigmoid_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "fcn_maxpool_bwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
+    "fcn_lrn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
+    "fcn_dropout_f32": (_i, [_vp, _vp] + [_i] * 8 + [_f, C.c_uint, _vp]),
+    "fcn_loss_f32": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "fcn_sgd_update_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp]),
+    "fcn_adam_update_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

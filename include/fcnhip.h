@@ -89,6 +89,7 @@ int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int
  *      net.forward() (fcn_object_detector.py:87) over models/deploy.prototxt:8-2176 ---- */
 #define FCN_CONV_RELU      1   /* y = max(y, 0)                                  */
 #define FCN_CONV_SIGMOID2  2   /* y2 = sigmoid(y) is written as well (y2 != NULL) */
+#define FCN_CONV_ACCUM     4   /* y += result (gradient fan-in when the kernel runs as a data-gradient pass) */
 typedef struct fcn_conv_desc {
     const float* x;      /* NHWC input, channel stride x_cstride                           */
     const float* w;      /* weights [Cout][kh][kw][Cin]  (OHWI, Cin contiguous)            */
@@ -199,6 +200,39 @@ int  fcn_gen_targets(const int32_t* rects, const int32_t* labels, const int32_t*
                      int num_classes, int gy, int gx, int stride, double iou_thresh,
                      float* foreground, float* bbox, float* size, float* obj, float* cvg_block,
                      fcn_stream_t s);
+
+/* ---- training: Net::Backward + losses + solver update as run by `caffe train` (train/train.sh:25-28) over the
+ *      loss tail models/train_val.prototxt:53-72,2237-2281 with the settings of train/<net>/solver.prototxt ---- */
+/* Weight / bias gradient of a Convolution layer.  `d` describes the FORWARD problem; d->y / y_cstride / y_coffset name the
+ * gradient of the layer's output (d->w, d->bias, d->y2 are ignored).  dw is [Cout][kh][kw][Cin] like the forward weights,
+ * db is [Cout] or NULL.  Bit-reproducible (pixel splits are summed in a fixed order).  Workspace size in floats: */
+size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* h_d, int* h_splits);
+int  fcn_conv2d_wgrad_f32(const fcn_conv_desc* h_d, float* dw, float* db, float* d_workspace, fcn_stream_t s);
+/* Filter bank of the data-gradient pass: wt[c][kh-1-r][kw-1-q][k] = w[k][r][q][c] (w: [Cout][kh][kw][Cin4],
+ * wt: [Cin][kh][kw][Cout4], zero padded).  dX = fcn_conv2d_fwd_f32(dY, wt) with pad' = k-1-pad for stride-1 layers. */
+int  fcn_conv_weights_flip_f32(const float* w, float* wt, int Cout, int kh, int kw, int Cin, int Cin4, int Cout4, fcn_stream_t s);
+int  fcn_relu_bwd_f32(const float* dy, const float* y, float* dx, int pixels, int C, int cstride, fcn_stream_t s);
+int  fcn_sigmoid_bwd_f32(const float* y, const float* dy, float* dx, size_t count, int accumulate, fcn_stream_t s);
+int  fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, int H, int W, int C, int dx_cstride, int dx_coffset,
+                         int k, int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, fcn_stream_t s);
+int  fcn_lrn_bwd_f32(const float* x, const float* y, const float* scale, const float* dy, float* dx, int pixels, int C,
+                     int x_cstride, int y_cstride, int local_size, float alpha, float beta, int accumulate, fcn_stream_t s);
+/* Dropout (TRAIN): y = x * mask / (1 - ratio); mask of element (n,c,h,w) = hash(NCHW index, seed) >= ratio * 2^32.
+ * The same call with the same seed applied to the gradient is the backward pass. */
+int  fcn_dropout_f32(const float* x, float* y, int N, int C, int H, int W, int x_cstride, int x_coffset, int y_cstride,
+                     int y_coffset, float ratio, unsigned seed, fcn_stream_t s);
+/* kind 0 = L1Loss (NVIDIA Caffe): loss = sum|a-b|/num, da = sign(a-b) * weight/num;
+ * kind 1 = EuclideanLoss: loss = sum(a-b)^2/(2 num), da = (a-b) * weight/num.  da may be NULL; d_loss is one device float. */
+int  fcn_loss_f32(int kind, const float* a, const float* b, float* da, float* d_loss, int pixels, int C, int cstride, int num,
+                  float weight, fcn_stream_t s);
+/* Solver update over one flat parameter buffer cut into segments (one per learnable blob). */
+typedef struct fcn_solver_seg { uint64_t offset, count; float lr_mult, decay_mult; } fcn_solver_seg;
+/* SGD: g' = g*grad_scale + wd*decay_mult*w ; hist = momentum*hist + rate*lr_mult*g' ; w -= hist */
+int  fcn_sgd_update_f32(float* w, const float* g, float* hist, const fcn_solver_seg* d_segs, int nseg, float rate, float momentum,
+                        float weight_decay, float grad_scale, fcn_stream_t s);
+/* Adam (Caffe AdamSolver): m,v moments, w -= rate*lr_mult*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+delta) */
+int  fcn_adam_update_f32(float* w, const float* g, float* m, float* v, const fcn_solver_seg* d_segs, int nseg, float rate,
+                         float beta1, float beta2, float delta, float weight_decay, int t, float grad_scale, fcn_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -266,3 +266,101 @@ def bilinear_filler(shape: Tuple[int, int, int, int]) -> np.ndarray:
     k1 = 1 - np.abs(xs / f - cc)
     ker = np.outer(k1, k1).astype(F32)
     return np.broadcast_to(ker, shape).copy()
+
+
+# --------------------------------------------------------------------------
+# backward ops (Caffe *_layer.cpp Backward_cpu restated)
+# --------------------------------------------------------------------------
+
+def col2im(col: np.ndarray, c: int, h: int, w: int, kh: int, kw: int, ph: int, pw: int, sh: int, sw: int) -> np.ndarray:
+    """(C*kh*kw, OH*OW) -> (C,H,W): scatter-add, inverse of :func:`im2col`."""
+    oh, ow = conv_out(h, kh, ph, sh), conv_out(w, kw, pw, sw)
+    cols = col.reshape(c, kh, kw, oh, ow)
+    xp = np.zeros((c, h + 2 * ph, w + 2 * pw), dtype=F32)
+    for r in range(kh):
+        for q in range(kw):
+            xp[:, r:r + sh * oh:sh, q:q + sw * ow:sw] += cols[:, r, q]
+    return xp[:, ph:ph + h, pw:pw + w]
+
+
+def conv2d_backward(x: np.ndarray, w: np.ndarray, dy: np.ndarray, pad: int, stride: int, need_dx: bool = True):
+    """Caffe ConvolutionLayer::Backward: dW = dY @ col^T summed over images, db = sum dY, dX = col2im(W^T @ dY)."""
+    n, cin, h, wd = x.shape
+    cout, _, kh, kw = w.shape
+    dw = np.zeros_like(w)
+    db = dy.sum(axis=(0, 2, 3)).astype(F32)
+    dx = np.zeros_like(x) if need_dx else None
+    wg = w.reshape(cout, cin * kh * kw)
+    for i in range(n):
+        col = im2col(x[i], kh, kw, pad, pad, stride, stride)
+        dyi = dy[i].reshape(cout, -1)
+        dw += (dyi @ col.T).reshape(w.shape)
+        if need_dx:
+            dx[i] = col2im(wg.T @ dyi, cin, h, wd, kh, kw, pad, pad, stride, stride)
+    return dw, db, dx
+
+
+def max_pool_backward(dy: np.ndarray, idx: np.ndarray, in_shape) -> np.ndarray:
+    n, c, h, w = in_shape
+    dx = np.zeros((n, c, h * w), dtype=F32)
+    flat_idx = idx.reshape(n, c, -1)
+    flat_dy = dy.reshape(n, c, -1)
+    for i in range(n):
+        for j in range(c):
+            np.add.at(dx[i, j], flat_idx[i, j], flat_dy[i, j])
+    return dx.reshape(n, c, h, w)
+
+
+def lrn_across_backward(x: np.ndarray, y: np.ndarray, scale: np.ndarray, dy: np.ndarray, local_size: int, alpha: float,
+                        beta: float) -> np.ndarray:
+    """Caffe LRNLayer::CrossChannelBackward_cpu: dX = dY*scale^-beta - (2 alpha beta / n) * X * sum_window(dY*Y/scale)."""
+    n, c, h, w = x.shape
+    pre = (local_size - 1) // 2
+    ratio = np.zeros((n, c + local_size - 1, h, w), dtype=F32)
+    ratio[:, pre:pre + c] = dy * y / scale
+    acc = np.zeros_like(x)
+    for j in range(local_size):
+        acc += ratio[:, j:j + c]
+    return (dy * np.power(scale, F32(-beta)) - F32(2.0 * alpha * beta / local_size) * x * acc).astype(F32)
+
+
+def sigmoid_backward(y: np.ndarray, dy: np.ndarray) -> np.ndarray:
+    return (dy * y * (F32(1) - y)).astype(F32)
+
+
+# counter-based dropout mask shared bit-for-bit with the HIP kernel (csrc/train.hip: dropout_keep):
+# keep element i iff hash32(i ^ seed-mix) >= ratio * 2^32
+def dropout_hash(index: np.ndarray, seed: int) -> np.ndarray:
+    x = (index.astype(np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x.astype(np.uint64) * np.uint64(0x7FEB352D) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    x = (x.astype(np.uint64) * np.uint64(0x846CA68B) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def dropout_mask(shape, ratio: float, seed: int) -> np.ndarray:
+    """1.0 where kept.  Index = NCHW linear index of the element."""
+    idx = np.arange(int(np.prod(shape)), dtype=np.uint64)
+    thresh = np.uint32(min(int(ratio * 4294967296.0), 4294967295))
+    return (dropout_hash(idx, seed) >= thresh).astype(F32).reshape(shape)
+
+
+# --------------------------------------------------------------------------
+# solver updates (Caffe SGDSolver / AdamSolver ::ComputeUpdateValue + Regularize), one parameter blob
+# --------------------------------------------------------------------------
+
+def sgd_update(w, g, hist, lr, momentum, weight_decay, lr_mult, decay_mult):
+    g = g + F32(weight_decay * decay_mult) * w
+    hist[...] = F32(momentum) * hist + F32(lr * lr_mult) * g
+    w -= hist
+
+
+def adam_update(w, g, m, v, lr, beta1, beta2, delta, weight_decay, lr_mult, decay_mult, t):
+    g = g + F32(weight_decay * decay_mult) * w
+    m[...] = F32(beta1) * m + F32(1 - beta1) * g
+    v[...] = F32(beta2) * v + F32(1 - beta2) * g * g
+    corr = math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    w -= F32(lr * lr_mult * corr) * m / (np.sqrt(v) + F32(delta))

@@ -170,11 +170,9 @@ class RefNet:
                 if self.phase == "TEST":
                     B[tops[0]] = bots[0]
                 else:
-                    mask = self.dropout_masks.get(name)
-                    if mask is None:
-                        rng = dropout_rng or np.random.default_rng(0)
-                        mask = (rng.random(bots[0].shape) >= ratio).astype(F32)
-                        self.dropout_masks[name] = mask
+                    # counter-based mask shared bit-for-bit with the HIP kernel (R.dropout_mask)
+                    mask = R.dropout_mask(bots[0].shape, ratio, getattr(self, "dropout_seed", 0))
+                    self.dropout_masks[name] = mask
                     B[tops[0]] = bots[0] * mask * F32(1.0 / (1.0 - ratio))
             elif t == "Eltwise":
                 p = l.get("eltwise_param")
@@ -197,3 +195,186 @@ class RefNet:
             else:
                 raise NotImplementedError("oracle: layer type %r (%s)" % (t, name))
         return B
+
+    # -- backward -----------------------------------------------------------
+    def loss_weights(self) -> Dict[str, float]:
+        out = {}
+        for l in self.layers:
+            t = l.get("type")
+            lw = [float(v) for v in l.getall("loss_weight")]
+            for i, tp in enumerate(l.getall("top")):
+                w = lw[i] if i < len(lw) else (1.0 if (t in ("L1Loss", "EuclideanLoss", "SoftmaxWithLoss") and i == 0) else 0.0)
+                if w:
+                    out[tp] = w
+        return out
+
+    def total_loss(self) -> float:
+        return float(sum(w * self.losses[k] for k, w in self.loss_weights().items()))
+
+    def backward(self) -> Dict[str, List[np.ndarray]]:
+        """Net::Backward: returns {layer: [dW, db]}; blob gradients are left in self.diffs."""
+        B = self.blobs
+        D: Dict[str, np.ndarray] = {}
+        grads: Dict[str, List[np.ndarray]] = {}
+        lw = self.loss_weights()
+        data_tops = set(self.inputs)
+        for l in self.layers:
+            if l.get("type") in ("Data", "Python", "Input"):
+                data_tops.update(l.getall("top"))
+
+        def acc(name, g):
+            if name in data_tops:
+                return
+            if name in D:
+                D[name] = D[name] + g
+            else:
+                D[name] = g.astype(F32)
+
+        for l in reversed(self.layers):
+            t = l.get("type")
+            name = l.get("name")
+            bots = l.getall("bottom")
+            tops = l.getall("top")
+            if t in ("Data", "Python", "Input"):
+                continue
+            if t in ("L1Loss", "EuclideanLoss"):
+                w = lw.get(tops[0], 0.0)
+                a, b = B[bots[0]], B[bots[1]]
+                g = R.l1_loss_grad(a, b, w) if t == "L1Loss" else R.euclidean_loss_grad(a, b, w)
+                acc(bots[0], g)
+                acc(bots[1], -g)
+                continue
+            if t == "SoftmaxWithLoss":
+                raise NotImplementedError("oracle backward: SoftmaxWithLoss")
+            if tops[0] not in D:
+                continue   # nothing flows back through this layer
+            dy = D[tops[0]]
+            if t == "Convolution":
+                p = l.get("convolution_param")
+                k, s, pad = _ksp(p)
+                need_dx = bots[0] not in data_tops and self._needs_grad(bots[0], data_tops)
+                dw, db, dx = R.conv2d_backward(B[bots[0]], self.params[name][0], dy, pad, s, need_dx)
+                grads[name] = [dw] + ([db] if len(self.params[name]) > 1 else [])
+                if need_dx:
+                    acc(bots[0], dx)
+            elif t == "ReLU":
+                g = dy * (B[tops[0]] > 0)
+                if bots[0] == tops[0]:
+                    D[bots[0]] = g.astype(F32)
+                else:
+                    acc(bots[0], g)
+            elif t == "Sigmoid":
+                acc(bots[0], R.sigmoid_backward(B[tops[0]], dy))
+            elif t == "Power":
+                p = l.get("power_param")
+                if float(p.get("power", 1.0)) != 1.0:
+                    raise NotImplementedError("oracle backward: Power with power != 1")
+                acc(bots[0], dy * F32(float(p.get("scale", 1.0))))
+            elif t == "Pooling":
+                p = l.get("pooling_param")
+                if p.get("pool", "MAX") != "MAX":
+                    raise NotImplementedError("oracle backward: AVE pooling")
+                acc(bots[0], R.max_pool_backward(dy, self.aux[name], B[bots[0]].shape))
+            elif t == "LRN":
+                p = l.get("lrn_param")
+                acc(bots[0], R.lrn_across_backward(B[bots[0]], B[tops[0]], self.aux[name], dy, int(p.get("local_size", 5)),
+                                                   float(p.get("alpha", 1.0)), float(p.get("beta", 0.75))))
+            elif t == "Concat":
+                off = 0
+                for b in bots:
+                    c = B[b].shape[1]
+                    acc(b, dy[:, off:off + c])
+                    off += c
+            elif t == "Slice":
+                pass   # handled below (needs all tops)
+            elif t == "Dropout":
+                ratio = float(l.get("dropout_param").get("dropout_ratio", 0.5))
+                if self.phase == "TEST":
+                    acc(bots[0], dy)
+                else:
+                    acc(bots[0], dy * self.dropout_masks[name] * F32(1.0 / (1.0 - ratio)))
+            elif t == "Eltwise":
+                p = l.get("eltwise_param")
+                op = p.get("operation", "SUM") if p else "SUM"
+                if op == "PROD":
+                    for i, b in enumerate(bots):
+                        other = None
+                        for j, b2 in enumerate(bots):
+                            if j != i:
+                                other = B[b2] if other is None else other * B[b2]
+                        acc(b, dy * other)
+                elif op == "SUM":
+                    cf = [float(c) for c in p.getall("coeff")] if p and p.getall("coeff") else [1.0] * len(bots)
+                    for c_, b in zip(cf, bots):
+                        acc(b, dy * F32(c_))
+                else:
+                    raise NotImplementedError("oracle backward: Eltwise MAX")
+            else:
+                raise NotImplementedError("oracle backward: %s" % t)
+        self.diffs = D
+        return grads
+
+    def _needs_grad(self, blob: str, data_tops) -> bool:
+        """True if some learnable layer lies upstream of `blob` (Caffe's propagate_down)."""
+        produced = {}
+        for l in self.layers:
+            for tp in l.getall("top"):
+                produced.setdefault(tp, []).append(l)
+        seen, stack = set(), [blob]
+        while stack:
+            b = stack.pop()
+            if b in seen or b in data_tops:
+                continue
+            seen.add(b)
+            for l in produced.get(b, []):
+                if l.get("name") in self.params:
+                    return True
+                stack.extend(l.getall("bottom"))
+        return False
+
+
+class RefSolver:
+    """Caffe Solver::Step restated: ForwardBackward, Regularize + ComputeUpdateValue (SGD or Adam), Update."""
+
+    def __init__(self, net: "RefNet", solver_msg, lr_mults: Dict[str, List[float]], decay_mults: Dict[str, List[float]]):
+        self.net = net
+        g = solver_msg.get
+        self.base_lr = float(g("base_lr", 0.01))
+        self.momentum = float(g("momentum", 0.0))
+        self.momentum2 = float(g("momentum2", 0.999))
+        self.delta = float(g("delta", 1e-8))
+        self.weight_decay = float(g("weight_decay", 0.0))
+        self.lr_policy = str(g("lr_policy", "fixed"))
+        self.gamma = float(g("gamma", 0.1))
+        self.stepsize = int(g("stepsize", 1))
+        st = g("solver_type", g("type", "SGD"))
+        self.kind = str(st).upper()
+        self.iter = 0
+        self.lr_mults, self.decay_mults = lr_mults, decay_mults
+        self.hist = {k: [np.zeros_like(b) for b in v] for k, v in net.params.items()}
+        self.hist2 = {k: [np.zeros_like(b) for b in v] for k, v in net.params.items()}
+
+    def lr(self) -> float:
+        if self.lr_policy == "fixed":
+            return self.base_lr
+        if self.lr_policy == "step":
+            return self.base_lr * self.gamma ** (self.iter // self.stepsize)
+        raise NotImplementedError(self.lr_policy)
+
+    def apply(self, grads: Dict[str, List[np.ndarray]]) -> None:
+        rate = self.lr()
+        for name, gs in grads.items():
+            for i, g in enumerate(gs):
+                lm = self.lr_mults.get(name, [1.0, 1.0])
+                dm = self.decay_mults.get(name, [1.0, 1.0])
+                lmi = lm[i] if i < len(lm) else 1.0
+                dmi = dm[i] if i < len(dm) else 1.0
+                w = self.net.params[name][i]
+                if lmi == 0.0:
+                    continue
+                if self.kind == "ADAM":
+                    R.adam_update(w, g, self.hist[name][i], self.hist2[name][i], rate, self.momentum, self.momentum2, self.delta,
+                                  self.weight_decay, lmi, dmi, self.iter + 1)
+                else:
+                    R.sgd_update(w, g, self.hist[name][i], rate, self.momentum, self.weight_decay, lmi, dmi)
+        self.iter += 1

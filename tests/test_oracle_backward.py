@@ -1,0 +1,157 @@
+"""Pins the oracle's backward pass and solver against torch autograd / torch.optim on a small net that contains every
+layer type of the training path (conv, in-place ReLU, ceil-mode max-pool, LRN, concat fan-out, sigmoid, dropout, eltwise
+PROD chain, L1Loss with loss_weight, EuclideanLoss) — CPU only."""
+import numpy as np
+import pytest
+
+from fcn_object_detector_amd import proto
+from fcn_object_detector_amd.netspec import NetSpec, fill_params
+from oracle import caffe_ref as R
+from oracle.net_ref import RefNet, RefSolver
+
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+
+NET = """
+layer { name: "data" type: "Python" top: "data" top: "coverage-label" top: "bbox-label" top: "size-block" top: "obj-block" top: "coverage-block"
+        python_param { module: "m" layer: "L" param_str: "" } }
+layer { name: "bb-label-norm" type: "Eltwise" bottom: "bbox-label" bottom: "size-block" top: "bbox-label-norm" eltwise_param { operation: PROD } }
+layer { name: "bb-obj-norm" type: "Eltwise" bottom: "bbox-label-norm" bottom: "obj-block" top: "bbox-obj-label-norm" eltwise_param { operation: PROD } }
+layer { name: "c1" type: "Convolution" bottom: "data" top: "c1" param { lr_mult: 1 decay_mult: 1 } param { lr_mult: 2 decay_mult: 0 }
+        convolution_param { num_output: 8 pad: 3 kernel_size: 7 stride: 2 weight_filler { type: "xavier" } bias_filler { type: "constant" value: 0.2 } } }
+layer { name: "r1" type: "ReLU" bottom: "c1" top: "c1" }
+layer { name: "p1" type: "Pooling" bottom: "c1" top: "p1" pooling_param { pool: MAX kernel_size: 3 stride: 2 } }
+layer { name: "n1" type: "LRN" bottom: "p1" top: "n1" lrn_param { local_size: 5 alpha: 0.0001 beta: 0.75 } }
+layer { name: "a" type: "Convolution" bottom: "n1" top: "a" param { lr_mult: 1 decay_mult: 1 } param { lr_mult: 2 decay_mult: 0 }
+        convolution_param { num_output: 4 kernel_size: 1 weight_filler { type: "xavier" } bias_filler { type: "constant" value: 0.2 } } }
+layer { name: "ra" type: "ReLU" bottom: "a" top: "a" }
+layer { name: "b" type: "Convolution" bottom: "n1" top: "b" param { lr_mult: 1 decay_mult: 1 } param { lr_mult: 2 decay_mult: 0 }
+        convolution_param { num_output: 8 pad: 1 kernel_size: 3 weight_filler { type: "xavier" } bias_filler { type: "constant" value: 0.2 } } }
+layer { name: "rb" type: "ReLU" bottom: "b" top: "b" }
+layer { name: "pp" type: "Pooling" bottom: "n1" top: "pp" pooling_param { pool: MAX kernel_size: 3 stride: 1 pad: 1 } }
+layer { name: "pj" type: "Convolution" bottom: "pp" top: "pj" param { lr_mult: 1 decay_mult: 1 } param { lr_mult: 2 decay_mult: 0 }
+        convolution_param { num_output: 4 kernel_size: 1 weight_filler { type: "xavier" } bias_filler { type: "constant" value: 0.2 } } }
+layer { name: "rp" type: "ReLU" bottom: "pj" top: "pj" }
+layer { name: "cat" type: "Concat" bottom: "a" bottom: "b" bottom: "pj" top: "cat" }
+layer { name: "drop" type: "Dropout" bottom: "cat" top: "drop" dropout_param { dropout_ratio: 0.4 } }
+layer { name: "cvg/classifier" type: "Convolution" bottom: "drop" top: "cvg/classifier" param { lr_mult: 1 decay_mult: 1 } param { lr_mult: 2 decay_mult: 0 }
+        convolution_param { num_output: 1 kernel_size: 1 weight_filler { type: "xavier" } bias_filler { type: "constant" value: 0 } } }
+layer { name: "coverage/sig" type: "Sigmoid" bottom: "cvg/classifier" top: "coverage" }
+layer { name: "bbox/regressor" type: "Convolution" bottom: "drop" top: "bboxes" param { lr_mult: 1 decay_mult: 1 } param { lr_mult: 2 decay_mult: 0 }
+        convolution_param { num_output: 4 kernel_size: 1 weight_filler { type: "xavier" } bias_filler { type: "constant" value: 0 } } }
+layer { name: "bbox_mask" type: "Eltwise" bottom: "bboxes" bottom: "coverage-block" top: "bboxes-masked" eltwise_param { operation: PROD } }
+layer { name: "bbox-norm" type: "Eltwise" bottom: "bboxes-masked" bottom: "size-block" top: "bboxes-masked-norm" eltwise_param { operation: PROD } }
+layer { name: "bbox-obj-norm" type: "Eltwise" bottom: "bboxes-masked-norm" bottom: "obj-block" top: "bboxes-obj-masked-norm" eltwise_param { operation: PROD } }
+layer { name: "bbox_loss" type: "L1Loss" bottom: "bboxes-obj-masked-norm" bottom: "bbox-obj-label-norm" top: "loss_bbox" loss_weight: 2.0 }
+layer { name: "coverage_loss" type: "EuclideanLoss" bottom: "coverage" bottom: "coverage-label" top: "loss_coverage" }
+"""
+
+
+def make(seed=3, n=2, h=30, w=26):
+    msg = proto.parse_text(NET)
+    rng = np.random.default_rng(seed)
+    gh, gw = 7, 6       # conv s2: 15x13 ; pool k3 s2 ceil: 7x6
+    data = {"data": rng.standard_normal((n, 3, h, w)).astype(np.float32),
+            "coverage-label": (rng.random((n, 1, gh, gw)) > 0.5).astype(np.float32)}
+    for k in ("bbox-label", "size-block", "obj-block", "coverage-block"):
+        data[k] = rng.random((n, 4, gh, gw)).astype(np.float32)
+    data["coverage-block"] = (data["coverage-block"] > 0.4).astype(np.float32)
+    spec = NetSpec(msg, "TRAIN")
+    spec.infer({k: v.shape for k, v in data.items()})
+    params = fill_params(spec, seed=5)
+    for k in params:      # non-trivial biases so that ReLU masks are mixed
+        params[k][1] = rng.standard_normal(params[k][1].shape).astype(np.float32) * 0.1
+    return msg, spec, data, params
+
+
+def torch_forward(data, P, mask):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    x = F.relu(F.conv2d(t(data["data"]), P["c1"][0], P["c1"][1], stride=2, padding=3))
+    x = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+    n1 = F.local_response_norm(x, 5, alpha=1e-4, beta=0.75, k=1.0)
+    a = F.relu(F.conv2d(n1, P["a"][0], P["a"][1]))
+    b = F.relu(F.conv2d(n1, P["b"][0], P["b"][1], padding=1))
+    pj = F.relu(F.conv2d(F.max_pool2d(n1, 3, 1, 1), P["pj"][0], P["pj"][1]))
+    cat = torch.cat([a, b, pj], 1)
+    drop = cat * t(mask) * (1.0 / (1.0 - 0.4))
+    cov = torch.sigmoid(F.conv2d(drop, P["cvg/classifier"][0], P["cvg/classifier"][1]))
+    bb = F.conv2d(drop, P["bbox/regressor"][0], P["bbox/regressor"][1])
+    pred = bb * t(data["coverage-block"]) * t(data["size-block"]) * t(data["obj-block"])
+    lab = t(data["bbox-label"]) * t(data["size-block"]) * t(data["obj-block"])
+    n = data["data"].shape[0]
+    l1 = (pred - lab).abs().sum() / n
+    l2 = ((cov - t(data["coverage-label"])) ** 2).sum() / (2 * n)
+    return 2.0 * l1 + l2, l1, l2
+
+
+def test_backward_matches_autograd():
+    msg, spec, data, params = make()
+    net = RefNet(msg, "TRAIN", {k: [a.copy() for a in v] for k, v in params.items()})
+    net.dropout_seed = 11
+    net.blobs.update(data)
+    net.forward()
+    grads = net.backward()
+    P = {k: [torch.tensor(a, requires_grad=True) for a in v] for k, v in params.items()}
+    mask = R.dropout_mask((2, 16, 7, 6), 0.4, 11)
+    assert 0.45 < mask.mean() < 0.75
+    loss, l1, l2 = torch_forward(data, P, mask)
+    loss.backward()
+    assert abs(net.losses["loss_bbox"] - l1.item()) < 1e-4 * abs(l1.item())
+    assert abs(net.losses["loss_coverage"] - l2.item()) < 1e-4 * abs(l2.item())
+    assert abs(net.total_loss() - loss.item()) < 1e-4 * abs(loss.item())
+    for name in params:
+        for g, p in zip(grads[name], P[name]):
+            ref = p.grad.numpy()
+            assert np.abs(g - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-6), name
+    assert "data" not in net.diffs            # nothing propagates into the data layer
+
+
+@pytest.mark.parametrize("kind", ["SGD", "ADAM"])
+def test_solver_matches_torch_optim(kind):
+    msg, spec, data, params = make(seed=9)
+    text = 'base_lr: 0.01 momentum: 0.9 weight_decay: 0.0005 lr_policy: "step" gamma: 0.5 stepsize: 2' + \
+           (' solver_type: ADAM' if kind == "ADAM" else '')
+    smsg = proto.parse_text(text)
+    lrm = {l.name: l.lr_mult for l in spec.param_layers()}
+    dcm = {l.name: l.decay_mult for l in spec.param_layers()}
+    net = RefNet(msg, "TRAIN", {k: [a.copy() for a in v] for k, v in params.items()})
+    net.blobs.update(data)
+    solver = RefSolver(net, smsg, lrm, dcm)
+    P = {k: [torch.tensor(a, requires_grad=True) for a in v] for k, v in params.items()}
+    groups = []
+    for k in params:
+        groups.append({"params": [P[k][0]], "lr_mult": 1.0, "wd": 0.0005})
+        groups.append({"params": [P[k][1]], "lr_mult": 2.0, "wd": 0.0})
+    losses = []
+    state = {id(p): (torch.zeros_like(p), torch.zeros_like(p)) for g in groups for p in g["params"]}
+    for it in range(4):
+        net.dropout_seed = 100 + it
+        net.forward()
+        losses.append(net.total_loss())
+        solver.apply(net.backward())
+        for g in groups:
+            for p in g["params"]:
+                p.grad = None
+        mask = R.dropout_mask((2, 16, 7, 6), 0.4, 100 + it)
+        loss, _, _ = torch_forward(data, P, mask)
+        assert abs(loss.item() - losses[-1]) < 2e-4 * abs(loss.item())
+        loss.backward()
+        rate = 0.01 * 0.5 ** (it // 2)
+        with torch.no_grad():
+            for g in groups:
+                for p in g["params"]:
+                    grad = p.grad + g["wd"] * p
+                    m, v = state[id(p)]
+                    if kind == "SGD":
+                        m.mul_(0.9).add_(rate * g["lr_mult"] * grad)
+                        p.sub_(m)
+                    else:
+                        m.mul_(0.9).add_(0.1 * grad)
+                        v.mul_(0.999).add_(0.001 * grad * grad)
+                        t = it + 1
+                        corr = np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+                        p.sub_(rate * g["lr_mult"] * corr * m / (v.sqrt() + 1e-8))
+    for k in params:
+        for a, p in zip(net.params[k], P[k]):
+            assert np.abs(a - p.detach().numpy()).max() < 2e-4 * max(np.abs(a).max(), 1e-6), k
+    assert losses[-1] < losses[0]
