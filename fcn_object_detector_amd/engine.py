@@ -60,6 +60,15 @@ class DeviceBuffer:
             pass
 
 
+class DevView:
+    """A slice of a DeviceBuffer (no ownership)."""
+
+    __slots__ = ("ptr", "nbytes")
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.ptr, self.nbytes = int(ptr), int(nbytes)
+
+
 class PinnedArray:
     """A numpy float32 array backed by hipHostMalloc memory (stable address for graph memcpy nodes)."""
 
@@ -151,13 +160,16 @@ class Engine:
         self.shapes = spec.infer(data_shapes)
         self.blobs: Dict[str, Blob] = {}
         self.params_host: Dict[str, List[np.ndarray]] = {}
-        self.params_dev: Dict[str, List[DeviceBuffer]] = {}
+        self.params_dev: Dict[str, List[DevView]] = {}
         self.ops: List[Op] = []
         self.graph_io: Optional[int] = None
         self.graph_core: Optional[int] = None
         self._staging: Dict[str, DeviceBuffer] = {}
         self._keep: List[object] = []
         self._conv_layer_meta: Dict[str, dict] = {}
+        self.aux_dev: Dict[str, DeviceBuffer] = {}      # TRAIN: pooling argmax / LRN scale kept for backward
+        self.loss_blobs: Dict[str, float] = {}          # loss top -> loss_weight
+        self.dropout_seed = 0
         self.inputs = spec.data_tops()
         self.outputs = [b for b in spec.output_blobs() if b in self.shapes]
         self._plan_buffers()
@@ -190,7 +202,7 @@ class Engine:
                     prods = [p for p in producers.get(b, []) if not (p.type in ("ReLU", "Dropout") and p.bottoms == p.tops)]
                     good = (self.fuse and b not in data_tops and b not in alias and c % 4 == 0 and len(prods) == 1
                             and prods[0].type in ("Convolution", "Pooling")
-                            and sum(1 for q in consumers.get(b, []) if q.type == "Concat") == 1)
+                            and [q.type for q in consumers.get(b, []) if not (q.type in ("ReLU", "Dropout") and q.bottoms == q.tops)] == ["Concat"])
                     ok = ok and good
                     plan.append((b, off))
                     off += c
@@ -251,9 +263,13 @@ class Engine:
                 self.blobs[nm].is_input = True
 
     def _alloc_params(self, params: Optional[Dict[str, List[np.ndarray]]]) -> None:
+        """All learnable blobs live in ONE flat device buffer in the kernels' layout (conv weights OHWI with Cin padded
+        to 4): the solver update and the gradient all-reduce are then single launches over one buffer."""
         from .netspec import fill_params
         if params is None:
             params = fill_params(self.spec, seed=0)
+        self.param_layout: List[dict] = []
+        off = 0
         for l in self.spec.param_layers():
             shapes = self.spec.param_shapes[l.name]
             blobs = params.get(l.name)
@@ -268,7 +284,18 @@ class Engine:
                     a = a.reshape(shp)
                 host.append(a.copy())
             self.params_host[l.name] = host
-            self.params_dev[l.name] = []
+            packed = [self._packed_weight(l)] + host[1:]
+            for i, arr in enumerate(packed):
+                lm = l.lr_mult[i] if i < len(l.lr_mult) else 1.0
+                dm = l.decay_mult[i] if i < len(l.decay_mult) else 1.0
+                self.param_layout.append(dict(layer=l.name, index=i, offset=off, count=int(arr.size), shape=tuple(arr.shape),
+                                              lr_mult=float(lm), decay_mult=float(dm)))
+                off += _r4(int(arr.size))
+        self.param_count = off
+        self.param_flat = DeviceBuffer(max(off, 4) * 4, zero=True)
+        for e in self.param_layout:
+            self.params_dev.setdefault(e["layer"], []).append(DevView(self.param_flat.ptr + 4 * e["offset"], 4 * e["count"]))
+        for l in self.spec.param_layers():
             self._upload_params(l)
 
     def _packed_weight(self, l: Layer) -> np.ndarray:
@@ -291,8 +318,6 @@ class Engine:
         packed = [self._packed_weight(l)] + [np.ascontiguousarray(h) for h in host[1:]]
         devs = self.params_dev[l.name]
         for i, arr in enumerate(packed):
-            if i >= len(devs):
-                devs.append(DeviceBuffer(arr.nbytes, zero=False))
             L.call("fcn_memcpy_h2d_async", devs[i].ptr, arr.ctypes.data, arr.nbytes, None)
         L.call("fcn_device_sync")
 
@@ -490,6 +515,10 @@ class Engine:
                 best, best_ms = cfg, ms.value
         return best
 
+    def _loss_grad_ptr(self, blob: str) -> Optional[int]:
+        """Device address the loss kernel writes d(loss)/d(blob) to; None in an inference engine."""
+        return None
+
     def _emit_simple(self, l: Layer) -> List[Op]:
         B, lib, t = self.blobs, L.load(), l.type
         out: List[Op] = []
@@ -504,8 +533,13 @@ class Engine:
                 k, s, pad = kernel_stride_pad(pp)
             byts = 4.0 * (xb.pixels * c + yb.pixels * c)
             if str(pp.get("pool", "MAX")) == "MAX":
+                idx_ptr = None
+                if self.spec.phase == "TRAIN":      # backward routes the gradient to the argmax
+                    ib = DeviceBuffer(yb.pixels * c * 4, zero=False)
+                    self.aux_dev[l.name] = ib
+                    idx_ptr = ib.ptr
                 out.append(Op("maxpool", l.name, lambda st: L.check(lib.fcn_maxpool_fwd_f32(
-                    xb.ptr, yb.buf.ptr, None, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)), 0.0, byts))
+                    xb.ptr, yb.buf.ptr, idx_ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)), 0.0, byts))
             else:
                 out.append(Op("avepool", l.name, lambda st: L.check(lib.fcn_avepool_fwd_f32(
                     xb.ptr, yb.buf.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)), 0.0, byts))
@@ -517,8 +551,13 @@ class Engine:
             if yb.coffset != 0:
                 raise NotImplementedError("LRN into a channel slice")
             ls, al, be, kk = int(p.get("local_size", 5)), float(p.get("alpha", 1.0)), float(p.get("beta", 0.75)), float(p.get("k", 1.0))
+            scale_ptr = None
+            if self.spec.phase == "TRAIN":
+                sb = DeviceBuffer(xb.pixels * xb.channels * 4, zero=False)
+                self.aux_dev[l.name] = sb
+                scale_ptr = sb.ptr
             out.append(Op("lrn", l.name, lambda st: L.check(lib.fcn_lrn_fwd_f32(
-                xb.ptr, yb.ptr, None, xb.pixels, xb.channels, xb.cstride, yb.cstride, ls, al, be, kk, st)),
+                xb.ptr, yb.ptr, scale_ptr, xb.pixels, xb.channels, xb.cstride, yb.cstride, ls, al, be, kk, st)),
                 0.0, 8.0 * xb.pixels * xb.channels))
         elif t in ("ReLU", "Sigmoid", "Power"):
             xb, yb = B[l.bottoms[0]], B[l.tops[0]]
@@ -536,11 +575,27 @@ class Engine:
                 fn = lambda st: L.check(lib.fcn_power_fwd_f32(xb.ptr, yb.ptr, count, pw, sc, sh, st))
             out.append(Op(t.lower(), l.name, fn, 0.0, 8.0 * count))
         elif t == "Dropout":
-            if self.spec.phase != "TEST":
-                raise NotImplementedError("Dropout in TRAIN phase is handled by the training engine")
             xb, yb = B[l.bottoms[0]], B[l.tops[0]]
-            out.append(Op("copy", l.name, lambda st: L.check(lib.fcn_copy_channels_f32(
-                xb.buf.ptr, yb.buf.ptr, xb.pixels, xb.channels, xb.cstride, xb.coffset, yb.cstride, yb.coffset, st))))
+            if self.spec.phase == "TEST":
+                out.append(Op("copy", l.name, lambda st: L.check(lib.fcn_copy_channels_f32(
+                    xb.buf.ptr, yb.buf.ptr, xb.pixels, xb.channels, xb.cstride, xb.coffset, yb.cstride, yb.coffset, st))))
+            else:
+                ratio = float(l.sub("dropout_param").get("dropout_ratio", 0.5))
+                n, c, h, w = xb.shape
+                out.append(Op("dropout", l.name, lambda st: L.check(lib.fcn_dropout_f32(
+                    xb.buf.ptr, yb.buf.ptr, n, c, h, w, xb.cstride, xb.coffset, yb.cstride, yb.coffset, ratio, self.dropout_seed, st)),
+                    0.0, 8.0 * xb.pixels * c))
+        elif t in ("L1Loss", "EuclideanLoss"):
+            ab, bb, lb = B[l.bottoms[0]], B[l.bottoms[1]], B[l.tops[0]]
+            if ab.shape != bb.shape or ab.coffset or bb.coffset or ab.cstride != bb.cstride:
+                raise NotImplementedError("loss layer %s on mismatched / sliced blobs" % l.name)
+            kind = 0 if t == "L1Loss" else 1
+            weight = l.loss_weight[0] if l.loss_weight else 1.0
+            da = self._loss_grad_ptr(l.bottoms[0])
+            self.loss_blobs[l.tops[0]] = float(weight)
+            out.append(Op("loss", l.name, lambda st: L.check(lib.fcn_loss_f32(
+                kind, ab.ptr, bb.ptr, da, lb.buf.ptr, ab.pixels, ab.channels, ab.cstride, ab.shape[0], weight, st)),
+                0.0, 8.0 * ab.pixels * ab.channels))
         elif t == "Concat":
             off = 0
             yb = B[l.tops[0]]

@@ -1,0 +1,394 @@
+"""Training step on the device: Net::ForwardBackward + solver update, optionally data-parallel.
+
+Stands in for `caffe train` (reference: train/train.sh:25-28) over the DetectNet training net
+(reference: models/train_val.prototxt with the Python data layer's tops, README.md:57-76) and the
+solver settings of the reference's solver.prototxt files (SGD with momentum, Adam, fixed / step
+learning-rate policy, L2 weight decay, per-blob lr_mult / decay_mult).
+
+Data layout: every blob that receives a gradient has a gradient buffer with the SAME NHWC view
+geometry as its activation (so Concat / Slice / Dropout views need no backward kernel); all
+parameter gradients live in one flat buffer parallel to `Engine.param_flat`, which is what the
+solver kernel updates and what the RCCL all-reduce sums across ranks in one call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import lib as L
+from . import proto
+from .engine import Blob, DevView, DeviceBuffer, Engine, Op, _r4
+from .netspec import DATA_TYPES, LOSS_TYPES, Layer, NetSpec, kernel_stride_pad
+
+F32 = np.float32
+
+
+class SolverParams:
+    """The subset of Caffe's SolverParameter the reference's solver.prototxt files use."""
+
+    def __init__(self, msg: Optional[proto.Msg] = None, **kw):
+        g = (lambda k, d=None: msg.get(k, d)) if msg is not None else (lambda k, d=None: d)
+        self.net = g("net", g("train_net"))
+        self.base_lr = float(kw.get("base_lr", g("base_lr", 0.01)))
+        self.momentum = float(kw.get("momentum", g("momentum", 0.0)))
+        self.momentum2 = float(kw.get("momentum2", g("momentum2", 0.999)))
+        self.delta = float(kw.get("delta", g("delta", 1e-8)))
+        self.weight_decay = float(kw.get("weight_decay", g("weight_decay", 0.0)))
+        self.lr_policy = str(kw.get("lr_policy", g("lr_policy", "fixed")))
+        self.gamma = float(kw.get("gamma", g("gamma", 0.1)))
+        self.stepsize = int(kw.get("stepsize", g("stepsize", 1)))
+        self.max_iter = int(kw.get("max_iter", g("max_iter", 1)))
+        self.iter_size = int(kw.get("iter_size", g("iter_size", 1)))
+        self.display = int(kw.get("display", g("display", 0)))
+        self.average_loss = int(kw.get("average_loss", g("average_loss", 1)))
+        self.snapshot = int(kw.get("snapshot", g("snapshot", 0)))
+        self.snapshot_prefix = str(kw.get("snapshot_prefix", g("snapshot_prefix", "snapshot")))
+        kind = kw.get("solver_type", g("solver_type", g("type", "SGD")))
+        self.kind = str(kind).upper()
+        if self.kind not in ("SGD", "ADAM"):
+            raise NotImplementedError("solver type %s (the reference uses SGD and ADAM)" % self.kind)
+        if self.lr_policy not in ("fixed", "step"):
+            raise NotImplementedError("lr_policy %s (the reference uses fixed and step)" % self.lr_policy)
+
+    def rate(self, it: int) -> float:
+        if self.lr_policy == "fixed":
+            return self.base_lr
+        return self.base_lr * self.gamma ** (it // self.stepsize)
+
+
+class TrainEngine(Engine):
+    """Engine for the TRAIN phase with backward pass and solver state."""
+
+    def __init__(self, spec: NetSpec, data_shapes: Dict[str, Tuple[int, ...]], params=None, device: int = 0,
+                 solver: Optional[SolverParams] = None, comm=None, autotune: bool = True):
+        if spec.phase != "TRAIN":
+            raise ValueError("TrainEngine needs a TRAIN-phase NetSpec")
+        self.solver = solver or SolverParams()
+        self.comm = comm                      # None or an object with all_reduce_sum(ptr, count, stream) and .world
+        self.grad_blobs: Dict[str, Blob] = {}
+        self.bwd_ops: List[Op] = []
+        self.iter = 0
+        super().__init__(spec, data_shapes, params, device, fuse=True, group_convs=True, autotune=autotune)
+        self._alloc_solver_state()
+        self._build_backward()
+
+    # ------------------------------------------------------------------ gradient buffers
+    def _needs_grad(self) -> set:
+        """Blobs downstream of a learnable layer (Caffe's propagate_down): only those carry gradients."""
+        need = set()
+        for l in self.spec.layers:
+            if l.type in DATA_TYPES:
+                continue
+            if l.name in self.spec.param_shapes or any(b in need for b in l.bottoms):
+                need.update(l.tops)
+        return need
+
+    def _plan_buffers(self) -> None:
+        super()._plan_buffers()
+        need = self._needs_grad()
+        self.need_grad = need
+        roots: Dict[int, DeviceBuffer] = {}      # activation buffer address -> gradient buffer
+        for name, b in self.blobs.items():
+            if name not in need or len(b.shape) != 4:
+                continue
+            gb = roots.get(b.buf.ptr)
+            if gb is None:
+                gb = DeviceBuffer(b.buf.nbytes, zero=True)
+                roots[b.buf.ptr] = gb
+            g = Blob(name, b.shape)
+            g.buf, g.coffset, g.cstride = gb, b.coffset, b.cstride
+            self.grad_blobs[name] = g
+
+    def _loss_grad_ptr(self, blob: str) -> Optional[int]:
+        g = self.grad_blobs.get(blob)
+        if g is None:
+            return None
+        if g.coffset:
+            raise NotImplementedError("loss gradient into a channel slice")
+        return g.ptr
+
+    # ------------------------------------------------------------------ solver state
+    def _alloc_solver_state(self) -> None:
+        n = max(self.param_count, 4)
+        self.grad_flat = DeviceBuffer(n * 4, zero=True)
+        self.hist = DeviceBuffer(n * 4, zero=True)
+        self.hist2 = DeviceBuffer(n * 4, zero=True) if self.solver.kind == "ADAM" else None
+        segs = (L.SolverSeg * len(self.param_layout))(*[
+            L.SolverSeg(e["offset"], e["count"], e["lr_mult"], e["decay_mult"]) for e in self.param_layout])
+        self._segs_host = segs
+        self.segs_dev = DeviceBuffer(max(C.sizeof(segs), 16), zero=False)
+        L.call("fcn_memcpy_h2d_async", self.segs_dev.ptr, C.addressof(segs), C.sizeof(segs), None)
+        L.call("fcn_device_sync")
+        self.loss_host = {name: np.zeros(1, F32) for name in self.loss_blobs}
+
+    def _grad_view(self, layer: str, index: int) -> DevView:
+        for e in self.param_layout:
+            if e["layer"] == layer and e["index"] == index:
+                return DevView(self.grad_flat.ptr + 4 * e["offset"], 4 * e["count"])
+        raise KeyError((layer, index))
+
+    # ------------------------------------------------------------------ backward plan
+    def _build_backward(self) -> None:
+        spec, B, G, lib = self.spec, self.blobs, self.grad_blobs, L.load()
+        written: Dict[int, List[Tuple[int, int]]] = {}      # gradient buffer -> channel ranges already holding a gradient
+
+        def state(g: Blob) -> str:
+            """'none' | 'full' for the channel range of view g (partial overlap is a planning error)."""
+            lo, hi = g.coffset, g.coffset + g.channels
+            cov = 0
+            for a, b in written.get(g.buf.ptr, []):
+                o = min(hi, b) - max(lo, a)
+                if o > 0:
+                    cov += o
+            if cov == 0:
+                return "none"
+            if cov >= hi - lo:
+                return "full"
+            raise NotImplementedError("gradient of %s is partially written" % g.name)
+
+        def mark(g: Blob) -> None:
+            written.setdefault(g.buf.ptr, []).append((g.coffset, g.coffset + g.channels))
+
+        ws_floats = 1
+        flips: Dict[str, DeviceBuffer] = {}
+        ops: List[Op] = []
+        skip_sigmoid_of = {m["sigmoid_top"]: name for name, m in self._conv_layer_meta.items() if m.get("sigmoid_top")}
+
+        for l in reversed(spec.layers):
+            t = l.type
+            if t in DATA_TYPES or t in ("Concat", "Slice") or (t == "ReLU" and l.name in self._fused_relu_layers()):
+                continue
+            if t in ("L1Loss", "EuclideanLoss"):
+                g = G.get(l.bottoms[0])
+                if g is None:
+                    continue
+                if l.bottoms[1] in self.need_grad:
+                    raise NotImplementedError("loss layer %s: gradient w.r.t. the second bottom" % l.name)
+                if state(g) != "none":
+                    raise NotImplementedError("loss gradient would have to accumulate into %s" % l.bottoms[0])
+                mark(g)                      # written by the forward loss kernel (da)
+                continue
+            if t == "Sigmoid" and l.tops[0] in skip_sigmoid_of:
+                # fused into the conv epilogue in forward; backward is its own small kernel
+                yb, gtop, gbot = B[l.tops[0]], G.get(l.tops[0]), G.get(l.bottoms[0])
+                if gtop is None or gbot is None or state(gtop) == "none":
+                    continue
+                acc = 1 if state(gbot) == "full" else 0
+                count = yb.pixels * yb.cstride
+                if yb.coffset or gtop.coffset or gbot.coffset or yb.cstride != gbot.cstride:
+                    raise NotImplementedError("sigmoid backward on channel slices")
+                ops.append(Op("sigmoid_bwd", l.name, lambda st, y=yb, a=gtop, b=gbot, acc=acc, n=count: L.check(
+                    lib.fcn_sigmoid_bwd_f32(y.ptr, a.ptr, b.ptr, n, acc, st))))
+                mark(gbot)
+                continue
+            gtop = G.get(l.tops[0]) if l.tops else None
+            if gtop is None or state(gtop) == "none":
+                continue                     # no gradient reaches this layer
+            if t == "Convolution":
+                meta = self._conv_layer_meta[l.name]
+                xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+                p = l.sub("convolution_param")
+                k, s, pad = kernel_stride_pad(p)
+                n, cin, h, w = xb.shape
+                _, cout, oh, ow = yb.shape
+                if meta.get("relu"):
+                    ops.append(Op("relu_bwd", l.name, lambda st, g=gtop, y=yb: L.check(lib.fcn_relu_bwd_f32(
+                        g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yb.pixels * cout))
+                d = L.ConvDesc()
+                d.x, d.y = xb.ptr, gtop.buf.ptr
+                d.N, d.H, d.W, d.Cin, d.x_cstride = n, h, w, _r4(cin), xb.cstride
+                d.Cout, d.kh, d.kw, d.pad, d.stride, d.OH, d.OW = cout, k, k, pad, s, oh, ow
+                d.y_cstride, d.y_coffset = gtop.cstride, gtop.coffset
+                if gtop.coffset % 4 or gtop.cstride % 4:
+                    raise NotImplementedError("gradient view of %s is not 16-byte aligned" % l.tops[0])
+                ws_floats = max(ws_floats, int(lib.fcn_conv2d_wgrad_workspace_floats(C.byref(d), None)))
+                dw = self._grad_view(l.name, 0)
+                db = self._grad_view(l.name, 1) if len(self.params_dev[l.name]) > 1 else None
+                self._keep.append(d)
+                flops = 2.0 * n * cout * oh * ow * cin * k * k
+                ops.append(Op("wgrad", l.name, lambda st, d=d, dw=dw, db=db: L.check(lib.fcn_conv2d_wgrad_f32(
+                    C.byref(d), dw.ptr, db.ptr if db else None, self._ws.ptr, st)), flops))
+                gbot = G.get(l.bottoms[0])
+                if gbot is not None:
+                    if s != 1:
+                        raise NotImplementedError("data gradient of the strided convolution %s" % l.name)
+                    co4 = gtop.cstride if gtop.coffset == 0 and gtop.cstride == _r4(cout) else None
+                    # the flipped bank reads Cout4 input channels: the gradient view must expose them contiguously
+                    cin_dg = _r4(cout)
+                    if gtop.cstride - gtop.coffset < cin_dg:
+                        raise NotImplementedError("gradient view of %s too narrow for the data-gradient pass" % l.tops[0])
+                    wt = DeviceBuffer(cin * k * k * cin_dg * 4, zero=True)
+                    flips[l.name] = wt
+                    wdev = self.params_dev[l.name][0]
+                    ops.append(Op("flip", l.name, lambda st, wdev=wdev, wt=wt, a=(cout, k, k, cin, _r4(cin), cin_dg): L.check(
+                        lib.fcn_conv_weights_flip_f32(wdev.ptr, wt.ptr, *a, st))))
+                    dd = L.ConvDesc()
+                    dd.x, dd.w, dd.bias, dd.y = gtop.ptr, wt.ptr, None, gbot.buf.ptr
+                    dd.N, dd.H, dd.W, dd.Cin, dd.x_cstride = n, oh, ow, cin_dg, gtop.cstride
+                    dd.Cout, dd.kh, dd.kw, dd.pad, dd.stride, dd.OH, dd.OW = cin, k, k, k - 1 - pad, 1, h, w
+                    dd.y_cstride, dd.y_coffset = gbot.cstride, gbot.coffset
+                    dd.flags = L.CONV_ACCUM if state(gbot) == "full" else 0
+                    self._keep.append(dd)
+                    ops.append(Op("dgrad", l.name, lambda st, dd=dd: L.check(lib.fcn_conv2d_fwd_f32(C.byref(dd), st)), flops))
+                    mark(gbot)
+                continue
+            gbot = G.get(l.bottoms[0]) if l.bottoms else None
+            if gbot is None:
+                continue
+            acc = 1 if state(gbot) == "full" else 0
+            if t == "Pooling":
+                pp = l.sub("pooling_param")
+                if str(pp.get("pool", "MAX")) != "MAX":
+                    raise NotImplementedError("backward of AVE pooling (%s)" % l.name)
+                xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+                n, c, h, w = xb.shape
+                _, _, oh, ow = yb.shape
+                k, s, pad = kernel_stride_pad(pp)
+                idx = self.aux_dev[l.name]
+                ops.append(Op("maxpool_bwd", l.name, lambda st, a=gtop, b=gbot, idx=idx, g=(n, h, w, c), kk=(k, s, pad, oh, ow), acc=acc: L.check(
+                    lib.fcn_maxpool_bwd_f32(a.buf.ptr, idx.ptr, b.buf.ptr, g[0], g[1], g[2], g[3], b.cstride, b.coffset, kk[0], kk[1], kk[2],
+                                            kk[3], kk[4], a.cstride, a.coffset, acc, st))))
+            elif t == "LRN":
+                xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+                p = l.sub("lrn_param")
+                ls, al, be = int(p.get("local_size", 5)), float(p.get("alpha", 1.0)), float(p.get("beta", 0.75))
+                sc = self.aux_dev[l.name]
+                if gtop.coffset or gbot.coffset or xb.coffset or yb.coffset:
+                    raise NotImplementedError("LRN backward on channel slices")
+                ops.append(Op("lrn_bwd", l.name, lambda st, x=xb, y=yb, sc=sc, a=gtop, b=gbot, q=(ls, al, be), acc=acc: L.check(
+                    lib.fcn_lrn_bwd_f32(x.ptr, y.ptr, sc.ptr, a.ptr, b.ptr, x.pixels, x.channels, x.cstride, y.cstride, q[0], q[1], q[2], acc, st))))
+            elif t == "Dropout":
+                if acc:
+                    raise NotImplementedError("dropout backward into an already written gradient")
+                ratio = float(l.sub("dropout_param").get("dropout_ratio", 0.5))
+                n, c, h, w = B[l.bottoms[0]].shape
+                ops.append(Op("dropout_bwd", l.name, lambda st, a=gtop, b=gbot, g=(n, c, h, w), r=ratio: L.check(lib.fcn_dropout_f32(
+                    a.buf.ptr, b.buf.ptr, g[0], g[1], g[2], g[3], a.cstride, a.coffset, b.cstride, b.coffset, r, self.dropout_seed, st))))
+            elif t == "Eltwise":
+                p = l.sub("eltwise_param")
+                if str(p.get("operation", "SUM")) != "PROD" or len(l.bottoms) != 2:
+                    raise NotImplementedError("backward of Eltwise %s" % l.name)
+                if l.bottoms[1] in self.need_grad:
+                    raise NotImplementedError("Eltwise PROD backward w.r.t. both bottoms (%s)" % l.name)
+                if acc:
+                    raise NotImplementedError("Eltwise backward into an already written gradient")
+                other = B[l.bottoms[1]]
+                count = gtop.pixels * gtop.cstride
+                if gtop.coffset or gbot.coffset or other.coffset or other.cstride != gtop.cstride:
+                    raise NotImplementedError("Eltwise backward on channel slices")
+                ops.append(Op("eltwise_bwd", l.name, lambda st, a=gtop, o=other, b=gbot, n=count: L.check(lib.fcn_eltwise_fwd_f32(
+                    a.ptr, o.ptr, b.ptr, n, L.ELT_PROD, 1.0, 1.0, st))))
+            elif t == "Sigmoid":
+                yb = B[l.tops[0]]
+                ops.append(Op("sigmoid_bwd", l.name, lambda st, y=yb, a=gtop, b=gbot, acc=acc: L.check(
+                    lib.fcn_sigmoid_bwd_f32(y.ptr, a.ptr, b.ptr, y.pixels * y.cstride, acc, st))))
+            elif t == "ReLU":
+                yb = B[l.tops[0]]
+                ops.append(Op("relu_bwd", l.name, lambda st, y=yb, a=gtop, b=gbot: L.check(lib.fcn_relu_bwd_f32(
+                    a.ptr, y.ptr, b.ptr, y.pixels, y.channels, y.cstride, st))))
+            elif t == "Power":
+                continue        # input transform: nothing upstream learns
+            else:
+                raise NotImplementedError("backward of layer type %s (%s)" % (t, l.name))
+            mark(gbot)
+        self._ws = DeviceBuffer(ws_floats * 4, zero=False)
+        self._flips = flips
+        self.bwd_ops = ops
+
+    def _fused_relu_layers(self) -> set:
+        if not hasattr(self, "_fused_relu_cache"):
+            out = set()
+            layers = self.spec.layers
+            for li, l in enumerate(layers):
+                if l.type == "Convolution" and self._conv_layer_meta.get(l.name, {}).get("relu"):
+                    top = l.tops[0]
+                    for nxt in layers[li + 1:]:
+                        if top in nxt.bottoms or top in nxt.tops:
+                            if nxt.type == "ReLU":
+                                out.add(nxt.name)
+                            break
+            self._fused_relu_cache = out
+        return self._fused_relu_cache
+
+    # ------------------------------------------------------------------ one solver iteration
+    def step(self, seed: Optional[int] = None) -> Dict[str, float]:
+        """Solver::Step for one iteration on the data currently in the input blobs' host arrays.
+        Returns {loss blob: value} plus 'loss' = sum of loss_weight * value (what `caffe train` prints)."""
+        lib = L.load()
+        with self.lock:
+            L.call("fcn_init", self.device)
+            self.dropout_seed = int(seed if seed is not None else self.iter) & 0xFFFFFFFF
+            for nm in self.inputs:
+                self._enqueue_upload(nm, self.stream)
+            self.run_ops(self.stream)
+            for op in self.bwd_ops:
+                op.run(self.stream)
+            world = 1
+            if self.comm is not None and self.comm.world > 1:
+                world = self.comm.world
+                self.comm.all_reduce_sum(self.grad_flat.ptr, self.param_count, self.stream)
+            self.apply_update(1.0 / (world * self.solver.iter_size))
+            for name, arr in self.loss_host.items():
+                L.check(lib.fcn_memcpy_d2h_async(arr.ctypes.data, self.blobs[name].buf.ptr, 4, self.stream))
+            L.call("fcn_stream_sync", self.stream)
+            for b in self.blobs.values():
+                b.host_valid = b.is_input
+            out = {k: float(v[0]) for k, v in self.loss_host.items()}
+            out["loss"] = float(sum(self.loss_blobs[k] * out[k] for k in self.loss_blobs))
+            self.iter += 1
+            return out
+
+    def apply_update(self, grad_scale: float) -> None:
+        sp, lib = self.solver, L.load()
+        rate = sp.rate(self.iter)
+        n = len(self.param_layout)
+        if sp.kind == "ADAM":
+            L.check(lib.fcn_adam_update_f32(self.param_flat.ptr, self.grad_flat.ptr, self.hist.ptr, self.hist2.ptr, self.segs_dev.ptr, n, rate,
+                                            sp.momentum, sp.momentum2, sp.delta, sp.weight_decay, self.iter + 1, grad_scale, self.stream))
+        else:
+            L.check(lib.fcn_sgd_update_f32(self.param_flat.ptr, self.grad_flat.ptr, self.hist.ptr, self.segs_dev.ptr, n, rate, sp.momentum,
+                                           sp.weight_decay, grad_scale, self.stream))
+
+    # ------------------------------------------------------------------ parameters back to Caffe layout
+    def download_params(self) -> Dict[str, List[np.ndarray]]:
+        """Current parameters as Caffe-layout host arrays (conv: OIHW, bias)."""
+        flat = np.empty(max(self.param_count, 4), F32)
+        L.call("fcn_memcpy_d2h_async", flat.ctypes.data, self.param_flat.ptr, flat.nbytes, self.stream)
+        L.call("fcn_stream_sync", self.stream)
+        return self._unpack(flat)
+
+    def download_grads(self) -> Dict[str, List[np.ndarray]]:
+        flat = np.empty(max(self.param_count, 4), F32)
+        L.call("fcn_memcpy_d2h_async", flat.ctypes.data, self.grad_flat.ptr, flat.nbytes, self.stream)
+        L.call("fcn_stream_sync", self.stream)
+        return self._unpack(flat)
+
+    def _unpack(self, flat: np.ndarray) -> Dict[str, List[np.ndarray]]:
+        out: Dict[str, List[np.ndarray]] = {}
+        types = {l.name: l.type for l in self.spec.layers}
+        for e in self.param_layout:
+            a = flat[e["offset"]:e["offset"] + e["count"]].reshape(e["shape"])
+            if e["index"] == 0 and types[e["layer"]] == "Convolution":
+                host_shape = self.params_host[e["layer"]][0].shape
+                a = a[..., :host_shape[1]].transpose(0, 3, 1, 2)
+            elif e["index"] == 0 and types[e["layer"]] == "Deconvolution":
+                a = a.reshape(self.params_host[e["layer"]][0].shape)
+            out.setdefault(e["layer"], []).append(np.ascontiguousarray(a))
+        return out
+
+    def read_grad(self, name: str) -> np.ndarray:
+        """NCHW host copy of a blob's gradient (debug / tests)."""
+        g = self.grad_blobs[name]
+        n, c, h, w = g.shape
+        raw = np.empty((n, h, w, g.cstride), F32)
+        L.call("fcn_memcpy_d2h_async", raw.ctypes.data, g.buf.ptr, raw.nbytes, self.stream)
+        L.call("fcn_stream_sync", self.stream)
+        return np.ascontiguousarray(raw[..., g.coffset:g.coffset + c].transpose(0, 3, 1, 2))
+
+    def save(self, path: str) -> None:
+        params = self.download_params()
+        layers = [(l.name, l.type, params[l.name]) for l in self.spec.param_layers()]
+        proto.write_caffemodel(path, layers, self.spec.name)
