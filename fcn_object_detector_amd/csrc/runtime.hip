@@ -155,6 +155,12 @@ int fcn_event_elapsed_ms(fcn_event_t start, fcn_event_t stop, float* h_ms) {
     return 0;
 }
 
+int fcn_stream_wait_event(fcn_stream_t s, fcn_event_t e) {
+    FCN_REQUIRE(e, FCN_E_ARG, "fcn_stream_wait_event: null event");
+    FCN_HIP(hipStreamWaitEvent(as_stream(s), (hipEvent_t)e, 0));
+    return 0;
+}
+
 int fcn_graph_begin(fcn_stream_t s) {
     FCN_REQUIRE(s, FCN_E_ARG, "fcn_graph_begin: capture needs an explicit stream");
     FCN_HIP(hipStreamBeginCapture(as_stream(s), hipStreamCaptureModeThreadLocal));

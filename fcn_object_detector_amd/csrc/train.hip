@@ -307,7 +307,7 @@ __device__ __forceinline__ unsigned dropout_hash(unsigned index, unsigned seed) 
 
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
                                                       int x_cstride, int x_coffset, int y_cstride, int y_coffset, unsigned thresh, float scale,
-                                                      unsigned seed) {
+                                                      unsigned seed, unsigned index_offset) {
     const long long total = (long long)N * H * W * C;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(t % C);
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
         long long u = pix / W;
         const int h = (int)(u % H);
         const int n = (int)(u / H);
-        const unsigned nchw = (unsigned)((((long long)n * C + c) * H + h) * W + w);
+        const unsigned nchw = (unsigned)((((long long)n * C + c) * H + h) * W + w) + index_offset;
         const bool keep = dropout_hash(nchw, seed) >= thresh;
         y[(size_t)pix * y_cstride + y_coffset + c] = keep ? x[(size_t)pix * x_cstride + x_coffset + c] * scale : 0.f;
     }
@@ -496,13 +496,13 @@ int fcn_lrn_bwd_f32(const float* x, const float* y, const float* scale, const fl
 
 // y = x * mask * 1/(1-ratio) with the counter-based mask of seed `seed`; run on activations (forward) or gradients (backward)
 int fcn_dropout_f32(const float* x, float* y, int N, int C, int H, int W, int x_cstride, int x_coffset, int y_cstride, int y_coffset,
-                    float ratio, unsigned seed, fcn_stream_t s) {
+                    float ratio, unsigned seed, unsigned index_offset, fcn_stream_t s) {
     FCN_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ratio >= 0.f && ratio < 1.f, FCN_E_ARG, "dropout: bad args");
     FCN_REQUIRE((long long)N * C * H * W < (1ll << 32), FCN_E_UNSUPPORTED, "dropout: blob too large for the 32-bit counter");
     double t = (double)ratio * 4294967296.0;
     const unsigned thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
     hipLaunchKernelGGL(dropout_kernel, dim3(stream_grid((long long)N * C * H * W, 256)), dim3(256), 0, as_stream(s), x, y, N, C, H, W, x_cstride,
-                       x_coffset, y_cstride, y_coffset, thresh, 1.f / (1.f - ratio), seed);
+                       x_coffset, y_cstride, y_coffset, thresh, 1.f / (1.f - ratio), seed, index_offset);
     FCN_LAUNCH_CHECK("dropout");
     return 0;
 }

@@ -171,3 +171,31 @@ class ControlPlane:
             except Exception:
                 pass
         self.peers, self.sock = [], None
+
+
+class RcclComm:
+    """Data plane: RCCL communicator inside libfcnhip.so; the ncclUniqueId travels over the control plane."""
+
+    def __init__(self, cp: ControlPlane, device: int):
+        import ctypes as C
+        from . import lib as L
+        self.cp, self.world, self.rank, self.device = cp, cp.world, cp.rank, device
+        L.call("fcn_init", device)
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            L.call("fcn_comm_unique_id", buf)
+        uid = cp.broadcast(bytes(buf.raw) if self.rank == 0 else None)
+        comm = C.c_void_p()
+        L.call("fcn_comm_init", C.byref(comm), C.create_string_buffer(uid, 128), self.world, self.rank)
+        self.comm = comm
+
+    def all_reduce_sum(self, ptr: int, count: int, stream) -> None:
+        """In-place sum of `count` floats at device address `ptr` over all ranks, enqueued on `stream`."""
+        from . import lib as L
+        L.call("fcn_comm_allreduce_sum_f32", self.comm, ptr, count, stream)
+
+    def close(self) -> None:
+        from . import lib as L
+        if self.comm:
+            L.load().fcn_comm_destroy(self.comm)
+            self.comm = None

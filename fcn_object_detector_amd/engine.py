@@ -170,6 +170,7 @@ class Engine:
         self.aux_dev: Dict[str, DeviceBuffer] = {}      # TRAIN: pooling argmax / LRN scale kept for backward
         self.loss_blobs: Dict[str, float] = {}          # loss top -> loss_weight
         self.dropout_seed = 0
+        self.dropout_index_offset = 0           # data-parallel rank r: r * (elements of the dropout blob)
         self.inputs = spec.data_tops()
         self.outputs = [b for b in spec.output_blobs() if b in self.shapes]
         self._plan_buffers()
@@ -583,7 +584,8 @@ class Engine:
                 ratio = float(l.sub("dropout_param").get("dropout_ratio", 0.5))
                 n, c, h, w = xb.shape
                 out.append(Op("dropout", l.name, lambda st: L.check(lib.fcn_dropout_f32(
-                    xb.buf.ptr, yb.buf.ptr, n, c, h, w, xb.cstride, xb.coffset, yb.cstride, yb.coffset, ratio, self.dropout_seed, st)),
+                    xb.buf.ptr, yb.buf.ptr, n, c, h, w, xb.cstride, xb.coffset, yb.cstride, yb.coffset, ratio, self.dropout_seed,
+                    self.dropout_index_offset, st)),
                     0.0, 8.0 * xb.pixels * c))
         elif t in ("L1Loss", "EuclideanLoss"):
             ab, bb, lb = B[l.bottoms[0]], B[l.bottoms[1]], B[l.tops[0]]

@@ -113,7 +113,12 @@ PROTOTYPES = {
     "fcn_sigmoid_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "fcn_maxpool_bwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
     "fcn_lrn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
-    "fcn_dropout_f32": (_i, [_vp, _vp] + [_i] * 8 + [_f, C.c_uint, _vp]),
+    "fcn_dropout_f32": (_i, [_vp, _vp] + [_i] * 8 + [_f, C.c_uint, C.c_uint, _vp]),
+    "fcn_stream_wait_event": (_i, [_vp, _vp]),
+    "fcn_comm_unique_id": (_i, [C.c_char_p]),
+    "fcn_comm_init": (_i, [C.POINTER(_vp), C.c_char_p, _i, _i]),
+    "fcn_comm_allreduce_sum_f32": (_i, [_vp, _vp, _sz, _vp]),
+    "fcn_comm_destroy": (_i, [_vp]),
     "fcn_loss_f32": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "fcn_sgd_update_f32": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp]),
     "fcn_adam_update_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp]),

@@ -266,7 +266,8 @@ class TrainEngine(Engine):
                 ratio = float(l.sub("dropout_param").get("dropout_ratio", 0.5))
                 n, c, h, w = B[l.bottoms[0]].shape
                 ops.append(Op("dropout_bwd", l.name, lambda st, a=gtop, b=gbot, g=(n, c, h, w), r=ratio: L.check(lib.fcn_dropout_f32(
-                    a.buf.ptr, b.buf.ptr, g[0], g[1], g[2], g[3], a.cstride, a.coffset, b.cstride, b.coffset, r, self.dropout_seed, st))))
+                    a.buf.ptr, b.buf.ptr, g[0], g[1], g[2], g[3], a.cstride, a.coffset, b.cstride, b.coffset, r, self.dropout_seed,
+                    self.dropout_index_offset, st))))
             elif t == "Eltwise":
                 p = l.sub("eltwise_param")
                 if str(p.get("operation", "SUM")) != "PROD" or len(l.bottoms) != 2:
@@ -297,6 +298,32 @@ class TrainEngine(Engine):
         self._ws = DeviceBuffer(ws_floats * 4, zero=False)
         self._flips = flips
         self.bwd_ops = ops
+        self._plan_buckets()
+
+    def _plan_buckets(self, bucket_floats: int = 1536 * 1024) -> None:
+        """Gradient buckets for the overlapped all-reduce: contiguous ranges of the flat gradient buffer (forward layer
+        order).  Backward fills the buffer from its end, so a bucket is complete once the wgrad of its FIRST layer has been
+        enqueued; its all-reduce then runs on a side stream while the main stream continues with earlier layers."""
+        self.buckets: List[dict] = []
+        if self.comm is None:
+            return
+        cur = None
+        for e in self.param_layout:
+            if cur is None or (e["index"] == 0 and cur["count"] >= bucket_floats):
+                cur = dict(offset=e["offset"], count=0, first_layer=e["layer"])
+                self.buckets.append(cur)
+            cur["count"] = e["offset"] + _r4(e["count"]) - cur["offset"]
+        wg_index = {op.name: i for i, op in enumerate(self.bwd_ops) if op.kind == "wgrad"}
+        lib = L.load()
+        sp = C.c_void_p()
+        L.call("fcn_stream_create", C.byref(sp))
+        self.comm_stream = int(sp.value)
+        for b in self.buckets:
+            b["after_op"] = wg_index.get(b["first_layer"], len(self.bwd_ops) - 1)
+            for key in ("ready", "done"):
+                ev = C.c_void_p()
+                L.call("fcn_event_create", C.byref(ev))
+                b[key] = ev
 
     def _fused_relu_layers(self) -> set:
         if not hasattr(self, "_fused_relu_cache"):
@@ -324,12 +351,20 @@ class TrainEngine(Engine):
             for nm in self.inputs:
                 self._enqueue_upload(nm, self.stream)
             self.run_ops(self.stream)
-            for op in self.bwd_ops:
+            world = self.comm.world if self.comm is not None else 1
+            triggers: Dict[int, List[dict]] = {}
+            for b in self.buckets:
+                triggers.setdefault(b["after_op"], []).append(b)
+            for i, op in enumerate(self.bwd_ops):
                 op.run(self.stream)
-            world = 1
-            if self.comm is not None and self.comm.world > 1:
-                world = self.comm.world
-                self.comm.all_reduce_sum(self.grad_flat.ptr, self.param_count, self.stream)
+                for b in triggers.get(i, ()):
+                    # this bucket's gradients are final: sum them across ranks on the side stream
+                    L.check(lib.fcn_event_record(b["ready"], self.stream))
+                    L.check(lib.fcn_stream_wait_event(self.comm_stream, b["ready"]))
+                    self.comm.all_reduce_sum(self.grad_flat.ptr + 4 * b["offset"], b["count"], self.comm_stream)
+                    L.check(lib.fcn_event_record(b["done"], self.comm_stream))
+            for b in self.buckets:
+                L.check(lib.fcn_stream_wait_event(self.stream, b["done"]))
             self.apply_update(1.0 / (world * self.solver.iter_size))
             for name, arr in self.loss_host.items():
                 L.check(lib.fcn_memcpy_d2h_async(arr.ctypes.data, self.blobs[name].buf.ptr, 4, self.stream))

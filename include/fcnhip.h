@@ -70,6 +70,7 @@ int  fcn_event_destroy(fcn_event_t e);
 int  fcn_event_record(fcn_event_t e, fcn_stream_t s);
 int  fcn_event_sync(fcn_event_t e);
 int  fcn_event_elapsed_ms(fcn_event_t start, fcn_event_t stop, float* h_ms);
+int  fcn_stream_wait_event(fcn_stream_t s, fcn_event_t e);   /* later work on s waits for e (overlap of collectives) */
 /* hipGraph capture of a whole Net::Forward / ForwardBackward launch sequence */
 int  fcn_graph_begin(fcn_stream_t s);
 int  fcn_graph_end(fcn_stream_t s, fcn_graph_t* g);
@@ -220,7 +221,9 @@ int  fcn_lrn_bwd_f32(const float* x, const float* y, const float* scale, const f
 /* Dropout (TRAIN): y = x * mask / (1 - ratio); mask of element (n,c,h,w) = hash(NCHW index, seed) >= ratio * 2^32.
  * The same call with the same seed applied to the gradient is the backward pass. */
 int  fcn_dropout_f32(const float* x, float* y, int N, int C, int H, int W, int x_cstride, int x_coffset, int y_cstride,
-                     int y_coffset, float ratio, unsigned seed, fcn_stream_t s);
+                     int y_coffset, float ratio, unsigned seed, unsigned index_offset, fcn_stream_t s);
+/* index_offset is added to the NCHW index: rank r of a data-parallel job passes r*N*C*H*W so that the masks of the
+ * shards together equal the mask of the undivided batch */
 /* kind 0 = L1Loss (NVIDIA Caffe): loss = sum|a-b|/num, da = sign(a-b) * weight/num;
  * kind 1 = EuclideanLoss: loss = sum(a-b)^2/(2 num), da = (a-b) * weight/num.  da may be NULL; d_loss is one device float. */
 int  fcn_loss_f32(int kind, const float* a, const float* b, float* da, float* d_loss, int pixels, int C, int cstride, int num,
@@ -233,6 +236,13 @@ int  fcn_sgd_update_f32(float* w, const float* g, float* hist, const fcn_solver_
 /* Adam (Caffe AdamSolver): m,v moments, w -= rate*lr_mult*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+delta) */
 int  fcn_adam_update_f32(float* w, const float* g, float* m, float* v, const fcn_solver_seg* d_segs, int nseg, float rate,
                          float beta1, float beta2, float delta, float weight_decay, int t, float grad_scale, fcn_stream_t s);
+
+/* ---- data-parallel exchange (new capability; the reference trains with --gpu=0 only, train/train.sh:26):
+ *      sum of the flat gradient buffer over all ranks with RCCL on the caller's stream ---- */
+int  fcn_comm_unique_id(char* h_id128);                                    /* rank 0: ncclGetUniqueId (128 bytes)   */
+int  fcn_comm_init(fcn_comm_t* comm, const char* h_id128, int world, int rank);
+int  fcn_comm_allreduce_sum_f32(fcn_comm_t comm, float* buf, size_t count, fcn_stream_t s);
+int  fcn_comm_destroy(fcn_comm_t comm);
 
 #ifdef __cplusplus
 }

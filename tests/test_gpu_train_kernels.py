@@ -125,11 +125,16 @@ def test_dropout_mask_is_the_oracle_mask(gpu):
     x = np.random.default_rng(4).standard_normal((3, 20, 6, 5)).astype(np.float32) + 3
     xd = dev_from(nhwc(x))
     yd = dev_from(np.zeros((3, 6, 5, 24), np.float32))
-    L.call("fcn_dropout_f32", xd.ptr, yd.ptr, 3, 20, 6, 5, 20, 0, 24, 4, 0.4, 12345, None)
+    L.call("fcn_dropout_f32", xd.ptr, yd.ptr, 3, 20, 6, 5, 20, 0, 24, 4, 0.4, 12345, 0, None)
     y = nchw(dev_to(yd, (3, 6, 5, 24)), 20, 4)
     mask = R.dropout_mask(x.shape, 0.4, 12345)
     assert np.array_equal(y, x * mask * np.float32(1.0 / (1.0 - 0.4)))
     assert 0.5 < mask.mean() < 0.7
+    # a data-parallel shard (images 1..2 of the 3) reproduces its part of the mask through index_offset
+    xs = dev_from(nhwc(x[1:]))
+    ys = dev_from(np.zeros((2, 6, 5, 24), np.float32))
+    L.call("fcn_dropout_f32", xs.ptr, ys.ptr, 2, 20, 6, 5, 20, 0, 24, 4, 0.4, 12345, 20 * 6 * 5, None)
+    assert np.array_equal(nchw(dev_to(ys, (2, 6, 5, 24)), 20, 4), y[1:])
 
 
 def test_losses(gpu):
