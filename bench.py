@@ -71,6 +71,65 @@ def cpu_baseline(msg, params, x, budget_s: float = 20.0):
                       "(median %.1f ms, %d BLAS threads of %d available cores)" % (len(times), med * 1e3, threads, avail)}, ref.blobs
 
 
+def synth_boxes(rng, n_images, size=448):
+    """BASELINE config 3 / SURVEY §8d: per image 1-3 rects, w,h ~ U{32..224}, x,y ~ U{0..size-1-w}, label 0."""
+    rects, labels = [], []
+    for _ in range(n_images):
+        rs = []
+        for _ in range(int(rng.integers(1, 4))):
+            w, h = int(rng.integers(32, 225)), int(rng.integers(32, 225))
+            rs.append((int(rng.integers(0, size - w)), int(rng.integers(0, size - h)), w, h))
+        rects.append(rs)
+        labels.append([0] * len(rs))
+    return rects, labels
+
+
+def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
+    """One data-parallel training step = target generation (device) + forward + backward + all-reduce + SGD update on
+    `per_gpu_batch` synthetic 448x448 images per GPU (BASELINE configs[2] at N=1, configs[3] at N=8)."""
+    from fcn_object_detector_amd import dp, lib as L, models, proto
+    from fcn_object_detector_amd.netspec import NetSpec, fill_params
+    from fcn_object_detector_amd.train import SolverParams, TrainEngine
+    msg = proto.parse_text(models.googlenet_detectnet_train("synthetic", "Boxes", "448,448,16,1,%d,none" % per_gpu_batch, num_classes=1))
+    n = per_gpu_batch
+    shapes = {"data": (n, 3, 448, 448), "coverage-label": (n, 1, 28, 28)}
+    for k in ("bbox-label", "size-block", "obj-block", "coverage-block"):
+        shapes[k] = (n, 4, 28, 28)
+    spec = NetSpec(msg, "TRAIN")
+    spec.infer(shapes)
+    comm = dp.RcclComm(cp, local) if world > 1 else None
+    eng = TrainEngine(NetSpec(msg, "TRAIN"), shapes, params=fill_params(spec, seed=1234), device=local, comm=comm,
+                      solver=SolverParams(base_lr=1e-4, momentum=0.9, weight_decay=1e-7, lr_policy="fixed"))
+    eng.dropout_index_offset = rank * n * 1024 * 28 * 28
+    rng = np.random.default_rng(1000 + rank)
+    eng.host_array("data")[...] = rng.random((n, 3, 448, 448), dtype=np.float32)
+    eng.upload_inputs()                                          # images resident in HBM; labels are generated on the device
+    losses = []
+    for it in range(max(warmup, 1)):
+        eng.set_targets(*synth_boxes(np.random.default_rng(42 + it * world + rank), n), stride=16)
+        losses.append(eng.step(seed=it, upload=False)["loss"])
+    L.call("fcn_device_sync")
+    cp.barrier()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        eng.set_targets(*synth_boxes(np.random.default_rng(4242 + it * world + rank), n), stride=16)
+        losses.append(eng.step(seed=1000 + it, upload=False)["loss"])
+    L.call("fcn_device_sync")
+    t_local = time.perf_counter() - t0
+    cp.barrier()
+    t_max = cp.max(t_local)
+    res = {"imgs_per_s": round(steps * n * world / t_max, 2), "ms_per_step": round(t_max * 1e3 / steps, 3), "steps": steps,
+           "per_gpu_batch": n, "global_batch": n * world, "n_gpus": world,
+           "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)], "train_gflop_per_img": 45.9,
+           "workload": "configs[%d]: DetectNet GoogLeNet train step (device target generation + fwd + bwd + %s + SGD), batch %d/GPU, 448x448, f32"
+                       % (2 if world == 1 else 3, "RCCL all-reduce of 23.9 MB grads" if world > 1 else "no collective", n)}
+    res["achieved_tflops"] = round(45.9e-3 * res["imgs_per_s"], 2)
+    eng.close()
+    if comm is not None:
+        comm.close()
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +137,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="frames per step (BASELINE config 2 uses 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step measurement reported under 'train'")
+    ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step (BASELINE configs[2]/[3])")
+    ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (default: min(steps, 30))")
     ap.add_argument("--per-op", action="store_true", help="print the per-launch table to stderr")
     args = ap.parse_args()
 
@@ -176,6 +238,11 @@ def main() -> None:
             out["speedup_vs_cpu"] = round(value / base["value"], 1)
     cp.barrier()
     eng.close()
+    if not args.no_train:
+        tsteps = args.train_steps or max(min(args.steps, 30), 1)
+        tr = bench_train(cp, rank, world, local, args.train_batch, tsteps, max(min(args.warmup, 5), 2))
+        if out is not None:
+            out["train"] = tr
     cp.close()
     if out is not None:
         print(json.dumps(out))

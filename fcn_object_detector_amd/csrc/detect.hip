@@ -257,10 +257,13 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
 // ---------------------------------------------------------------------------------------------
 // target generation: one lane per (image, class, cell)
 // ---------------------------------------------------------------------------------------------
+// NHWC = false: the Python layer's NCHW tops; NHWC = true: the engine's blob buffers (channel strides fg_cs / blk_cs)
+template <bool NHWC>
 __global__ __launch_bounds__(256) void gen_targets_kernel(const int32_t* __restrict__ rects, const int32_t* __restrict__ labels,
                                                           const int32_t* __restrict__ offs, int batch, int C, int gy, int gx, int stride,
                                                           double iou_thresh, float* __restrict__ fg, float* __restrict__ bbox,
-                                                          float* __restrict__ size, float* __restrict__ obj, float* __restrict__ cvgb) {
+                                                          float* __restrict__ size, float* __restrict__ obj, float* __restrict__ cvgb,
+                                                          int fg_cs, int blk_cs) {
     const int G = gy * gx;
     const long long total = (long long)batch * C * G;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -287,6 +290,23 @@ __global__ __launch_bounds__(256) void gen_targets_kernel(const int32_t* __restr
             float score = __fdiv_rn(anb, aub);
             score = __fdiv_rn(score, area_ratio);
             if ((double)score > iou_thresh) hit = r;  // later rects overwrite earlier ones
+        }
+        if (NHWC) {
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, s0 = 0.f, s1 = 0.f, ob = 0.f, cv = 0.f;
+            if (hit >= 0) {
+                const int rx = rects[4 * hit + 0], ry = rects[4 * hit + 1], rw = rects[4 * hit + 2], rh = rects[4 * hit + 3];
+                b0 = (float)(rx - cx); b1 = (float)(ry - cy); b2 = (float)(rx + rw - cx); b3 = (float)(ry + rh - cy);
+                s0 = (float)(1.0 / (double)rw); s1 = (float)(1.0 / (double)rh);
+                ob = __fdiv_rn((float)((double)stride * (double)stride), (float)((double)rw * (double)rh));
+                cv = 1.f;
+            }
+            const size_t o = ((size_t)img * G + cell) * blk_cs + 4 * cls;
+            bbox[o] = b0; bbox[o + 1] = b1; bbox[o + 2] = b2; bbox[o + 3] = b3;
+            size[o] = s0; size[o + 1] = s1; size[o + 2] = s0; size[o + 3] = s1;
+            obj[o] = ob; obj[o + 1] = ob; obj[o + 2] = ob; obj[o + 3] = ob;
+            cvgb[o] = cv; cvgb[o + 1] = cv; cvgb[o + 2] = cv; cvgb[o + 3] = cv;
+            fg[((size_t)img * G + cell) * fg_cs + cls] = cv;
+            continue;
         }
         const size_t o4 = ((size_t)img * 4 * C + 4 * cls) * G + cell;
         float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, s0 = 0.f, s1 = 0.f, ob = 0.f, cv = 0.f;
@@ -351,9 +371,22 @@ int fcn_gen_targets(const int32_t* rects, const int32_t* labels, const int32_t* 
     FCN_REQUIRE(rects && labels && rect_offsets && foreground && bbox && size && obj && cvg_block, FCN_E_ARG, "gen_targets: null");
     FCN_REQUIRE(batch > 0 && num_classes > 0 && gy > 0 && gx > 0 && stride > 0, FCN_E_ARG, "gen_targets: bad extents");
     const long long total = (long long)batch * num_classes * gy * gx;
-    hipLaunchKernelGGL(gen_targets_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(s), rects, labels, rect_offsets, batch,
-                       num_classes, gy, gx, stride, iou_thresh, foreground, bbox, size, obj, cvg_block);
+    hipLaunchKernelGGL(gen_targets_kernel<false>, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(s), rects, labels, rect_offsets, batch,
+                       num_classes, gy, gx, stride, iou_thresh, foreground, bbox, size, obj, cvg_block, 0, 0);
     FCN_LAUNCH_CHECK("gen_targets");
+    return 0;
+}
+
+int fcn_gen_targets_nhwc(const int32_t* rects, const int32_t* labels, const int32_t* rect_offsets, int batch, int num_classes, int gy, int gx,
+                         int stride, double iou_thresh, float* foreground, int fg_cstride, float* bbox, float* size, float* obj,
+                         float* cvg_block, int blk_cstride, fcn_stream_t s) {
+    FCN_REQUIRE(rects && labels && rect_offsets && foreground && bbox && size && obj && cvg_block, FCN_E_ARG, "gen_targets_nhwc: null");
+    FCN_REQUIRE(batch > 0 && num_classes > 0 && gy > 0 && gx > 0 && stride > 0 && fg_cstride >= num_classes && blk_cstride >= 4 * num_classes,
+                FCN_E_ARG, "gen_targets_nhwc: bad extents");
+    const long long total = (long long)batch * num_classes * gy * gx;
+    hipLaunchKernelGGL(gen_targets_kernel<true>, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(s), rects, labels, rect_offsets, batch,
+                       num_classes, gy, gx, stride, iou_thresh, foreground, bbox, size, obj, cvg_block, fg_cstride, blk_cstride);
+    FCN_LAUNCH_CHECK("gen_targets_nhwc");
     return 0;
 }
 

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "fcn_detect_workspace_bytes": (_sz, [C.POINTER(DetectParams), _i]),
     "fcn_detect_decode_group": (_i, [_vp, _vp, _i, _sz, _sz, C.POINTER(DetectParams), _vp, _vp, _vp, _vp, _vp]),
     "fcn_gen_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fcn_gen_targets_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "fcn_conv2d_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc), C.POINTER(_i)]),
     "fcn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "fcn_conv_weights_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

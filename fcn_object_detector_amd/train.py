@@ -341,15 +341,65 @@ class TrainEngine(Engine):
         return self._fused_relu_cache
 
     # ------------------------------------------------------------------ one solver iteration
-    def step(self, seed: Optional[int] = None) -> Dict[str, float]:
-        """Solver::Step for one iteration on the data currently in the input blobs' host arrays.
+    # blob names of the DetectNet label tops, in the order DataArgumentationLayer emits them (data_argumentation_layer.py:67-72)
+    LABEL_TOPS = ("coverage-label", "bbox-label", "size-block", "obj-block", "coverage-block")
+
+    def set_targets(self, rects: Sequence[Sequence[Sequence[int]]], labels: Sequence[Sequence[int]], stride: int,
+                    iou_thresh: float = 0.1, tops: Sequence[str] = LABEL_TOPS) -> None:
+        """Stage the ground-truth boxes of the next step; the label blobs are then generated ON THE DEVICE inside step()
+        (fcn_gen_targets_nhwc: bounding_box_parameterized_labels of the reference) instead of being uploaded."""
+        fg = self.blobs[tops[0]]
+        n, c, gy, gx = fg.shape
+        if len(rects) != n or len(labels) != n:
+            raise ValueError("need boxes for %d images" % n)
+        offs = np.zeros(n + 1, np.int32)
+        flat_r, flat_l = [], []
+        for i, (rs, ls) in enumerate(zip(rects, labels)):
+            for r, lab in zip(rs, ls):
+                if not 0 <= int(lab) < c:
+                    raise IndexError("label %d outside [0, %d)" % (lab, c))
+                flat_r.append([int(v) for v in r])
+                flat_l.append(int(lab))
+            offs[i + 1] = len(flat_r)
+        if not hasattr(self, "_tgt"):
+            cap = max(64 * n, 256)
+            self._tgt = dict(cap=cap, rects=DeviceBuffer(cap * 16, zero=True), labels=DeviceBuffer(cap * 4, zero=True),
+                             offs=DeviceBuffer((n + 1) * 4, zero=True))
+        if len(flat_r) > self._tgt["cap"]:
+            raise ValueError("too many boxes in one batch (%d > %d)" % (len(flat_r), self._tgt["cap"]))
+        self._tgt.update(h_rects=np.asarray(flat_r, np.int32).reshape(-1, 4), h_labels=np.asarray(flat_l, np.int32), h_offs=offs,
+                         stride=int(stride), thresh=float(iou_thresh), tops=tuple(tops), pending=True)
+
+    def _enqueue_targets(self) -> None:
+        t, lib = self._tgt, L.load()
+        if t["h_rects"].size:
+            L.check(lib.fcn_memcpy_h2d_async(t["rects"].ptr, t["h_rects"].ctypes.data, t["h_rects"].nbytes, self.stream))
+            L.check(lib.fcn_memcpy_h2d_async(t["labels"].ptr, t["h_labels"].ctypes.data, t["h_labels"].nbytes, self.stream))
+        L.check(lib.fcn_memcpy_h2d_async(t["offs"].ptr, t["h_offs"].ctypes.data, t["h_offs"].nbytes, self.stream))
+        fg, bb, sz, ob, cv = (self.blobs[nm] for nm in t["tops"])
+        n, c, gy, gx = fg.shape
+        for b in (bb, sz, ob, cv):
+            if b.coffset or b.cstride != bb.cstride:
+                raise NotImplementedError("label blobs must be plain buffers of one geometry")
+        L.check(lib.fcn_gen_targets_nhwc(t["rects"].ptr, t["labels"].ptr, t["offs"].ptr, n, c, gy, gx, t["stride"], t["thresh"],
+                                         fg.ptr, fg.cstride, bb.ptr, sz.ptr, ob.ptr, cv.ptr, bb.cstride, self.stream))
+
+    def step(self, seed: Optional[int] = None, upload: bool = True) -> Dict[str, float]:
+        """Solver::Step for one iteration.  Inputs come from the input blobs' host arrays (upload=True), except label
+        blobs staged with set_targets(), which are generated on the device; upload=False reuses what is already in HBM.
         Returns {loss blob: value} plus 'loss' = sum of loss_weight * value (what `caffe train` prints)."""
         lib = L.load()
         with self.lock:
             L.call("fcn_init", self.device)
             self.dropout_seed = int(seed if seed is not None else self.iter) & 0xFFFFFFFF
-            for nm in self.inputs:
-                self._enqueue_upload(nm, self.stream)
+            dev_targets = getattr(self, "_tgt", None) is not None and self._tgt.get("pending")
+            if upload:
+                skip = set(self._tgt["tops"]) if dev_targets else set()
+                for nm in self.inputs:
+                    if nm not in skip:
+                        self._enqueue_upload(nm, self.stream)
+            if dev_targets:
+                self._enqueue_targets()
             self.run_ops(self.stream)
             world = self.comm.world if self.comm is not None else 1
             triggers: Dict[int, List[dict]] = {}

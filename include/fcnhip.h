@@ -201,6 +201,12 @@ int  fcn_gen_targets(const int32_t* rects, const int32_t* labels, const int32_t*
                      int num_classes, int gy, int gx, int stride, double iou_thresh,
                      float* foreground, float* bbox, float* size, float* obj, float* cvg_block,
                      fcn_stream_t s);
+/* same arithmetic, written straight into the engine's NHWC blob buffers (element (img, cell, channel) at
+ * [(img*gy*gx + cell) * cstride + channel]) so a training step needs no host round trip for its labels */
+int  fcn_gen_targets_nhwc(const int32_t* rects, const int32_t* labels, const int32_t* rect_offsets, int batch,
+                          int num_classes, int gy, int gx, int stride, double iou_thresh,
+                          float* foreground, int fg_cstride, float* bbox, float* size, float* obj, float* cvg_block,
+                          int blk_cstride, fcn_stream_t s);
 
 /* ---- training: Net::Backward + losses + solver update as run by `caffe train` (train/train.sh:25-28) over the
  *      loss tail models/train_val.prototxt:53-72,2237-2281 with the settings of train/<net>/solver.prototxt ---- */
