@@ -277,10 +277,12 @@ def write_caffemodel(path: str, layers: List[Tuple[str, str, List[np.ndarray]]],
         f.write(bytes(out))
 
 
-def pack_solverstate(it: int, history: List[np.ndarray]) -> bytes:
-    """SolverState { int32 iter = 1; repeated BlobProto history = 3; } (public caffe.proto)."""
+def pack_solverstate(it: int, history: List[np.ndarray], learned_net: str = "") -> bytes:
+    """SolverState { int32 iter = 1; string learned_net = 2; repeated BlobProto history = 3; } (public caffe.proto)."""
     out = bytearray()
     out += _enc_varint((1 << 3) | 0) + _enc_varint(it)
+    if learned_net:
+        out += _ld(2, learned_net.encode("utf-8"))
     for h in history:
         arr = np.ascontiguousarray(h, dtype="<f4")
         shape = b"".join(_enc_varint(int(d)) for d in arr.shape)
@@ -288,11 +290,13 @@ def pack_solverstate(it: int, history: List[np.ndarray]) -> bytes:
     return bytes(out)
 
 
-def unpack_solverstate(buf: bytes) -> Tuple[int, List[np.ndarray]]:
-    it, hist = 0, []
+def unpack_solverstate(buf: bytes, with_learned_net: bool = False):
+    it, hist, learned = 0, [], ""
     for num, wt, v in _fields(buf):
         if num == 1 and wt == 0:
             it = v
+        elif num == 2 and wt == 2:
+            learned = bytes(v).decode("utf-8")
         elif num == 3 and wt == 2:
             hist.append(_decode_blob(v))
-    return it, hist
+    return (it, hist, learned) if with_learned_net else (it, hist)

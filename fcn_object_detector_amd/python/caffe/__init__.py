@@ -16,7 +16,6 @@ All arithmetic runs in libfcnhip.so on the GPU; there is no CPU mode.
 """
 from __future__ import annotations
 
-import importlib
 import os
 import sys
 import threading
@@ -31,6 +30,7 @@ if _PKG_PARENT not in sys.path:
 
 from fcn_object_detector_amd import lib as _L  # noqa: E402
 from fcn_object_detector_amd import proto as _proto  # noqa: E402
+from fcn_object_detector_amd import pylayer as _pylayer  # noqa: E402
 from fcn_object_detector_amd.engine import Engine as _Engine  # noqa: E402
 from fcn_object_detector_amd.netspec import NetSpec as _NetSpec, fill_params as _fill_params  # noqa: E402
 
@@ -64,66 +64,8 @@ def _current_device() -> int:
     return getattr(_state, "device", _default_device)
 
 
-class Layer(object):
-    """Base class of Python layers (``type: 'Python'``); mirrors caffe.Layer."""
-
-    def __init__(self):
-        self.param_str = ""
-        self.blobs = []
-        self.phase = TEST
-
-    def setup(self, bottom, top):
-        pass
-
-    def reshape(self, bottom, top):
-        pass
-
-    def forward(self, bottom, top):
-        pass
-
-    def backward(self, top, propagate_down, bottom):
-        pass
-
-
-class _TopProxy(object):
-    """What a Python layer sees as ``top[i]`` / ``bottom[i]``: ``reshape(*dims)`` and a float32 ``data`` array."""
-
-    def __init__(self, name: str):
-        self.name = name
-        self.shape_ = None
-        self._data = None
-        self.diff = None
-
-    def reshape(self, *dims):
-        dims = tuple(int(d) for d in (dims[0] if len(dims) == 1 and isinstance(dims[0], (tuple, list)) else dims))
-        if self.shape_ != dims:
-            self.shape_ = dims
-            if self._data is None or self._data.shape != dims:
-                self._data = np.zeros(dims, np.float32)
-
-    @property
-    def data(self):
-        return self._data
-
-    @property
-    def shape(self):
-        return self.shape_
-
-    @property
-    def num(self):
-        return self.shape_[0]
-
-    @property
-    def channels(self):
-        return self.shape_[1]
-
-    @property
-    def height(self):
-        return self.shape_[2]
-
-    @property
-    def width(self):
-        return self.shape_[3]
+Layer = _pylayer.Layer
+_TopProxy = _pylayer.TopProxy
 
 
 class _Blob(object):
@@ -217,29 +159,7 @@ class Net(object):
     # ---- construction -------------------------------------------------
     def _setup_python_layers(self) -> None:
         spec = _NetSpec(self._msg, self._phase)
-        for l in spec.layers:
-            if l.type != "Python":
-                continue
-            pp = l.sub("python_param")
-            mod = importlib.import_module(str(pp.get("module")))
-            cls = getattr(mod, str(pp.get("layer")))
-            inst = cls.__new__(cls)
-            Layer.__init__(inst)
-            try:
-                cls.__init__(inst)
-            except TypeError:
-                pass
-            inst.param_str = str(pp.get("param_str", ""))
-            inst.phase = TRAIN if self._phase == "TRAIN" else TEST
-            bottoms = [_TopProxy(b) for b in l.bottoms]
-            tops = [_TopProxy(t) for t in l.tops]
-            inst.setup(bottoms, tops)
-            inst.reshape(bottoms, tops)
-            for t in tops:
-                if t.shape_ is None:
-                    raise RuntimeError("Python layer %s did not reshape top %s" % (l.name, t.name))
-                self._data_shapes[t.name] = t.shape_
-            self._py_layers.append((l, inst, bottoms, tops))
+        self._py_layers, self._data_shapes = _pylayer.setup_python_layers(spec, TRAIN if self._phase == "TRAIN" else TEST)
 
     def _build(self, initial_params) -> None:
         spec = _NetSpec(self._msg, self._phase)
@@ -329,3 +249,14 @@ class Net(object):
 
     def backward(self, **kwargs):
         raise NotImplementedError("Net.backward(): training runs through the `caffe train` tool")
+
+
+# ---- solvers (pycaffe: caffe.SGDSolver / caffe.AdamSolver / caffe.get_solver) --------------------------------------
+def get_solver(solver_file, **kw):
+    from fcn_object_detector_amd.solver import Solver
+    kw.setdefault("device", _current_device())
+    return Solver(str(solver_file), **kw)
+
+
+SGDSolver = get_solver
+AdamSolver = get_solver

@@ -464,6 +464,46 @@ class TrainEngine(Engine):
             out.setdefault(e["layer"], []).append(np.ascontiguousarray(a))
         return out
 
+    def _pack(self, per_layer: Dict[str, List[np.ndarray]]) -> np.ndarray:
+        """Inverse of _unpack: Caffe-layout blobs -> the flat device layout (padded input channels stay zero)."""
+        flat = np.zeros(max(self.param_count, 4), F32)
+        types = {l.name: l.type for l in self.spec.layers}
+        for e in self.param_layout:
+            a = np.asarray(per_layer[e["layer"]][e["index"]], F32)
+            if e["index"] == 0 and types[e["layer"]] == "Convolution":
+                co, ci, kh, kw = self.params_host[e["layer"]][0].shape
+                d = np.zeros(e["shape"], F32)
+                d[..., :ci] = a.reshape(co, ci, kh, kw).transpose(0, 2, 3, 1)
+                a = d
+            flat[e["offset"]:e["offset"] + e["count"]] = a.reshape(-1)
+        return flat
+
+    def download_history(self) -> List[np.ndarray]:
+        """Solver history in Caffe's order: one blob per learnable parameter (SGD momentum / Adam m), then Adam's v blobs."""
+        out: List[np.ndarray] = []
+        for buf in (self.hist, self.hist2):
+            if buf is None:
+                continue
+            flat = np.empty(max(self.param_count, 4), F32)
+            L.call("fcn_memcpy_d2h_async", flat.ctypes.data, buf.ptr, flat.nbytes, self.stream)
+            L.call("fcn_stream_sync", self.stream)
+            per = self._unpack(flat)
+            for l in self.spec.param_layers():
+                out.extend(per[l.name])
+        return out
+
+    def upload_history(self, history: Sequence[np.ndarray]) -> None:
+        bufs = [b for b in (self.hist, self.hist2) if b is not None]
+        per_buf = sum(len(self.params_host[l.name]) for l in self.spec.param_layers())
+        if len(history) != per_buf * len(bufs):
+            raise ValueError("solver state holds %d history blobs, this solver needs %d" % (len(history), per_buf * len(bufs)))
+        it = iter(history)
+        for buf in bufs:
+            per = {l.name: [next(it) for _ in self.params_host[l.name]] for l in self.spec.param_layers()}
+            flat = self._pack(per)
+            L.call("fcn_memcpy_h2d_async", buf.ptr, flat.ctypes.data, flat.nbytes, self.stream)
+            L.call("fcn_stream_sync", self.stream)
+
     def read_grad(self, name: str) -> np.ndarray:
         """NCHW host copy of a blob's gradient (debug / tests)."""
         g = self.grad_blobs[name]
