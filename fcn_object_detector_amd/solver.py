@@ -42,8 +42,7 @@ class _BlobView(object):
 
     @property
     def data(self) -> np.ndarray:
-        e = self._eng
-        return e.host_array(self._name) if self._name in e.inputs else e.read_blob(self._name)
+        return self._eng.read_blob(self._name)
 
     @property
     def diff(self) -> np.ndarray:

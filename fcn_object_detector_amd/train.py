@@ -421,6 +421,9 @@ class TrainEngine(Engine):
             L.call("fcn_stream_sync", self.stream)
             for b in self.blobs.values():
                 b.host_valid = b.is_input
+            if dev_targets:
+                for nm in self._tgt["tops"]:
+                    self.blobs[nm].host_valid = False      # generated in HBM, never on the host
             out = {k: float(v[0]) for k, v in self.loss_host.items()}
             out["loss"] = float(sum(self.loss_blobs[k] * out[k] for k in self.loss_blobs))
             self.iter += 1
