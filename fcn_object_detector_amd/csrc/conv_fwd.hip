@@ -111,7 +111,7 @@ struct Cfg {
     static_assert((BK / 8) % WAVES_K == 0, "each wave needs whole k-steps of a chunk");
     static_assert(STEP % 16 == 0, "a lane's rows must agree mod 16 so that its swizzle (and k position) is the same for all of them");
     static_assert(BM % STEP == 0 && BN % STEP == 0, "A / B rows must split into whole wave-instructions");
-    static_assert(WAVES_K == 1 || WAVES_K == 2 || WAVES_K == 4, "K split over 1, 2 or 4 waves");
+    static_assert(WAVES_K == 1 || WAVES_K == 2 || WAVES_K == 4 || WAVES_K == 8, "K split over 1, 2, 4 or 8 waves");
     static_assert(WTM <= 2 && WTN <= 2, "fragment reads are written out for at most 2x2 MFMA tiles per wave");
     static_assert(NBUF >= 3 && INST * (D - 1) <= 63, "vmcnt is a 6-bit counter");
     static_assert(!PF || NBUF >= 4, "fragment prefetch needs chunk c+1 landed while c+2.. are in flight");
@@ -187,30 +187,31 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const float* zero_page = reinterpret_cast<const float*>(zp_bits);
     const int lds_wave_base = RPI * wid * BK;   // float offset of instruction 0's 1 KiB piece inside a ring slot
 
-    // Issue the LDS-DMA of one chunk (INST x global_load_lds_dwordx4 per wave) into ring slot `buf`.  Every lane
-    // always loads: lanes outside the image / tile / K read the zero page, so padding arrives as zeros and the
-    // number of outstanding instructions per chunk is a constant the vmcnt waits can count on.
-    auto issue_chunk = [&](const int buf) {
-        const int kr = (kt * p.kw_magic) >> 16;            // kt / kw (magic = ceil(65536 / kw), exact for kt < 8192)
-        const int kq = kt - kr * p.kw;
-        const int koff = (kr * p.W + kq) * p.x_cstride + kc;
-        const bool k_ok = kt < taps;
-        float* dst = smem + buf * BUF_FLOATS + lds_wave_base;
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const bool ok = k_ok && (unsigned)(a_iy0[i] + kr) < (unsigned)p.H && (unsigned)(a_ix0[i] + kq) < (unsigned)p.W;
-            unsigned long long src = reinterpret_cast<unsigned long long>(ok ? p.x + (a_off[i] + koff) : zero_page);
-            asm volatile("" : "+v"(src));    // one select, one DMA (keeps hipcc from forking the load into two exec-masked copies)
-            __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(dst + STEP * i * BK), 16, 0, 0);
-        }
-        const bool kb_ok = kb < p.K;
-#pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            unsigned long long src = reinterpret_cast<unsigned long long>((kb_ok && b_off[i] >= 0) ? p.w + b_off[i] : zero_page);
-            asm volatile("" : "+v"(src));
-            __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(dst + (BM + STEP * i) * BK), 16, 0, 0);
-            b_off[i] += b_off[i] >= 0 ? BK : 0;
-        }
+    int is_kr = 0, is_kq = 0, is_koff = 0;   // state shared by the pieces of one chunk's issue
+    bool is_kok = false, is_kbok = false;
+    float* is_dst = smem;
+    auto issue_pre = [&](const int buf) {
+        is_kr = (kt * p.kw_magic) >> 16;            // kt / kw (magic = ceil(65536 / kw), exact for kt < 8192)
+        is_kq = kt - is_kr * p.kw;
+        is_koff = (is_kr * p.W + is_kq) * p.x_cstride + kc;
+        is_kok = kt < taps;
+        is_kbok = kb < p.K;
+        is_dst = smem + buf * BUF_FLOATS + lds_wave_base;
+    };
+    auto issue_a = [&](const int i) {
+        // bitwise & on purpose: && becomes a divergent branch around the address arithmetic
+        const bool ok = (int)is_kok & (int)((unsigned)(a_iy0[i] + is_kr) < (unsigned)p.H) & (int)((unsigned)(a_ix0[i] + is_kq) < (unsigned)p.W);
+        unsigned long long src = reinterpret_cast<unsigned long long>(ok ? p.x + (a_off[i] + is_koff) : zero_page);
+        asm volatile("" : "+v"(src));    // one select, one DMA (keeps hipcc from forking the load into two exec-masked copies)
+        __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + STEP * i * BK), 16, 0, 0);
+    };
+    auto issue_b = [&](const int i) {
+        unsigned long long src = reinterpret_cast<unsigned long long>(((int)is_kbok & (int)(b_off[i] >= 0)) ? p.w + b_off[i] : zero_page);
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + (BM + STEP * i) * BK), 16, 0, 0);
+        b_off[i] += b_off[i] >= 0 ? BK : 0;
+    };
+    auto issue_post = [&]() {
         kb += BK;
         // advance by one chunk: BK = bk_taps * Cin + bk_rem
         kc += bk_rem;
@@ -218,6 +219,17 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         const bool wrap = kc >= p.Cin;
         kc -= wrap ? p.Cin : 0;
         kt += wrap ? 1 : 0;
+    };
+    // Issue the LDS-DMA of one chunk (INST x global_load_lds_dwordx4 per wave) into ring slot `buf`.  Every lane
+    // always loads: lanes outside the image / tile / K read the zero page, so padding arrives as zeros and the
+    // number of outstanding instructions per chunk is a constant the vmcnt waits can count on.
+    auto issue_chunk = [&](const int buf) {
+        issue_pre(buf);
+#pragma unroll
+        for (int i = 0; i < IA; ++i) issue_a(i);
+#pragma unroll
+        for (int i = 0; i < IB; ++i) issue_b(i);
+        issue_post();
     };
 
     f32x16 acc[WTM][WTN];
@@ -327,13 +339,41 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 wait_vmcnt<INST*(D - 1 - (PF ? 1 : 0))>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                issue_chunk(buf_issue);
-                buf_issue = next(buf_issue);
                 if (PF) {
-                    frags_landed(u & 1, 0, KS);                 // read one iteration ago: no stall
-                    read_frags((u + 1) & 1, next(buf_cur));     // in flight behind the MFMAs below
+                    // The wave has one instruction stream: address arithmetic, DMA issue and fragment reads placed in
+                    // front of the MFMAs would leave the matrix core idle meanwhile (with one wave per SIMD nobody
+                    // else feeds it).  The fragments of chunk c were read one iteration ago, so the MFMAs start right
+                    // after the barrier and everything else is issued in their shadow, one piece per MFMA group:
+                    // first the fragment reads of chunk c+1, then the DMA of chunk c+D.
+                    frags_landed(u & 1, 0, KS);
+                    const unsigned nslot = (unsigned)next(buf_cur) * (BUF_FLOATS * 4);
+                    constexpr int NG = KS * 4;                  // MFMA groups of WTM*WTN instructions
+                    constexpr int NP = KS + 1 + IA + IB + 1;    // pieces: reads, issue_pre, A loads, B loads, issue_post
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                            for (int j = 0; j < WTN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][g / 4][i][g % 4], bf[u & 1][g / 4][j][g % 4],
+                                                                                 acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = g * NP / NG; q < (g + 1) * NP / NG; ++q) {
+                            if (q < KS) read_step((u + 1) & 1, q, q, nslot);
+                            else if (q == KS) issue_pre(buf_issue);
+                            else if (q < KS + 1 + IA) issue_a(q - KS - 1);
+                            else if (q < KS + 1 + IA + IB) issue_b(q - KS - 1 - IA);
+                            else issue_post();
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    buf_issue = next(buf_issue);
+                } else {
+                    issue_chunk(buf_issue);
+                    buf_issue = next(buf_issue);
+                    mfma_chunk(u & 1, buf_cur);
                 }
-                mfma_chunk(u & 1, buf_cur);
                 buf_cur = next(buf_cur);
             }
         }
@@ -426,10 +466,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_one
     X(4, 1, 1, 2, 1, 2, 64, 4, true)   \
     X(5, 1, 1, 1, 1, 4, 64, 4, true)   \
     X(6, 1, 1, 2, 2, 1, 64, 4, true)   \
-    X(7, 1, 1, 1, 1, 4, 64, 6, true)
+    X(7, 1, 1, 1, 1, 4, 64, 6, true)   \
+    X(8, 1, 1, 1, 1, 8, 64, 4, true)   \
+    X(9, 1, 1, 2, 2, 2, 64, 4, true)   \
+    X(10, 1, 1, 2, 2, 2, 32, 4, true)  \
+    X(11, 2, 1, 2, 2, 2, 32, 4, true)  \
+    X(12, 1, 1, 2, 1, 4, 64, 4, true)  \
+    X(13, 2, 2, 2, 2, 2, 32, 3, false)
 
 struct TileCfg { int bm, bn, bk; bool prefetch; };
-constexpr int kNumCfg = 8;
+constexpr int kNumCfg = 14;
 constexpr TileCfg kCfgs[kNumCfg] = {
 #define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
     FCN_CONV_CONFIGS(X)
@@ -475,7 +521,7 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
 // costs about max(MFMA cycles, staged bytes / 12) plus a barrier; workgroups run in rounds over 256 CUs.
 int choose_cfg(const ConvP* ps, int n) {
     const char* force = getenv("FCN_CONV_CFG");
-    if (force && force[0] >= '0' && force[0] < '0' + kNumCfg) return force[0] - '0';
+    if (force && force[0] >= '0' && force[0] <= '9' && atoi(force) < kNumCfg) return atoi(force);
     int best = 0;
     double best_cost = 1e300;
     for (int c = 0; c < kNumCfg; ++c) {

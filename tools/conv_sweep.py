@@ -37,6 +37,9 @@ SHAPES = [
 ]
 
 
+CFGS = [int(c) for c in os.environ.get("SWEEP_CFGS", "").split(",") if c]
+
+
 def main():
     want = sys.argv[1:] or None
     L.call("fcn_init", 0)
@@ -64,7 +67,7 @@ def main():
         arr = (L.ConvDesc * len(descs))(*descs)
         ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(descs))), zero=False)
         line = "%-10s %6.3f GFLOP |" % (name, flops / 1e9)
-        for cfg in ["auto", "0", "1", "2", "3", "4", "5", "6", "7"]:
+        for cfg in ["auto"] + [str(i) for i in (CFGS or range(lib.fcn_conv2d_num_configs()))]:
             if cfg == "auto":
                 os.environ.pop("FCN_CONV_CFG", None)
             else:
