@@ -32,6 +32,7 @@
 // Several independent problems (the branches of an inception module) share ONE launch
 // (fcn_conv2d_fwd_group_f32).
 #include <mutex>
+#include <unordered_map>
 #include <type_traits>
 
 #include "common.h"
@@ -84,8 +85,23 @@ struct ConvP {
     float in_shift;   // unused by the kernel (kept so the struct mirrors fcn_conv_desc)
     int kw_magic;
     int M, K, tiles_m, tiles_n, tile_end;  // tile_end: exclusive prefix end of this problem's tiles in a group launch
+    unsigned ow_magic, oh_magic;          // ceil(2^32 / OW), ceil(2^32 / OH) when exact for every m < M, else 0 (= divide)
     const float* zero_page;               // 16 zero bytes in HBM: what out-of-image / out-of-tile lanes load
 };
+
+// A group launch carries its problems in the kernel arguments: a workgroup finds its problem with scalar
+// compares on the prefix table and ONE scalar load, instead of chasing a table in global memory (three or four
+// dependent L2 round trips in front of the first LDS-DMA of a kernel that only runs for ~10 us).
+constexpr int kMaxGroup = 8;
+struct GroupArgs {
+    int nprob;
+    int tile_end[kMaxGroup];
+    ConvP p[kMaxGroup];
+};
+
+__device__ __forceinline__ int fast_div(int m, unsigned magic, int d) {
+    return magic ? (int)__umulhi((unsigned)m, magic) : m / d;
+}
 
 
 template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
@@ -164,10 +180,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         const int m = m0 + STEP * i + lrow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int ox = mm % p.OW;
-        const int t = mm / p.OW;
-        const int oy = t % p.OH;
-        const int img = t / p.OH;
+        const int t = fast_div(mm, p.ow_magic, p.OW);
+        const int ox = mm - t * p.OW;
+        const int img = fast_div(t, p.oh_magic, p.OH);
+        const int oy = t - img * p.OH;
         a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);   // rows past M never pass the bounds test
         a_ix0[i] = ox * p.stride - p.pad;
         a_off[i] = ((img * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.x_cstride;
@@ -313,6 +329,14 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         }
     };
 
+    // the bias is needed only by the epilogue: fetch it now so that its latency is not exposed at the end
+    float bias_v[WTN];
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+        const int n = n0 + (wn * WTN + j) * 32 + (lane & 31);
+        bias_v[j] = p.bias ? *(const float __attribute__((address_space(1)))*)(p.bias + (n < p.Cout ? n : p.Cout - 1)) : 0.f;
+    }
+
     // ---- prologue: chunks 0 .. D-1 in flight (chunks past K are all-zero, so the counts below never change) ----
     int buf_issue = 0;                 // ring slot of the next chunk to issue
     auto next = [](int b) { return b + 1 == NBUF ? 0 : b + 1; };
@@ -419,7 +443,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     for (int j = 0; j < WTN; ++j) {
         const int n = n0 + (wn * WTN + j) * 32 + (lane & 31);
         if (n >= p.Cout) continue;
-        const float bv = p.bias ? *(const float __attribute__((address_space(1)))*)(p.bias + n) : 0.f;
+        const float bv = bias_v[j];
 #pragma unroll
         for (int i = 0; i < WTM; ++i) {
             const int mrow = m0 + (wm * WTM + i) * 32 + 4 * (lane >> 5);
@@ -440,13 +464,23 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 }
 
 template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const ConvP* __restrict__ probs, int nprob) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
-    int tile = blockIdx.x;
+    const int tile = blockIdx.x;
     int pi = 0, begin = 0;
-    while (pi + 1 < nprob && tile >= probs[pi].tile_end) { begin = probs[pi].tile_end; ++pi; }
-    const ConvP p = probs[pi];
-    conv_body<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(p, tile - begin, smem);
+#pragma unroll
+    for (int i = 0; i < kMaxGroup - 1; ++i) {      // tile_end is increasing: count the problems that end at or before this tile
+        const bool past = i + 1 < a.nprob && tile >= a.tile_end[i];
+        pi += past ? 1 : 0;
+        begin = past ? a.tile_end[i] : begin;
+    }
+    typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
+    karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    union { ConvP p; unsigned w[sizeof(ConvP) / 4]; } u;     // scalar loads from the kernarg segment at a scalar offset
+    const unsigned __attribute__((address_space(4)))* src = (const unsigned __attribute__((address_space(4)))*)&ka->p[pi];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(ConvP) / 4); ++i) u.w[i] = src[i];
+    conv_body<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(u.p, tile - begin, smem);
 }
 
 template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
@@ -513,6 +547,9 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
     p.K = d.kh * d.kw * d.Cin;
     p.tiles_m = p.tiles_n = p.tile_end = 0;
     p.kw_magic = (65536 + d.kw - 1) / d.kw;
+    // m / OW == umulhi(m, ceil(2^32 / OW)) for every m with m * OW < 2^32 (error term < OW per 2^32)
+    p.ow_magic = (d.OW > 1 && (long long)p.M * d.OW < (1ll << 32)) ? (unsigned)(((1ull << 32) + d.OW - 1) / d.OW) : 0u;
+    p.oh_magic = (d.OH > 1 && (long long)p.M * d.OH < (1ll << 32)) ? (unsigned)(((1ull << 32) + d.OH - 1) / d.OH) : 0u;
     p.zero_page = zero_page;
 }
 
@@ -570,16 +607,21 @@ void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
     }
 }
 
-void launch_group_cfg(int cfg, const ConvP* d_ps, int n, int total, hipStream_t st) {
+void launch_group_cfg(int cfg, const GroupArgs& ga, int total, hipStream_t st) {
     switch (cfg) {
-#define X(I, A, B, C_, D, E, F, G, H)                                                                                                    \
-    case I:                                                                                                                              \
-        hipLaunchKernelGGL((conv_fwd_group<A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, d_ps, n); \
+#define X(I, A, B, C_, D, E, F, G, H)                                                                                                  \
+    case I:                                                                                                                            \
+        hipLaunchKernelGGL((conv_fwd_group<A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, ga); \
         break;
         FCN_CONV_CONFIGS(X)
 #undef X
     }
 }
+
+// host copies of prepared groups, keyed by their device workspace (the launch needs the problems by value)
+struct HostGroup { int n; ConvP ps[16]; };
+std::mutex g_groups_mu;
+std::unordered_map<const void*, HostGroup> g_groups;
 
 }  // namespace
 
@@ -619,6 +661,12 @@ int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_worksp
     const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
     const int total = plan_tiles_cfg(cfg, ps, n);
     FCN_HIP(hipMemcpy(d_workspace, ps, sizeof(ConvP) * n, hipMemcpyHostToDevice));
+    {
+        std::lock_guard<std::mutex> lock(g_groups_mu);
+        HostGroup& hg = g_groups[d_workspace];
+        hg.n = n;
+        for (int i = 0; i < n; ++i) hg.ps[i] = ps[i];
+    }
     h_out->d_probs = d_workspace;
     h_out->n = n;
     h_out->cfg = cfg;
@@ -629,8 +677,26 @@ int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_worksp
 int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
     FCN_REQUIRE(g && g->d_probs && g->n > 0 && g->total_tiles > 0, FCN_E_ARG, "fcn_conv2d_fwd_group_f32: unprepared group");
     FCN_REQUIRE(g->cfg >= 0 && g->cfg < kNumCfg, FCN_E_ARG, "fcn_conv2d_fwd_group_f32: bad cfg %d", g->cfg);
-    launch_group_cfg(g->cfg, reinterpret_cast<const ConvP*>(g->d_probs), g->n, g->total_tiles, as_stream(s));
-    FCN_LAUNCH_CHECK("conv_fwd_group");
+    HostGroup hg;
+    {
+        std::lock_guard<std::mutex> lock(g_groups_mu);
+        auto it = g_groups.find(g->d_probs);
+        FCN_REQUIRE(it != g_groups.end() && it->second.n == g->n, FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared by this library instance");
+        hg = it->second;
+    }
+    // at most kMaxGroup problems ride in one launch's kernel arguments; larger groups take several launches
+    for (int first = 0; first < hg.n; first += kMaxGroup) {
+        GroupArgs ga;
+        ga.nprob = hg.n - first < kMaxGroup ? hg.n - first : kMaxGroup;
+        const int base = first ? hg.ps[first - 1].tile_end : 0;
+        for (int i = 0; i < kMaxGroup; ++i) {
+            const ConvP& src = hg.ps[first + (i < ga.nprob ? i : ga.nprob - 1)];
+            ga.p[i] = src;
+            ga.tile_end[i] = src.tile_end - base;
+        }
+        launch_group_cfg(g->cfg, ga, ga.tile_end[ga.nprob - 1], as_stream(s));
+        FCN_LAUNCH_CHECK("conv_fwd_group");
+    }
     return 0;
 }
 
