@@ -192,14 +192,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     if (do_bias && tid < WG_BN && n0 + tid < p.Cout) p.db_part[(size_t)split * p.Cout + n0 + tid] = bsum;
 }
 
-// out[i] = sum_s parts[s][i] in a fixed order
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t count,
-                                                              int splits) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+// out[i] = sum_s parts[s][i] in a FIXED order (bit-reproducible), but not a serial one: 16 lanes per output each
+// sum every 16th slab, then the 16 lane sums are added in lane order.  A serial loop over up to 256 slabs is a chain of
+// dependent-latency loads on a handful of workgroups (100+ us for the small layers); this tree keeps the loads in flight.
+constexpr int RED_LANES = 16;
+__global__ __launch_bounds__(64 * RED_LANES) void reduce_partials_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t count,
+                                                                         int splits) {
+    __shared__ float part[RED_LANES][64];
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * 64; base < count; base += (size_t)gridDim.x * 64) {
+        const size_t i = base + o;
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += parts[(size_t)k * count + i];
-        out[i] = s;
+        if (i < count) {
+#pragma unroll 4
+            for (int k = sl; k < splits; k += RED_LANES) s += parts[(size_t)k * count + i];
+        }
+        part[sl][o] = s;
+        __syncthreads();
+        if (sl == 0 && i < count) {
+            float t = part[0][o];
+#pragma unroll
+            for (int l = 1; l < RED_LANES; ++l) t += part[l][o];
+            out[i] = t;
+        }
+        __syncthreads();
     }
 }
 
@@ -441,8 +457,9 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     hipStream_t st = as_stream(s);
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.tiles_n * p.tiles_k * splits), dim3(256), 0, st, p);
     const size_t cnt = (size_t)p.Cout * p.K;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(stream_grid((long long)cnt, 256)), dim3(256), 0, st, p.dw_part, dw, cnt, splits);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, st, p.db_part, db, (size_t)p.Cout, splits);
+    const int red_blocks = (int)((cnt + 63) / 64 < 4096 ? (cnt + 63) / 64 : 4096);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(red_blocks), dim3(64 * RED_LANES), 0, st, p.dw_part, dw, cnt, splits);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.Cout, 64)), dim3(64 * RED_LANES), 0, st, p.db_part, db, (size_t)p.Cout, splits);
     FCN_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }

@@ -785,14 +785,14 @@ class Engine:
                     b.host_valid = False
             return float(ms.value)
 
-    def time_ops(self, reps: int = 20) -> List[Tuple[str, str, float, float, float]]:
+    def time_ops(self, reps: int = 20, ops: Optional[Sequence["Op"]] = None) -> List[Tuple[str, str, float, float, float]]:
         """Per-op HIP-event timing (ms) on the engine's stream: [(kind, name, ms, flops, bytes)]."""
         out = []
         with self.lock:
             e0, e1 = C.c_void_p(), C.c_void_p()
             L.call("fcn_event_create", C.byref(e0))
             L.call("fcn_event_create", C.byref(e1))
-            for op in self.ops:
+            for op in (self.ops if ops is None else ops):
                 op.run(self.stream)
                 L.call("fcn_event_record", e0, self.stream)
                 for _ in range(reps):

@@ -232,7 +232,15 @@ class TrainEngine(Engine):
                     dd.y_cstride, dd.y_coffset = gbot.cstride, gbot.coffset
                     dd.flags = L.CONV_ACCUM if state(gbot) == "full" else 0
                     self._keep.append(dd)
-                    ops.append(Op("dgrad", l.name, lambda st, dd=dd: L.check(lib.fcn_conv2d_fwd_f32(C.byref(dd), st)), flops))
+                    # the forward kernel on the flipped bank, as a one-problem group so that its tile shape is autotuned too
+                    arr = (L.ConvDesc * 1)(dd)
+                    gws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(1)), zero=False)
+                    grp = L.ConvGroup()
+                    cfg = self._tuned_cfg("dgrad:" + l.name, arr, 1, gws) if self.autotune else -1
+                    L.call("fcn_conv2d_group_prepare", arr, 1, gws.ptr, cfg, C.byref(grp))
+                    self._keep.extend([arr, gws, grp])
+                    ops.append(Op("dgrad", "%s [cfg%d %dwg]" % (l.name, grp.cfg, grp.total_tiles),
+                                  lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops))
                     mark(gbot)
                 continue
             gbot = G.get(l.bottoms[0]) if l.bottoms else None
