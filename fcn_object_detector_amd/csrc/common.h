@@ -40,11 +40,12 @@ const float* zero_page_for_current_device(int* rc);
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// grid for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8, no more
+// grid for HBM-bound grid-stride kernels: one work item per thread while that takes at most 64 Ki blocks (a grid only
+// slightly larger than the chip's resident capacity would otherwise run 1 vs 2 loop iterations per thread: a 2x tail)
 inline int stream_grid(long long work_items, int block) {
     long long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
-    if (g > 2048) g = 2048;
+    if (g > 65536) g = 8192;
     return (int)g;
 }
 

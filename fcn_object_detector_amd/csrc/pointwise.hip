@@ -142,6 +142,15 @@ __global__ __launch_bounds__(256) void avepool_kernel(const float* __restrict__ 
 // LRN across channels, local_size 5 fast path: one lane = 4 channels; the 5-wide window of those
 // 4 channels lives in the 12 floats c-4..c+7 of the same pixel (three 16-byte loads).
 // ---------------------------------------------------------------------------------------------
+// s^-beta; beta = 0.75 (every LRN of the reference nets) is two square roots and a reciprocal instead of powf
+__device__ __forceinline__ float pow_neg_beta(float s, float beta) {
+    if (beta == 0.75f) {
+        const float r = sqrtf(s);
+        return 1.f / (r * sqrtf(r));
+    }
+    return powf(s, -beta);
+}
+
 __global__ __launch_bounds__(256) void lrn5_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ scale,
                                                    long long pixels, int C, int x_cstride, int y_cstride, float alpha_over_n,
                                                    float beta, float kk) {
@@ -162,10 +171,10 @@ __global__ __launch_bounds__(256) void lrn5_kernel(const float* __restrict__ x, 
         s.z = kk + alpha_over_n * (q[4] + q[5] + q[6] + q[7] + q[8]);
         s.w = kk + alpha_over_n * (q[5] + q[6] + q[7] + q[8] + q[9]);
         float4 o;
-        o.x = c.x * powf(s.x, -beta);
-        o.y = c.y * powf(s.y, -beta);
-        o.z = c.z * powf(s.z, -beta);
-        o.w = c.w * powf(s.w, -beta);
+        o.x = c.x * pow_neg_beta(s.x, beta);
+        o.y = c.y * pow_neg_beta(s.y, beta);
+        o.z = c.z * pow_neg_beta(s.z, beta);
+        o.w = c.w * pow_neg_beta(s.w, beta);
         st4(y + (size_t)pix * y_cstride + g * 4, o);
         if (scale) st4(scale + (size_t)pix * C + g * 4, s);
     }

@@ -288,6 +288,39 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// same, 4 channels (16 bytes) per lane: the shapes of the reference nets always allow it
+__global__ __launch_bounds__(256) void maxpool_bwd_v4_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx, float* __restrict__ dx,
+                                                             int N, int H, int W, int C, int dx_cstride, int dx_coffset, int k, int stride,
+                                                             int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate) {
+    const unsigned C4 = (unsigned)C >> 2;
+    const unsigned total = (unsigned)N * H * W * C4;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const unsigned pix = t / C4;
+        const int c = (int)(t - pix * C4) * 4;
+        const unsigned row = pix / (unsigned)W;
+        const int ix = (int)(pix - row * (unsigned)W);
+        const int n = (int)(row / (unsigned)H);
+        const int iy = (int)(row - (unsigned)n * (unsigned)H);
+        const int oy_lo = max(0, (iy + pad - k + stride) / stride), oy_hi = min(OH - 1, (iy + pad) / stride);
+        const int ox_lo = max(0, (ix + pad - k + stride) / stride), ox_hi = min(OW - 1, (ix + pad) / stride);
+        const int me = iy * W + ix;
+        v4f g = {0.f, 0.f, 0.f, 0.f};
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const size_t o = ((size_t)(n * OH + oy) * OW + ox);
+                const int4 id = *reinterpret_cast<const int4*>(idx + o * C + c);
+                const v4f d = *reinterpret_cast<const v4f*>(dy + o * dy_cstride + dy_coffset + c);
+                g[0] += id.x == me ? d[0] : 0.f;
+                g[1] += id.y == me ? d[1] : 0.f;
+                g[2] += id.z == me ? d[2] : 0.f;
+                g[3] += id.w == me ? d[3] : 0.f;
+            }
+        v4f* dst = reinterpret_cast<v4f*>(dx + (size_t)pix * dx_cstride + dx_coffset + c);
+        if (accumulate) g += *dst;
+        *dst = g;
+    }
+}
+
 // LRN backward: dX = dY*scale^-beta - (2 alpha beta / n) * X * sum_{window} (dY * Y / scale)
 __global__ __launch_bounds__(256) void lrn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ scale,
                                                       const float* __restrict__ dy, float* __restrict__ dx, long long pixels, int C,
@@ -307,6 +340,46 @@ __global__ __launch_bounds__(256) void lrn_bwd_kernel(const float* __restrict__ 
         const float g = dyp[c] * powf(sp[c], -beta) - ratio2ab * x[(size_t)pix * x_cstride + c] * acc;
         float* d = dx + (size_t)pix * x_cstride + c;
         *d = accumulate ? *d + g : g;
+    }
+}
+
+// local_size 5 fast path: one lane = 4 channels, the window terms dY*Y/scale of channels c-4..c+7 come from three
+// 16-byte loads per operand (same layout trick as the forward lrn5 kernel)
+__global__ __launch_bounds__(256) void lrn5_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ dy, float* __restrict__ dx, long long pixels, int C,
+                                                       int x_cstride, int y_cstride, float ratio2ab, float beta, int accumulate) {
+    const int cg = C / 4;
+    const long long total = pixels * cg;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long pix = t / cg;
+        const int g = (int)(t - pix * cg);
+        const float* yp = y + (size_t)pix * y_cstride + g * 4;
+        const float* dyp = dy + (size_t)pix * y_cstride + g * 4;
+        const float* sp = scale + (size_t)pix * C + g * 4;
+        const bool hl = g > 0, hr = g + 1 < cg;
+        const v4f yc = *(const v4f*)yp, dc = *(const v4f*)dyp, sc = *(const v4f*)sp;
+        const v4f qc = dc * yc / sc;
+        const v4f ql = hl ? *(const v4f*)(dyp - 4) * *(const v4f*)(yp - 4) / *(const v4f*)(sp - 4) : zero;
+        const v4f qr = hr ? *(const v4f*)(dyp + 4) * *(const v4f*)(yp + 4) / *(const v4f*)(sp + 4) : zero;
+        const float q[12] = {ql[0], ql[1], ql[2], ql[3], qc[0], qc[1], qc[2], qc[3], qr[0], qr[1], qr[2], qr[3]};
+        const v4f xc = *(const v4f*)(x + (size_t)pix * x_cstride + g * 4);
+        v4f o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float acc = q[i + 2] + q[i + 3] + q[i + 4] + q[i + 5] + q[i + 6];     // channels c-2 .. c+2, ascending like the generic kernel
+            float p75;
+            if (beta == 0.75f) {
+                const float r = sqrtf(sc[i]);
+                p75 = 1.f / (r * sqrtf(r));
+            } else {
+                p75 = powf(sc[i], -beta);
+            }
+            o[i] = dc[i] * p75 - ratio2ab * xc[i] * acc;
+        }
+        v4f* d = (v4f*)(dx + (size_t)pix * x_cstride + g * 4);
+        if (accumulate) o += *d;
+        *d = o;
     }
 }
 
@@ -496,8 +569,14 @@ int fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, i
                         int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, fcn_stream_t s) {
     FCN_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && OH > 0 && OW > 0, FCN_E_ARG, "maxpool_bwd: bad args");
     FCN_REQUIRE(dx_cstride >= dx_coffset + C && dy_cstride >= dy_coffset + C, FCN_E_ARG, "maxpool_bwd: channel slice out of range");
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((long long)N * H * W * C, 256)), dim3(256), 0, as_stream(s), dy, idx, dx, N, H, W, C,
-                       dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate);
+    const bool v4 = C % 4 == 0 && dx_cstride % 4 == 0 && dx_coffset % 4 == 0 && dy_cstride % 4 == 0 && dy_coffset % 4 == 0 &&
+                    (long long)N * H * W * (C / 4) < (1ll << 31) && (((uintptr_t)dy | (uintptr_t)idx | (uintptr_t)dx) & 15) == 0;
+    if (v4)
+        hipLaunchKernelGGL(maxpool_bwd_v4_kernel, dim3(stream_grid((long long)N * H * W * (C / 4), 256)), dim3(256), 0, as_stream(s), dy, idx, dx, N, H,
+                           W, C, dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((long long)N * H * W * C, 256)), dim3(256), 0, as_stream(s), dy, idx, dx, N, H, W, C,
+                           dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate);
     FCN_LAUNCH_CHECK("maxpool_bwd");
     return 0;
 }
@@ -505,8 +584,14 @@ int fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, i
 int fcn_lrn_bwd_f32(const float* x, const float* y, const float* scale, const float* dy, float* dx, int pixels, int C, int x_cstride,
                     int y_cstride, int local_size, float alpha, float beta, int accumulate, fcn_stream_t s) {
     FCN_REQUIRE(x && y && scale && dy && dx && pixels > 0 && C > 0 && local_size > 0, FCN_E_ARG, "lrn_bwd: bad args");
-    hipLaunchKernelGGL(lrn_bwd_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, as_stream(s), x, y, scale, dy, dx,
-                       (long long)pixels, C, x_cstride, y_cstride, local_size, 2.f * alpha * beta / (float)local_size, beta, accumulate);
+    const bool fast = local_size == 5 && C % 4 == 0 && x_cstride % 4 == 0 && y_cstride % 4 == 0 &&
+                      (((uintptr_t)x | (uintptr_t)y | (uintptr_t)scale | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0;
+    if (fast)
+        hipLaunchKernelGGL(lrn5_bwd_kernel, dim3(stream_grid((long long)pixels * (C / 4), 256)), dim3(256), 0, as_stream(s), x, y, scale, dy, dx,
+                           (long long)pixels, C, x_cstride, y_cstride, 2.f * alpha * beta / (float)local_size, beta, accumulate);
+    else
+        hipLaunchKernelGGL(lrn_bwd_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, as_stream(s), x, y, scale, dy, dx,
+                           (long long)pixels, C, x_cstride, y_cstride, local_size, 2.f * alpha * beta / (float)local_size, beta, accumulate);
     FCN_LAUNCH_CHECK("lrn_bwd");
     return 0;
 }

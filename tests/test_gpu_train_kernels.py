@@ -90,35 +90,40 @@ def test_relu_sigmoid_bwd(gpu):
     assert np.allclose(dev_to(od, (300,)), 1 + R.sigmoid_backward(sg, g), rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("c,cs_dy,co_dy,cs_dx,co_dx", [(8, 16, 8, 12, 4), (6, 9, 2, 7, 1)])     # 16-byte lanes / scalar fallback
 @pytest.mark.parametrize("k,s,p,h,w", [(3, 2, 0, 15, 14), (3, 1, 1, 9, 7), (2, 2, 0, 8, 6), (3, 2, 0, 28, 28)])
-def test_maxpool_bwd(gpu, k, s, p, h, w):
+def test_maxpool_bwd(gpu, k, s, p, h, w, c, cs_dy, co_dy, cs_dx, co_dx):
     rng = np.random.default_rng(2)
-    x = rng.standard_normal((2, 8, h, w)).astype(np.float32)
+    x = rng.standard_normal((2, c, h, w)).astype(np.float32)
     x[0, :, 1, 1] = x[0, :, 1, 2]                                        # ties
     y, idx = R.max_pool(x, k, s, p, return_index=True)
     oh, ow = y.shape[2:]
     dy = rng.standard_normal(y.shape).astype(np.float32)
     ref = R.max_pool_backward(dy, idx, x.shape)
-    dyd = dev_from(nhwc(dy, 16, 8))
+    dyd = dev_from(nhwc(dy, cs_dy, co_dy))
     idd = dev_from(np.ascontiguousarray(idx.transpose(0, 2, 3, 1)).astype(np.int32))
     base = rng.standard_normal(x.shape).astype(np.float32)
-    dxd = dev_from(nhwc(base, 12, 4))
-    L.call("fcn_maxpool_bwd_f32", dyd.ptr, idd.ptr, dxd.ptr, 2, h, w, 8, 12, 4, k, s, p, oh, ow, 16, 8, 1, None)
-    assert np.allclose(nchw(dev_to(dxd, (2, h, w, 12)), 8, 4), base + ref, rtol=1e-6, atol=1e-6)
-    L.call("fcn_maxpool_bwd_f32", dyd.ptr, idd.ptr, dxd.ptr, 2, h, w, 8, 12, 4, k, s, p, oh, ow, 16, 8, 0, None)
-    assert np.allclose(nchw(dev_to(dxd, (2, h, w, 12)), 8, 4), ref, rtol=1e-6, atol=1e-6)
+    dxd = dev_from(nhwc(base, cs_dx, co_dx))
+    L.call("fcn_maxpool_bwd_f32", dyd.ptr, idd.ptr, dxd.ptr, 2, h, w, c, cs_dx, co_dx, k, s, p, oh, ow, cs_dy, co_dy, 1, None)
+    assert np.allclose(nchw(dev_to(dxd, (2, h, w, cs_dx)), c, co_dx), base + ref, rtol=1e-6, atol=1e-6)
+    L.call("fcn_maxpool_bwd_f32", dyd.ptr, idd.ptr, dxd.ptr, 2, h, w, c, cs_dx, co_dx, k, s, p, oh, ow, cs_dy, co_dy, 0, None)
+    assert np.allclose(nchw(dev_to(dxd, (2, h, w, cs_dx)), c, co_dx), ref, rtol=1e-6, atol=1e-6)
 
 
-def test_lrn_bwd(gpu):
+@pytest.mark.parametrize("c,ls,beta", [(64, 5, 0.75), (64, 5, 0.6), (6, 3, 0.75), (10, 5, 0.75)])   # 16-byte fast path / generic kernel
+def test_lrn_bwd(gpu, c, ls, beta):
     rng = np.random.default_rng(3)
-    x = (rng.standard_normal((2, 64, 4, 5)) * 20).astype(np.float32)
-    y, scale = R.lrn_across(x, 5, 1e-4, 0.75, 1.0, return_scale=True)
+    x = (rng.standard_normal((2, c, 4, 5)) * 20).astype(np.float32)
+    y, scale = R.lrn_across(x, ls, 1e-4, beta, 1.0, return_scale=True)
     dy = rng.standard_normal(x.shape).astype(np.float32)
-    ref = R.lrn_across_backward(x, y, scale, dy, 5, 1e-4, 0.75)
+    ref = R.lrn_across_backward(x, y, scale, dy, ls, 1e-4, beta)
     xd, yd, sd, dyd = dev_from(nhwc(x)), dev_from(nhwc(y)), dev_from(nhwc(scale)), dev_from(nhwc(dy))
-    dxd = dev_from(np.zeros((2, 4, 5, 64), np.float32))
-    L.call("fcn_lrn_bwd_f32", xd.ptr, yd.ptr, sd.ptr, dyd.ptr, dxd.ptr, 40, 64, 64, 64, 5, 1e-4, 0.75, 0, None)
-    assert rel_err(nchw(dev_to(dxd, (2, 4, 5, 64)), 64), ref) < 1e-5
+    base = rng.standard_normal((2, 4, 5, c)).astype(np.float32)
+    dxd = dev_from(base)
+    L.call("fcn_lrn_bwd_f32", xd.ptr, yd.ptr, sd.ptr, dyd.ptr, dxd.ptr, 40, c, c, c, ls, 1e-4, beta, 0, None)
+    assert rel_err(nchw(dev_to(dxd, (2, 4, 5, c)), c), ref) < 1e-5
+    L.call("fcn_lrn_bwd_f32", xd.ptr, yd.ptr, sd.ptr, dyd.ptr, dxd.ptr, 40, c, c, c, ls, 1e-4, beta, 1, None)
+    assert rel_err(nchw(dev_to(dxd, (2, 4, 5, c)), c), 2 * ref) < 1e-5
 
 
 def test_dropout_mask_is_the_oracle_mask(gpu):
