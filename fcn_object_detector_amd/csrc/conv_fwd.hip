@@ -506,10 +506,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_one
     X(10, 1, 1, 2, 2, 2, 32, 4, true)  \
     X(11, 2, 1, 2, 2, 2, 32, 4, true)  \
     X(12, 1, 1, 2, 1, 4, 64, 4, true)  \
-    X(13, 2, 2, 2, 2, 2, 32, 3, false)
+    X(13, 2, 2, 2, 2, 2, 32, 3, false) \
+    X(14, 1, 1, 2, 2, 1, 32, 3, false) \
+    X(15, 2, 1, 2, 2, 1, 32, 3, false) \
+    X(16, 1, 2, 2, 2, 1, 32, 3, false)
 
 struct TileCfg { int bm, bn, bk; bool prefetch; };
-constexpr int kNumCfg = 14;
+constexpr int kNumCfg = 17;
 constexpr TileCfg kCfgs[kNumCfg] = {
 #define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
     FCN_CONV_CONFIGS(X)

@@ -53,35 +53,52 @@ struct WgradP {
 };
 
 constexpr int WG_BP = 32;      // pixels per chunk
-constexpr int WG_BN = 64;      // output channels per workgroup
-constexpr int WG_BK = 64;      // weight k-indices per workgroup
-constexpr int WG_NBUF = 4;
-constexpr int WG_BUF_FLOATS = WG_BP * (WG_BN + WG_BK);
 
-// 256 threads = 4 waves as 2 (cout) x 2 (k); each wave owns a 32x32 tile of dW.
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
-    __shared__ __attribute__((aligned(16))) float smem[WG_NBUF * WG_BUF_FLOATS];
+// Tile shapes of the dW GEMM.  A workgroup owns BN output channels x BK weight k-indices with WAVES_N x WAVES_K
+// waves, each wave TN x TK 32x32 MFMA tiles.  Measured on MI355X (tools/wgrad_sweep.py): what pays is the number of
+// workgroups RESIDENT per CU (each wave has one instruction stream, so loads, LDS reads and MFMAs of one workgroup
+// serialise and only another workgroup's waves fill the matrix core meanwhile) - a 3-slot ring (48-72 KiB of LDS)
+// beats both deeper rings and larger tiles that leave one workgroup per CU.
+template <int TN, int TK, int WAVES_N, int WAVES_K, int NBUF>
+struct WgCfg {
+    static constexpr int BN = 32 * TN * WAVES_N, BK = 32 * TK * WAVES_K;
+    static constexpr int NW = WAVES_N * WAVES_K, NT = 64 * NW;
+    static constexpr int RN = 256 / BN, RK = 256 / BK;          // pixel rows one 1 KiB LDS-DMA instruction covers
+    static constexpr int IN_ = WG_BP / RN / NW, IK = WG_BP / RK / NW;   // instructions per wave per chunk (dY rows, im2col rows)
+    static constexpr int INST = IN_ + IK;
+    static constexpr int BUF_FLOATS = WG_BP * (BN + BK);
+    static_assert(BN <= 256 && BK <= 256 && (WG_BP / RN) % NW == 0 && (WG_BP / RK) % NW == 0, "rows must split into whole wave-instructions");
+    static_assert(NBUF >= 3 && NBUF * BUF_FLOATS * 4 <= 160 * 1024, "exceeds the CU's 160 KiB LDS");
+    static_assert(INST * (NBUF - 2) <= 63, "vmcnt is a 6-bit counter");
+};
+
+template <int TN, int TK, int WAVES_N, int WAVES_K, int NBUF>
+__global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_kernel(WgradP p) {
+    constexpr int WG_NBUF = NBUF;
+    using C = WgCfg<TN, TK, WAVES_N, WAVES_K, NBUF>;
+    constexpr int BN = C::BN, BK = C::BK, NW = C::NW, RN = C::RN, RK = C::RK, IN_ = C::IN_, IK = C::IK, INST = C::INST;
+    constexpr int BUF_FLOATS = C::BUF_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[WG_NBUF * BUF_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wid >> 1, wkk = wid & 1;
+    const int wn = wid / WAVES_K, wkk = wid % WAVES_K;
 
     int b = blockIdx.x;
     const int split = b % p.splits;
     b /= p.splits;
     const int tile_k = b % p.tiles_k;
     const int tile_n = b / p.tiles_k;
-    const int n0 = tile_n * WG_BN;
-    const int k0 = tile_k * WG_BK;
+    const int n0 = tile_n * BN;
+    const int k0 = tile_k * BK;
 
-    // ---- loader: one LDS-DMA instruction = 1 KiB = 4 pixel rows x 64 floats; 4 waves x 2 instructions cover the
-    //      32 x 64 dY tile, another 2 per wave the 32 x 64 im2col tile.  Lane -> (row = lane / 16, slot = lane % 16).
-    const int lrow = lane >> 4, lslot = lane & 15;
-    // dY source column (fixed for the kernel)
-    const int dy_col = n0 + lslot * 4;
+    // ---- loader: one LDS-DMA instruction = 1 KiB = RN pixel rows of BN floats (dY) or RK rows of BK floats (im2col);
+    //      lane -> (row = lane / (B/4), 16-byte slot = lane % (B/4)).  Source column / k index are fixed per lane.
+    const int n_row = lane / (BN / 4), n_slot = lane % (BN / 4);
+    const int k_row = lane / (BK / 4), k_slot = lane % (BK / 4);
+    const int dy_col = n0 + n_slot * 4;
     const bool dy_col_ok = dy_col < p.Cout;          // Cout is padded to 4 in the gradient buffer (cstride), columns past it read zeros
-    // im2col source: k index of this lane's segment -> (tap, channel), fixed for the kernel
-    const int kidx = k0 + lslot * 4;
+    const int kidx = k0 + k_slot * 4;
     const int ktap = kidx / p.Cin;
     const int kch = kidx - ktap * p.Cin;
     const int kr = (ktap * p.kw_magic) >> 16;
@@ -96,45 +113,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
     int nchunks = total_chunks - chunk0;
     if (nchunks > p.chunks_per_split) nchunks = p.chunks_per_split;
     if (nchunks < 0) nchunks = 0;
+    const int chunk_end = chunk0 + nchunks;
     const int ohw = p.OH * p.OW;
 
     int issue_chunk_idx = chunk0;
+    float* is_dst = smem;
+    auto issue_pre = [&](const int buf) { is_dst = smem + buf * BUF_FLOATS; };
+    auto issue_n = [&](const int i) {          // dY[m][n0 + 4*slot ..]
+        const int row = RN * (NW * i + wid) + n_row;
+        const int m = issue_chunk_idx * WG_BP + row;
+        const bool ok = (int)(m < p.M) & (int)(issue_chunk_idx < chunk_end) & (int)dy_col_ok;
+        unsigned long long src = reinterpret_cast<unsigned long long>(ok ? p.dy + (size_t)m * p.dy_cstride + dy_col : zero_page);
+        asm volatile("" : "+v"(src));
+        __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + RN * (NW * i + wid) * BN), 16, 0, 0);
+    };
+    auto issue_k = [&](const int i) {          // im2col row m, k segment
+        const int row = RK * (NW * i + wid) + k_row;
+        const int m = issue_chunk_idx * WG_BP + row;
+        const bool m_ok = (int)(m < p.M) & (int)(issue_chunk_idx < chunk_end);
+        const int mm = m_ok ? m : 0;
+        const int img = (int)__umulhi((unsigned)mm, p.ohw_magic);
+        const int rem = mm - img * ohw;
+        const int oy = (int)__umulhi((unsigned)rem, p.ow_magic);
+        const int ox = rem - oy * p.OW;
+        const int iy = oy * p.stride - p.pad + kr;
+        const int ix = ox * p.stride - p.pad + kq;
+        const bool ok = (int)m_ok & (int)k_ok & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
+        unsigned long long srcx = reinterpret_cast<unsigned long long>(
+            ok ? p.x + ((size_t)(img * p.H + iy) * p.W + ix) * p.x_cstride + kch : zero_page);
+        asm volatile("" : "+v"(srcx));
+        __builtin_amdgcn_global_load_lds((gvoid_cptr)srcx, (lds_ptr)(is_dst + WG_BP * BN + RK * (NW * i + wid) * BK), 16, 0, 0);
+    };
     auto issue_chunk = [&](const int buf) {
-        float* dst = smem + buf * WG_BUF_FLOATS;
+        issue_pre(buf);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = 16 * i + 4 * wid + lrow;            // pixel row inside the chunk
-            const int m = issue_chunk_idx * WG_BP + row;
-            const bool m_ok = m < p.M && issue_chunk_idx < chunk0 + nchunks;
-            // dY[m][n0 + 4*slot ..]
-            unsigned long long src = reinterpret_cast<unsigned long long>((m_ok && dy_col_ok) ? p.dy + (size_t)m * p.dy_cstride + dy_col : zero_page);
-            asm volatile("" : "+v"(src));
-            __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(dst + (16 * i + 4 * wid) * WG_BN), 16, 0, 0);
-            // im2col row m, k segment
-            const int mm = m_ok ? m : 0;
-            const int img = (int)__umulhi((unsigned)mm, p.ohw_magic);
-            const int rem = mm - img * ohw;
-            const int oy = (int)__umulhi((unsigned)rem, p.ow_magic);
-            const int ox = rem - oy * p.OW;
-            const int iy = oy * p.stride - p.pad + kr;
-            const int ix = ox * p.stride - p.pad + kq;
-            const bool ok = m_ok && k_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            unsigned long long srcx = reinterpret_cast<unsigned long long>(
-                ok ? p.x + ((size_t)(img * p.H + iy) * p.W + ix) * p.x_cstride + kch : zero_page);
-            asm volatile("" : "+v"(srcx));
-            __builtin_amdgcn_global_load_lds((gvoid_cptr)srcx, (lds_ptr)(dst + WG_BP * WG_BN + (16 * i + 4 * wid) * WG_BK), 16, 0, 0);
-        }
+        for (int i = 0; i < IN_; ++i) issue_n(i);
+#pragma unroll
+        for (int i = 0; i < IK; ++i) issue_k(i);
         ++issue_chunk_idx;
     };
 
-    f32x16 acc;
+    f32x16 acc[TN][TK];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float bsum = 0.f;   // bias gradient partial of channel n0 + tid (threads 0..63 of the k-tile-0 workgroups)
-    const bool do_bias = p.db_part != nullptr && tile_k == 0;
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum = 0.f;   // bias gradient partial of channel n0 + tid (threads 0..BN-1 of the k-tile-0 workgroups)
+    const bool do_bias = p.db_part != nullptr && tile_k == 0 && tid < BN;
 
     constexpr int D = WG_NBUF - 1;
-    constexpr int INST = 4;     // LDS-DMA instructions per wave per chunk
     int buf_issue = 0, buf_cur = 0;
     auto next = [](int v) { return v + 1 == WG_NBUF ? 0 : v + 1; };
 #pragma unroll
@@ -142,55 +171,103 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradP p) {
         issue_chunk(buf_issue);
         buf_issue = next(buf_issue);
     }
+    // fragment addresses: lane (i = lane & 31, p = lane >> 5) of MFMA step s reads element i of pixel row 2s + p
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
-    const unsigned a_addr = lds0 + 4u * ((lane >> 5) * WG_BN + wn * 32 + (lane & 31));
-    const unsigned b_addr = lds0 + 4u * (WG_BP * WG_BN + (lane >> 5) * WG_BK + wkk * 32 + (lane & 31));
+    const unsigned a_addr = lds0 + 4u * ((lane >> 5) * BN + wn * TN * 32 + (lane & 31));
+    const unsigned b_addr = lds0 + 4u * (WG_BP * BN + (lane >> 5) * BK + wkk * TK * 32 + (lane & 31));
+    const unsigned bias_addr = lds0 + 4u * (unsigned)(tid < BN ? tid : 0);
 
-    for (int c = 0; c < nchunks; ++c) {
-        wait_vmcnt<INST*(D - 1)>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue_chunk(buf_issue);
-        buf_issue = next(buf_issue);
-        const unsigned slot = (unsigned)buf_cur * (WG_BUF_FLOATS * 4);
-        float av[16], bv[16];
+    // fragments of a whole chunk (16 MFMA steps of 2 pixels), read with inline asm: hipcc cannot tell an LDS-DMA in
+    // flight from a slot that landed long ago and would drain vmcnt in front of compiler-generated LDS reads
+    float av[1][16][TN], bv[1][16][TK];
+    auto read_step = [&](const int par, const int st, const unsigned slot) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {       // pixel pair s: rows 2s, 2s+1
-            asm volatile("ds_read_b32 %0, %1" : "=v"(av[s]) : "v"(a_addr + slot + 4u * (2 * s * WG_BN)));
-            asm volatile("ds_read_b32 %0, %1" : "=v"(bv[s]) : "v"(b_addr + slot + 4u * (2 * s * WG_BK)));
-        }
+        for (int i = 0; i < TN; ++i)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(av[par][st][i]) : "v"(a_addr + slot + 4u * (2 * st * BN + 32 * i)));
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+            asm volatile("ds_read_b32 %0, %1" : "=v"(bv[par][st][j]) : "v"(b_addr + slot + 4u * (2 * st * BK + 32 * j)));
+    };
+    auto landed = [&](const int par) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            asm volatile("" : "+v"(av[s]));
-            asm volatile("" : "+v"(bv[s]));
+        for (int st = 0; st < 16; ++st) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) asm volatile("" : "+v"(av[par][st][i]));
+#pragma unroll
+            for (int j = 0; j < TK; ++j) asm volatile("" : "+v"(bv[par][st][j]));
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+
+    {
+        // plain order: refill the ring, read the whole chunk's fragments, multiply.  With two workgroups resident per CU
+        // (small tiles, 64 KiB of LDS each) the other workgroup's waves fill the matrix core meanwhile.
+        for (int c = 0; c < nchunks; ++c) {
+            wait_vmcnt<INST*(D - 1)>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_chunk(buf_issue);
+            buf_issue = next(buf_issue);
+            const unsigned slot = (unsigned)buf_cur * (BUF_FLOATS * 4);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
-        if (do_bias && tid < WG_BN) {
-            const float* col = smem + buf_cur * WG_BUF_FLOATS + tid;
-            float t = 0.f;
+            for (int st = 0; st < 16; ++st) read_step(0, st, slot);
+            landed(0);
 #pragma unroll
-            for (int r = 0; r < WG_BP; ++r) t += col[r * WG_BN];
-            bsum += t;
+            for (int st = 0; st < 16; ++st)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][st][i], bv[0][st][j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+                float t = 0.f;
+#pragma unroll
+                for (int r0 = 0; r0 < WG_BP; r0 += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) asm volatile("ds_read_b32 %0, %1" : "=v"(v[r]) : "v"(bias_addr + slot + 4u * ((r0 + r) * BN)));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        asm volatile("" : "+v"(v[r]));
+                        t += v[r];
+                    }
+                }
+                bsum += t;
+            }
+            buf_cur = next(buf_cur);
         }
-        buf_cur = next(buf_cur);
     }
     wait_vmcnt<0>();
 
     // dW partial slab [split][cout][k]: C/D map col = lane & 31 (k), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
     float* slab = p.dw_part + (size_t)split * p.Cout * p.K;
-    const int kcol = k0 + wkk * 32 + (lane & 31);
-    if (kcol < p.K) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (n < p.Cout) *(gf_ptr)(slab + (size_t)n * p.K + kcol) = acc[r];
+    for (int j = 0; j < TK; ++j) {
+        const int kcol = k0 + (wkk * TK + j) * 32 + (lane & 31);
+        if (kcol >= p.K) continue;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (wn * TN + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (n < p.Cout) *(gf_ptr)(slab + (size_t)n * p.K + kcol) = acc[i][j][r];
+            }
         }
     }
-    if (do_bias && tid < WG_BN && n0 + tid < p.Cout) p.db_part[(size_t)split * p.Cout + n0 + tid] = bsum;
+    if (do_bias && n0 + tid < p.Cout) p.db_part[(size_t)split * p.Cout + n0 + tid] = bsum;
 }
+
+// tile shapes: X(index, TN, TK, WAVES_N, WAVES_K)
+#define FCN_WGRAD_CONFIGS(X) \
+    X(0, 1, 1, 2, 2, 3)      \
+    X(1, 1, 2, 2, 2, 3)      \
+    X(2, 2, 1, 2, 2, 3)      \
+    X(3, 1, 1, 2, 2, 4)
+struct WgShape { int bn, bk, nw; double eff; };   // eff: sustained fraction of the MFMA rate seen in the sweep (ranking only)
+constexpr int kNumWgCfg = 4;
+constexpr WgShape kWgShapes[kNumWgCfg] = {{64, 64, 4, 0.55}, {64, 128, 4, 0.50}, {128, 64, 4, 0.60}, {64, 64, 4, 0.50}};
 
 // out[i] = sum_s parts[s][i] in a FIXED order (bit-reproducible), but not a serial one: 16 lanes per output each
 // sum every 16th slab, then the 16 lane sums are added in lane order.  A serial loop over up to 256 slabs is a chain of
@@ -478,15 +555,36 @@ unsigned magic32(unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((0x10000
 
 extern "C" {
 
-size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* d, int* h_splits) {
-    if (!d || d->Cout <= 0) return 0;
+// tile shape with the least padded work per unit of sustained rate, then enough pixel splits to fill the chip
+static void plan_wgrad(const fcn_conv_desc* d, int* cfg_out, int* splits_out) {
     const long long M = (long long)d->N * d->OH * d->OW, K = (long long)d->kh * d->kw * d->Cin;
-    const int tiles = cdiv(d->Cout, WG_BN) * cdiv(K, WG_BK);
+    int best = 0;
+    const char* force = getenv("FCN_WGRAD_CFG");
+    if (force && force[0] >= '0' && force[0] < '0' + kNumWgCfg) {
+        best = force[0] - '0';
+    } else {
+        double best_cost = 1e300;
+        for (int c = 0; c < kNumWgCfg; ++c) {
+            const double padded = (double)cdiv(d->Cout, kWgShapes[c].bn) * kWgShapes[c].bn * cdiv(K, kWgShapes[c].bk) * kWgShapes[c].bk;
+            const double cost = padded / kWgShapes[c].eff;
+            if (cost < best_cost) { best_cost = cost; best = c; }
+        }
+    }
+    const int tiles = cdiv(d->Cout, kWgShapes[best].bn) * cdiv(K, kWgShapes[best].bk);
     const int chunks = cdiv(M, WG_BP);
-    int splits = cdiv(1024, tiles);
+    int splits = cdiv(kWgShapes[best].nw == 8 ? 512 : 1024, tiles);
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
     if (splits > 256) splits = 256;
+    *cfg_out = best;
+    *splits_out = splits;
+}
+
+size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* d, int* h_splits) {
+    if (!d || d->Cout <= 0) return 0;
+    const long long K = (long long)d->kh * d->kw * d->Cin;
+    int cfg = 0, splits = 1;
+    plan_wgrad(d, &cfg, &splits);
     if (h_splits) *h_splits = splits;
     return (size_t)splits * ((size_t)d->Cout * K + d->Cout);
 }
@@ -507,8 +605,8 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     int rc = 0;
     const float* zp = zero_page_for_current_device(&rc);
     if (rc) return rc;
-    int splits = 1;
-    fcn_conv2d_wgrad_workspace_floats(d, &splits);
+    int splits = 1, cfg = 0;
+    plan_wgrad(d, &cfg, &splits);
     WgradP p;
     p.x = d->x;
     p.dy = d->y + d->y_coffset;
@@ -518,8 +616,8 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     p.dy_cstride = d->y_cstride;
     p.M = d->N * d->OH * d->OW;
     p.K = d->kh * d->kw * d->Cin;
-    p.tiles_n = cdiv(p.Cout, WG_BN);
-    p.tiles_k = cdiv(p.K, WG_BK);
+    p.tiles_n = cdiv(p.Cout, kWgShapes[cfg].bn);
+    p.tiles_k = cdiv(p.K, kWgShapes[cfg].bk);
     p.splits = splits;
     p.chunks_per_split = cdiv(cdiv(p.M, WG_BP), splits);
     p.ow_magic = magic32((unsigned)p.OW);
@@ -528,7 +626,14 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     p.dw_part = d_workspace;
     p.db_part = db ? d_workspace + (size_t)splits * p.Cout * p.K : nullptr;
     hipStream_t st = as_stream(s);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.tiles_n * p.tiles_k * splits), dim3(256), 0, st, p);
+    switch (cfg) {
+#define X(I, A, B, C_, D, E)                                                                                                              \
+    case I:                                                                                                                               \
+        hipLaunchKernelGGL((conv_wgrad_kernel<A, B, C_, D, E>), dim3(p.tiles_n * p.tiles_k * splits), dim3(64 * C_ * D), 0, st, p); \
+        break;
+        FCN_WGRAD_CONFIGS(X)
+#undef X
+    }
     const size_t cnt = (size_t)p.Cout * p.K;
     const int red_blocks = (int)((cnt + 63) / 64 < 4096 ? (cnt + 63) / 64 : 4096);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(red_blocks), dim3(64 * RED_LANES), 0, st, p.dw_part, dw, cnt, splits);

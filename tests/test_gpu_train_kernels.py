@@ -31,8 +31,13 @@ WG_CASES = [  # cin, cout, k, stride, pad, h, w, n
 ]
 
 
+@pytest.mark.parametrize("wg_cfg", [None, "0", "1", "2", "3"])       # heuristic tile shape, then every shape forced
 @pytest.mark.parametrize("case", WG_CASES)
-def test_wgrad_and_dgrad_match_oracle(gpu, case):
+def test_wgrad_and_dgrad_match_oracle(gpu, monkeypatch, case, wg_cfg):
+    if wg_cfg is None:
+        monkeypatch.delenv("FCN_WGRAD_CFG", raising=False)
+    else:
+        monkeypatch.setenv("FCN_WGRAD_CFG", wg_cfg)
     cin, cout, k, s, p, h, w, n = case
     rng = np.random.default_rng(hash(case) % 2**32)
     x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
@@ -58,7 +63,7 @@ def test_wgrad_and_dgrad_match_oracle(gpu, case):
     # run it twice: bit-reproducible
     L.call("fcn_conv2d_wgrad_f32", C.byref(d), dwd.ptr, dbd.ptr, ws.ptr, None)
     assert np.array_equal(dev_to(dwd, (cout, k, k, cin4)), dw)
-    if s != 1:
+    if s != 1 or wg_cfg is not None:
         return
     # data gradient = forward kernel on dY with the flipped bank, accumulating into an existing gradient
     wd = dev_from(pack_ohwi(wt))
