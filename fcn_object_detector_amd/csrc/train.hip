@@ -311,6 +311,24 @@ __global__ __launch_bounds__(256) void weights_flip_kernel(const float* __restri
     }
 }
 
+// the same for every layer of a net at once: blockIdx.y = segment
+__global__ __launch_bounds__(256) void weights_flip_batch_kernel(const float* __restrict__ w_base, float* __restrict__ wt_base,
+                                                                 const fcn_flip_seg* __restrict__ segs) {
+    const fcn_flip_seg sg = segs[blockIdx.y];
+    const float* w = w_base + sg.w_offset;
+    float* wt = wt_base + sg.wt_offset;
+    const unsigned total = (unsigned)sg.Cin * sg.kh * sg.kw * sg.Cout4;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const unsigned k = t % (unsigned)sg.Cout4;
+        unsigned u = t / (unsigned)sg.Cout4;
+        const unsigned q = u % (unsigned)sg.kw;
+        u /= (unsigned)sg.kw;
+        const unsigned r = u % (unsigned)sg.kh;
+        const unsigned c = u / (unsigned)sg.kh;
+        wt[t] = k < (unsigned)sg.Cout ? w[(((size_t)k * sg.kh + (sg.kh - 1 - r)) * sg.kw + (sg.kw - 1 - q)) * sg.Cin4 + c] : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // pointwise backward
 // ---------------------------------------------------------------------------------------------
@@ -647,6 +665,13 @@ int fcn_conv_weights_flip_f32(const float* w, float* wt, int Cout, int kh, int k
     const long long total = (long long)Cin * kh * kw * Cout4;
     hipLaunchKernelGGL(weights_flip_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(s), w, wt, Cout, kh, kw, Cin, Cin4, Cout4);
     FCN_LAUNCH_CHECK("weights_flip");
+    return 0;
+}
+
+int fcn_conv_weights_flip_batch_f32(const float* w_base, float* wt_base, const fcn_flip_seg* d_segs, int nseg, fcn_stream_t s) {
+    FCN_REQUIRE(w_base && wt_base && d_segs && nseg > 0 && nseg <= 65535, FCN_E_ARG, "weights_flip_batch: bad args");
+    hipLaunchKernelGGL(weights_flip_batch_kernel, dim3(96, nseg), dim3(256), 0, as_stream(s), w_base, wt_base, d_segs);
+    FCN_LAUNCH_CHECK("weights_flip_batch");
     return 0;
 }
 

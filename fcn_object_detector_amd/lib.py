@@ -43,6 +43,11 @@ class SolverSeg(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("count", C.c_uint64), ("lr_mult", C.c_float), ("decay_mult", C.c_float)]
 
 
+class FlipSeg(C.Structure):
+    _fields_ = [("w_offset", C.c_uint64), ("wt_offset", C.c_uint64), ("Cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
+                ("Cin", C.c_int32), ("Cin4", C.c_int32), ("Cout4", C.c_int32)]
+
+
 class DetectParams(C.Structure):
     _fields_ = [
         ("num_classes", C.c_int32), ("gy", C.c_int32), ("gx", C.c_int32), ("cell_w", C.c_int32), ("cell_h", C.c_int32),
@@ -110,6 +115,7 @@ PROTOTYPES = {
     "fcn_conv2d_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc), C.POINTER(_i)]),
     "fcn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "fcn_conv_weights_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_conv_weights_flip_batch_f32": (_i, [_vp, _vp, _vp, _i, _vp]),
     "fcn_relu_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fcn_sigmoid_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "fcn_maxpool_bwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),

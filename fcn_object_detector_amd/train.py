@@ -153,8 +153,31 @@ class TrainEngine(Engine):
             written.setdefault(g.buf.ptr, []).append((g.coffset, g.coffset + g.channels))
 
         ws_floats = 1
-        flips: Dict[str, DeviceBuffer] = {}
         ops: List[Op] = []
+        # Flipped / transposed filter banks of the data-gradient passes: slices of ONE flat buffer that a single launch
+        # refreshes from the current weights at the start of every backward pass (58 launches otherwise).
+        flip_layout: Dict[str, int] = {}
+        flip_segs: List[L.FlipSeg] = []
+        flip_floats = 0
+        for l in spec.layers:
+            if l.type != "Convolution" or G.get(l.bottoms[0]) is None or G.get(l.tops[0]) is None:
+                continue
+            k, s_, _pad = kernel_stride_pad(l.sub("convolution_param"))
+            if s_ != 1:
+                continue
+            cin, cout = B[l.bottoms[0]].shape[1], B[l.tops[0]].shape[1]
+            flip_layout[l.name] = flip_floats
+            flip_segs.append(L.FlipSeg((self.params_dev[l.name][0].ptr - self.param_flat.ptr) // 4, flip_floats, cout, k, k, cin,
+                                       _r4(cin), _r4(cout)))
+            flip_floats += _r4(cin * k * k * _r4(cout))
+        self._flip_flat = DeviceBuffer(max(flip_floats, 4) * 4, zero=True)
+        if flip_segs:
+            seg_arr = (L.FlipSeg * len(flip_segs))(*flip_segs)
+            self._flip_segs_dev = DeviceBuffer(C.sizeof(seg_arr), zero=False)
+            L.call("fcn_memcpy_h2d_async", self._flip_segs_dev.ptr, C.addressof(seg_arr), C.sizeof(seg_arr), None)
+            L.call("fcn_device_sync")
+            ops.append(Op("flip", "%d filter banks" % len(flip_segs), lambda st, n=len(flip_segs): L.check(lib.fcn_conv_weights_flip_batch_f32(
+                self.param_flat.ptr, self._flip_flat.ptr, self._flip_segs_dev.ptr, n, st))))
         skip_sigmoid_of = {m["sigmoid_top"]: name for name, m in self._conv_layer_meta.items() if m.get("sigmoid_top")}
 
         for l in reversed(spec.layers):
@@ -220,11 +243,7 @@ class TrainEngine(Engine):
                     cin_dg = _r4(cout)
                     if gtop.cstride - gtop.coffset < cin_dg:
                         raise NotImplementedError("gradient view of %s too narrow for the data-gradient pass" % l.tops[0])
-                    wt = DeviceBuffer(cin * k * k * cin_dg * 4, zero=True)
-                    flips[l.name] = wt
-                    wdev = self.params_dev[l.name][0]
-                    ops.append(Op("flip", l.name, lambda st, wdev=wdev, wt=wt, a=(cout, k, k, cin, _r4(cin), cin_dg): L.check(
-                        lib.fcn_conv_weights_flip_f32(wdev.ptr, wt.ptr, *a, st))))
+                    wt = DevView(self._flip_flat.ptr + 4 * flip_layout[l.name], cin * k * k * cin_dg * 4)
                     dd = L.ConvDesc()
                     dd.x, dd.w, dd.bias, dd.y = gtop.ptr, wt.ptr, None, gbot.buf.ptr
                     dd.N, dd.H, dd.W, dd.Cin, dd.x_cstride = n, oh, ow, cin_dg, gtop.cstride
@@ -304,7 +323,6 @@ class TrainEngine(Engine):
                 raise NotImplementedError("backward of layer type %s (%s)" % (t, l.name))
             mark(gbot)
         self._ws = DeviceBuffer(ws_floats * 4, zero=False)
-        self._flips = flips
         self.bwd_ops = ops
         self._plan_buckets()
 

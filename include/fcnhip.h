@@ -218,6 +218,9 @@ int  fcn_conv2d_wgrad_f32(const fcn_conv_desc* h_d, float* dw, float* db, float*
 /* Filter bank of the data-gradient pass: wt[c][kh-1-r][kw-1-q][k] = w[k][r][q][c] (w: [Cout][kh][kw][Cin4],
  * wt: [Cin][kh][kw][Cout4], zero padded).  dX = fcn_conv2d_fwd_f32(dY, wt) with pad' = k-1-pad for stride-1 layers. */
 int  fcn_conv_weights_flip_f32(const float* w, float* wt, int Cout, int kh, int kw, int Cin, int Cin4, int Cout4, fcn_stream_t s);
+/* All filter banks of a net in ONE launch: segment i flips w_base + w_offset (floats) into wt_base + wt_offset. */
+typedef struct fcn_flip_seg { uint64_t w_offset, wt_offset; int32_t Cout, kh, kw, Cin, Cin4, Cout4; } fcn_flip_seg;
+int  fcn_conv_weights_flip_batch_f32(const float* w_base, float* wt_base, const fcn_flip_seg* d_segs, int nseg, fcn_stream_t s);
 int  fcn_relu_bwd_f32(const float* dy, const float* y, float* dx, int pixels, int C, int cstride, fcn_stream_t s);
 int  fcn_sigmoid_bwd_f32(const float* y, const float* dy, float* dx, size_t count, int accumulate, fcn_stream_t s);
 int  fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, int H, int W, int C, int dx_cstride, int dx_coffset,

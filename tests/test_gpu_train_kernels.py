@@ -200,3 +200,29 @@ def test_solver_updates(gpu, kind):
     out = dev_to(wd, (total,))
     for i in range(4):
         assert np.allclose(out[offs[i]:offs[i] + sizes[i]], wr[i], rtol=2e-5, atol=1e-6), i
+
+
+def test_weights_flip_batch_equals_per_layer_flip(gpu):
+    rng = np.random.default_rng(8)
+    layers = [(64, 3, 24), (33, 1, 100), (16, 5, 8)]              # cout, k, cin
+    w_chunks, segs, wt_off, w_off = [], [], 0, 0
+    for cout, k, cin in layers:
+        cin4, co4 = r4(cin), r4(cout)
+        w = rng.standard_normal((cout, k, k, cin4)).astype(np.float32)
+        w[..., cin:] = 0
+        segs.append(L.FlipSeg(w_off, wt_off, cout, k, k, cin, cin4, co4))
+        w_chunks.append(w.reshape(-1))
+        w_off += w.size
+        wt_off += r4(cin * k * k * co4)
+    wd = dev_from(np.concatenate(w_chunks))
+    wtd = dev_from(np.full(wt_off, 9.0, np.float32))
+    arr = (L.FlipSeg * len(segs))(*segs)
+    sd = DeviceBuffer(C.sizeof(arr), zero=False)
+    L.call("fcn_memcpy_h2d_async", sd.ptr, C.addressof(arr), C.sizeof(arr), None)
+    L.call("fcn_conv_weights_flip_batch_f32", wd.ptr, wtd.ptr, sd.ptr, len(segs), None)
+    got = dev_to(wtd, (wt_off,))
+    for sg, (cout, k, cin) in zip(segs, layers):
+        one = dev_from(np.zeros(cin * k * k * sg.Cout4, np.float32))
+        L.call("fcn_conv_weights_flip_f32", wd.ptr + 4 * sg.w_offset, one.ptr, cout, k, k, cin, sg.Cin4, sg.Cout4, None)
+        want = dev_to(one, (cin * k * k * sg.Cout4,))
+        assert np.array_equal(got[sg.wt_offset:sg.wt_offset + want.size], want)
