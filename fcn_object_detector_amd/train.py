@@ -426,19 +426,19 @@ class TrainEngine(Engine):
                         self._enqueue_upload(nm, self.stream)
             if dev_targets:
                 self._enqueue_targets()
-            self.run_ops(self.stream)
             world = self.comm.world if self.comm is not None else 1
-            triggers: Dict[int, List[dict]] = {}
-            for b in self.buckets:
-                triggers.setdefault(b["after_op"], []).append(b)
-            for i, op in enumerate(self.bwd_ops):
-                op.run(self.stream)
-                for b in triggers.get(i, ()):
-                    # this bucket's gradients are final: sum them across ranks on the side stream
-                    L.check(lib.fcn_event_record(b["ready"], self.stream))
-                    L.check(lib.fcn_stream_wait_event(self.comm_stream, b["ready"]))
-                    self.comm.all_reduce_sum(self.grad_flat.ptr + 4 * b["offset"], b["count"], self.comm_stream)
-                    L.check(lib.fcn_event_record(b["done"], self.comm_stream))
+            for kind, item in self._step_plan():
+                if kind == "graph":
+                    L.check(lib.fcn_graph_launch(item, self.stream))
+                elif kind == "op":
+                    item.run(self.stream)
+                else:
+                    for b in item:
+                        # this bucket's gradients are final: sum them across ranks on the side stream
+                        L.check(lib.fcn_event_record(b["ready"], self.stream))
+                        L.check(lib.fcn_stream_wait_event(self.comm_stream, b["ready"]))
+                        self.comm.all_reduce_sum(self.grad_flat.ptr + 4 * b["offset"], b["count"], self.comm_stream)
+                        L.check(lib.fcn_event_record(b["done"], self.comm_stream))
             for b in self.buckets:
                 L.check(lib.fcn_stream_wait_event(self.stream, b["done"]))
             self.apply_update(1.0 / (world * self.solver.iter_size))
@@ -454,6 +454,65 @@ class TrainEngine(Engine):
             out["loss"] = float(sum(self.loss_blobs[k] * out[k] for k in self.loss_blobs))
             self.iter += 1
             return out
+
+    # kinds whose launch arguments change from step to step (the dropout seed): they stay ordinary launches
+    DYNAMIC_KINDS = ("dropout", "dropout_bwd")
+
+    def _step_plan(self) -> List[Tuple[str, object]]:
+        """Forward + backward of one step as [("graph", hipGraphExec) | ("op", Op) | ("reduce", [buckets])].
+        Maximal runs of launches with step-invariant arguments are captured once into hipGraphs (a step is ~240
+        launches, most of them a few microseconds long: inside a graph the gap between two of them is about half of
+        what a stream launch costs); dropout and the points where a gradient bucket goes to RCCL stay outside."""
+        if getattr(self, "_plan", None) is not None:
+            return self._plan
+        import os
+        use_graph = os.environ.get("FCN_TRAIN_GRAPH", "1") != "0"
+        triggers: Dict[int, List[dict]] = {}
+        for b in self.buckets:
+            triggers.setdefault(b["after_op"], []).append(b)
+        seq: List[Tuple[str, object]] = [("op", op) for op in self.ops]
+        for i, op in enumerate(self.bwd_ops):
+            seq.append(("op", op))
+            if i in triggers:
+                seq.append(("reduce", triggers[i]))
+        plan: List[Tuple[str, object]] = []
+        run: List[Op] = []
+
+        def flush() -> None:
+            if not run:
+                return
+            if use_graph and len(run) > 1:
+                L.call("fcn_graph_begin", self.stream)
+                try:
+                    for op in run:
+                        op.run(self.stream)
+                finally:
+                    g = C.c_void_p()
+                    L.call("fcn_graph_end", self.stream, C.byref(g))
+                self._step_graphs.append(int(g.value))
+                plan.append(("graph", int(g.value)))
+            else:
+                plan.extend(("op", op) for op in run)
+            run.clear()
+
+        self._step_graphs: List[int] = []
+        for kind, item in seq:
+            if kind == "op" and item.kind not in self.DYNAMIC_KINDS:
+                run.append(item)
+                continue
+            flush()
+            plan.append((kind, item))
+        flush()
+        self._plan = plan
+        return plan
+
+    def close(self) -> None:
+        lib = L.load()
+        for g in getattr(self, "_step_graphs", []):
+            lib.fcn_graph_destroy(g)
+        self._step_graphs = []
+        self._plan = None
+        super().close()
 
     def apply_update(self, grad_scale: float) -> None:
         sp, lib = self.solver, L.load()
