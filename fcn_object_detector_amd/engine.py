@@ -19,6 +19,7 @@ NCHW<->NHWC change happens on the device at the boundary only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -707,6 +708,11 @@ class Engine:
                 self.host_array(nm)
                 if len(self.blobs[nm].shape) == 4:
                     self._stage(nm)
+        if not getattr(self, "_warm", False):
+            # code objects load lazily on a kernel's first launch, which must not happen inside a stream capture
+            self.run_ops(self.stream)
+            L.call("fcn_stream_sync", self.stream)
+            self._warm = True
         L.call("fcn_graph_begin", self.stream)
         try:
             if with_io:
@@ -723,6 +729,7 @@ class Engine:
 
     def forward(self, use_graph: bool = True) -> Dict[str, np.ndarray]:
         """Upload inputs, run every layer, download the output blobs (synchronous, like Net.forward())."""
+        use_graph = use_graph and os.environ.get("FCN_NO_GRAPH", "0") in ("", "0")
         with self.lock:
             L.call("fcn_init", self.device)
             for nm in self.inputs:
@@ -761,6 +768,7 @@ class Engine:
 
     def forward_resident(self, iters: int = 1, use_graph: bool = True) -> float:
         """Run the layer stack ``iters`` times on inputs already in HBM; returns HIP-event ms for all iterations."""
+        use_graph = use_graph and os.environ.get("FCN_NO_GRAPH", "0") in ("", "0")      # plain launches (e.g. under a profiler)
         with self.lock:
             L.call("fcn_init", self.device)
             if use_graph and self.graph_core is None:

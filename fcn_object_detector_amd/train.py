@@ -466,7 +466,11 @@ class TrainEngine(Engine):
         if getattr(self, "_plan", None) is not None:
             return self._plan
         import os
-        use_graph = os.environ.get("FCN_TRAIN_GRAPH", "1") != "0"
+        # the first step runs as ordinary launches (code objects load lazily on a kernel's first launch, which must not
+        # happen inside a stream capture); graphs are captured from the second step on
+        first = not getattr(self, "_warm", False)
+        self._warm = True
+        use_graph = os.environ.get("FCN_TRAIN_GRAPH", "1") != "0" and os.environ.get("FCN_NO_GRAPH", "0") in ("", "0") and not first
         triggers: Dict[int, List[dict]] = {}
         for b in self.buckets:
             triggers.setdefault(b["after_op"], []).append(b)
@@ -495,7 +499,7 @@ class TrainEngine(Engine):
                 plan.extend(("op", op) for op in run)
             run.clear()
 
-        self._step_graphs: List[int] = []
+        self._step_graphs: List[int] = getattr(self, "_step_graphs", [])
         for kind, item in seq:
             if kind == "op" and item.kind not in self.DYNAMIC_KINDS:
                 run.append(item)
@@ -503,7 +507,8 @@ class TrainEngine(Engine):
             flush()
             plan.append((kind, item))
         flush()
-        self._plan = plan
+        if not first:
+            self._plan = plan
         return plan
 
     def close(self) -> None:
