@@ -93,11 +93,57 @@ struct ConvP {
 // compares on the prefix table and ONE scalar load, instead of chasing a table in global memory (three or four
 // dependent L2 round trips in front of the first LDS-DMA of a kernel that only runs for ~10 us).
 constexpr int kMaxGroup = 8;
+constexpr int kMaxPool = 2;
+struct PoolP {
+    const float* x;
+    float* y;
+    int* idx;
+    int N, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride, y_coffset;
+    int items, wg_end;     // float4 work items; exclusive prefix end of this pool's workgroups (after the conv tiles)
+};
 struct GroupArgs {
     int nprob;
     int tile_end[kMaxGroup];
+    int npool;
+    PoolP pool[kMaxPool];
     ConvP p[kMaxGroup];
 };
+constexpr int kPoolItemsPerThread = 2;
+
+// MAX pooling riding in a convolution launch (Caffe semantics as in pointwise.hip: window clipped to the image, strict
+// '>' so the first maximum in raster order wins).  One work item = 4 channels of one output pixel.
+template <int NT>
+__device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
+    const int cg = q.C >> 2;
+#pragma unroll
+    for (int it = 0; it < kPoolItemsPerThread; ++it) {
+        const int t = (wg * kPoolItemsPerThread + it) * NT + (int)threadIdx.x;
+        if (t >= q.items) return;
+        const int pix = t / cg;
+        const int g = t - pix * cg;
+        const int row = pix / q.OW;
+        const int ox = pix - row * q.OW;
+        const int n = row / q.OH;
+        const int oy = row - n * q.OH;
+        int hs = oy * q.stride - q.pad, ws = ox * q.stride - q.pad;
+        const int he = min(hs + q.k, q.H), we = min(ws + q.k, q.W);
+        hs = max(hs, 0);
+        ws = max(ws, 0);
+        const float* xb = q.x + (size_t)n * q.H * q.W * q.x_cstride + g * 4;
+        v4f m = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+        int mi[4] = {-1, -1, -1, -1};
+        for (int iy = hs; iy < he; ++iy)
+            for (int ix = ws; ix < we; ++ix) {
+                const v4f v = *(const v4f*)(xb + ((size_t)iy * q.W + ix) * q.x_cstride);
+                const int id = iy * q.W + ix;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > m[e]) { m[e] = v[e]; mi[e] = id; }
+            }
+        *(v4f*)(q.y + (size_t)pix * q.y_cstride + q.y_coffset + g * 4) = m;
+        if (q.idx) *(int4*)(q.idx + (size_t)pix * q.C + g * 4) = make_int4(mi[0], mi[1], mi[2], mi[3]);
+    }
+}
 
 __device__ __forceinline__ int fast_div(int m, unsigned magic, int d) {
     return magic ? (int)__umulhi((unsigned)m, magic) : m / d;
@@ -467,6 +513,13 @@ template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int N
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
     const int tile = blockIdx.x;
+    const int conv_tiles = a.tile_end[kMaxGroup - 1];      // the host repeats the last prefix in the unused entries
+    if (tile >= conv_tiles) {      // workgroups behind the convolution tiles: the poolings fused into this launch
+        const int w = tile - conv_tiles;
+        if (w < a.pool[0].wg_end) pool_body<64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[0], w);
+        else pool_body<64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[1], w - a.pool[0].wg_end);
+        return;
+    }
     int pi = 0, begin = 0;
 #pragma unroll
     for (int i = 0; i < kMaxGroup - 1; ++i) {      // tile_end is increasing: count the problems that end at or before this tile
@@ -512,6 +565,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_one
     X(16, 1, 2, 2, 2, 1, 32, 3, false)
 
 struct TileCfg { int bm, bn, bk; bool prefetch; };
+constexpr int kCfgThreads[] = {
+#define X(I, A, B, C_, D, E, F, G, H) Cfg<A, B, C_, D, E, F, G, H>::NT,
+    FCN_CONV_CONFIGS(X)
+#undef X
+};
 constexpr int kNumCfg = 17;
 constexpr TileCfg kCfgs[kNumCfg] = {
 #define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
@@ -622,7 +680,7 @@ void launch_group_cfg(int cfg, const GroupArgs& ga, int total, hipStream_t st) {
 }
 
 // host copies of prepared groups, keyed by their device workspace (the launch needs the problems by value)
-struct HostGroup { int n; ConvP ps[16]; };
+struct HostGroup { int n; ConvP ps[16]; int npool; PoolP pools[kMaxPool]; };
 std::mutex g_groups_mu;
 std::unordered_map<const void*, HostGroup> g_groups;
 
@@ -650,8 +708,15 @@ size_t fcn_conv2d_group_workspace_bytes(int n) { return sizeof(ConvP) * (size_t)
 int fcn_conv2d_num_configs(void) { return kNumCfg; }
 
 int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out) {
+    return fcn_conv2d_group_prepare_fused(h_descs, n, nullptr, 0, d_workspace, cfg_request, h_out);
+}
+
+int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fcn_pool_desc* h_pools, int npools, void* d_workspace,
+                                   int cfg_request, fcn_conv_group* h_out) {
     FCN_REQUIRE(h_descs && h_out && d_workspace && n > 0 && n <= 16, FCN_E_ARG, "fcn_conv2d_group_prepare: need 1..16 problems, workspace, out");
     FCN_REQUIRE(cfg_request >= -1 && cfg_request < kNumCfg, FCN_E_ARG, "fcn_conv2d_group_prepare: tile configuration %d out of range", cfg_request);
+    FCN_REQUIRE(npools >= 0 && npools <= kMaxPool && (npools == 0 || (h_pools && n <= kMaxGroup)), FCN_E_ARG,
+                "fcn_conv2d_group_prepare_fused: at most %d poolings, and only beside at most %d convolutions", kMaxPool, kMaxGroup);
     ConvP ps[16];
     int zrc = 0;
     const float* zp = zero_page_for_current_device(&zrc);
@@ -661,6 +726,24 @@ int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_worksp
         if (rc) return rc;
         fill(ps[i], h_descs[i], zp);
     }
+    PoolP pools[kMaxPool] = {};
+    for (int i = 0; i < npools; ++i) {
+        const fcn_pool_desc& d = h_pools[i];
+        FCN_REQUIRE(d.x && d.y && d.N > 0 && d.H > 0 && d.W > 0 && d.C > 0 && d.k > 0 && d.stride > 0 && d.pad >= 0 && d.pad < d.k && d.OH > 0 &&
+                        d.OW > 0, FCN_E_ARG, "fused maxpool: bad args");
+        FCN_REQUIRE((d.OH - 1) * d.stride - d.pad < d.H && (d.OW - 1) * d.stride - d.pad < d.W, FCN_E_ARG,
+                    "fused maxpool: last window starts outside the image");
+        FCN_REQUIRE(d.C % 4 == 0 && d.x_cstride % 4 == 0 && d.y_cstride % 4 == 0 && d.y_coffset % 4 == 0 && d.x_cstride >= d.C &&
+                        d.y_coffset >= 0 && d.y_cstride >= d.y_coffset + d.C, FCN_E_ALIGN, "fused maxpool: channels / strides must be multiples of 4");
+        FCN_REQUIRE((((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.idx) & 15) == 0, FCN_E_ALIGN, "fused maxpool: pointers must be 16-byte aligned");
+        FCN_REQUIRE((long long)d.N * d.OH * d.OW * (d.C / 4) < (1ll << 30), FCN_E_UNSUPPORTED, "fused maxpool: too large");
+        PoolP& q = pools[i];
+        q.x = d.x; q.y = d.y; q.idx = d.idx;
+        q.N = d.N; q.H = d.H; q.W = d.W; q.C = d.C; q.x_cstride = d.x_cstride; q.k = d.k; q.stride = d.stride; q.pad = d.pad;
+        q.OH = d.OH; q.OW = d.OW; q.y_cstride = d.y_cstride; q.y_coffset = d.y_coffset;
+        q.items = d.N * d.OH * d.OW * (d.C / 4);
+        q.wg_end = 0;      // depends on the workgroup size of the tile configuration: set at launch
+    }
     const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
     const int total = plan_tiles_cfg(cfg, ps, n);
     FCN_HIP(hipMemcpy(d_workspace, ps, sizeof(ConvP) * n, hipMemcpyHostToDevice));
@@ -669,6 +752,8 @@ int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_worksp
         HostGroup& hg = g_groups[d_workspace];
         hg.n = n;
         for (int i = 0; i < n; ++i) hg.ps[i] = ps[i];
+        hg.npool = npools;
+        for (int i = 0; i < kMaxPool; ++i) hg.pools[i] = pools[i];
     }
     h_out->d_probs = d_workspace;
     h_out->n = n;
@@ -690,6 +775,8 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
     // at most kMaxGroup problems ride in one launch's kernel arguments; larger groups take several launches
     for (int first = 0; first < hg.n; first += kMaxGroup) {
         GroupArgs ga;
+        ga.npool = 0;
+        for (int i = 0; i < kMaxPool; ++i) ga.pool[i] = PoolP{};
         ga.nprob = hg.n - first < kMaxGroup ? hg.n - first : kMaxGroup;
         const int base = first ? hg.ps[first - 1].tile_end : 0;
         for (int i = 0; i < kMaxGroup; ++i) {
@@ -697,7 +784,19 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
             ga.p[i] = src;
             ga.tile_end[i] = src.tile_end - base;
         }
-        launch_group_cfg(g->cfg, ga, ga.tile_end[ga.nprob - 1], as_stream(s));
+        int grid = ga.tile_end[ga.nprob - 1];
+        if (hg.npool > 0) {      // only with n <= kMaxGroup: a single launch
+            const int per_wg = kCfgThreads[g->cfg] * kPoolItemsPerThread;
+            int end = 0;
+            ga.npool = hg.npool;
+            for (int i = 0; i < kMaxPool; ++i) {
+                ga.pool[i] = hg.pools[i < hg.npool ? i : hg.npool - 1];
+                if (i < hg.npool) end += (ga.pool[i].items + per_wg - 1) / per_wg;
+                ga.pool[i].wg_end = end;
+            }
+            grid += end;
+        }
+        launch_group_cfg(g->cfg, ga, grid, as_stream(s));
         FCN_LAUNCH_CHECK("conv_fwd_group");
     }
     return 0;

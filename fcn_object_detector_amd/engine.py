@@ -417,7 +417,7 @@ class Engine:
                 continue      # folded into the consumer convolutions' loaders
             ops = self._emit_simple(l)
             tasks.append(dict(kind="op", layer=l, ops=ops, reads=[self._range(b) for b in l.bottoms],
-                              writes=[self._range(tp) for tp in l.tops]))
+                              writes=[self._range(tp) for tp in l.tops], pool_desc=self._fusable_pool_desc(l)))
 
         def hit(a, b) -> bool:
             return any(x[0] == y[0] and x[1] < y[2] and y[1] < x[2] for x in a for y in b)
@@ -435,7 +435,8 @@ class Engine:
             levels.append(lv)
         order = sorted(range(len(tasks)), key=lambda i: (levels[i], 0 if tasks[i]["kind"] == "op" else 1, i))
 
-        def emit_convs(items: List[dict]) -> None:
+        def emit_convs(items: List[dict], pools: List[dict]) -> None:
+            """One grouped launch per 16 convolutions of a level; the level's fusable MAX poolings ride in the first one."""
             for base in range(0, len(items), 16):
                 chunk = items[base:base + 16]
                 name = "+".join(it["layer"].name for it in chunk)
@@ -444,27 +445,60 @@ class Engine:
                 arr = (L.ConvDesc * len(chunk))(*[it["desc"] for it in chunk])
                 ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(chunk))), zero=False)
                 grp = L.ConvGroup()
-                cfg = self._tuned_cfg(name, arr, len(chunk), ws) if self.autotune else -1
-                L.call("fcn_conv2d_group_prepare", arr, len(chunk), ws.ptr, cfg, C.byref(grp))
-                self._keep.extend([arr, ws, grp])
+                fused = pools[:2] if base == 0 and len(chunk) <= 8 else []
+                parr = (L.PoolDesc * max(len(fused), 1))(*[pt["pool_desc"] for pt in fused])
+                tune_key = name + ("{+%d pool}" % len(fused) if fused else "")
+                cfg = self._tuned_cfg(tune_key, arr, len(chunk), ws, parr, len(fused)) if self.autotune else -1
+                L.call("fcn_conv2d_group_prepare_fused", arr, len(chunk), parr, len(fused), ws.ptr, cfg, C.byref(grp))
+                self._keep.extend([arr, parr, ws, grp])
                 kind = "conv_group" if len(chunk) > 1 else "conv"
-                self.ops.append(Op(kind, "%s [cfg%d %dwg]" % (name, grp.cfg, grp.total_tiles),
-                                   lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
+                label = "%s [cfg%d %dwg]" % (name, grp.cfg, grp.total_tiles)
+                if fused:
+                    label = "%s {+%s}" % (label, "+".join(pt["layer"].name for pt in fused))
+                    byts += sum(pt["ops"][0].bytes for pt in fused)
+                    del pools[:len(fused)]
+                self.ops.append(Op(kind, label, lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
+            for pt in pools:            # no convolution launch at this level to ride in
+                self.ops.extend(pt["ops"])
+            pools.clear()
 
         pending: List[dict] = []
+        pending_pools: List[dict] = []
         cur = None
         for i in order:
             if levels[i] != cur:
-                emit_convs(pending)
+                emit_convs(pending, pending_pools)
                 pending, cur = [], levels[i]
             if tasks[i]["kind"] == "conv":
                 pending.append(tasks[i])
+            elif tasks[i].get("pool_desc") is not None and self.fuse and self.group_convs:
+                pending_pools.append(tasks[i])
             else:
                 self.ops.extend(tasks[i]["ops"])
-        emit_convs(pending)
+        emit_convs(pending, pending_pools)
         self.levels = max(levels) + 1 if levels else 0
 
-    def _tuned_cfg(self, name: str, arr, n: int, ws: DeviceBuffer) -> int:
+    def _fusable_pool_desc(self, l: Layer) -> Optional[L.PoolDesc]:
+        """fcn_pool_desc of a MAX pooling that can ride in a convolution launch (16-byte channel groups), else None."""
+        if l.type != "Pooling":
+            return None
+        pp = l.sub("pooling_param")
+        if str(pp.get("pool", "MAX")) != "MAX" or bool(pp.get("global_pooling", False)):
+            return None
+        xb, yb = self.blobs[l.bottoms[0]], self.blobs[l.tops[0]]
+        n, c, h, w = xb.shape
+        _, _, oh, ow = yb.shape
+        k, s, pad = kernel_stride_pad(pp)
+        if c % 4 or xb.cstride % 4 or yb.cstride % 4 or yb.coffset % 4 or xb.coffset % 4 or n * oh * ow * (c // 4) >= 1 << 30:
+            return None
+        idx = self.aux_dev.get(l.name)
+        d = L.PoolDesc()
+        d.x, d.y, d.idx = xb.ptr, yb.buf.ptr, (idx.ptr if idx is not None else None)
+        d.N, d.H, d.W, d.C, d.x_cstride, d.k, d.stride, d.pad = n, h, w, c, xb.cstride, k, s, pad
+        d.OH, d.OW, d.y_cstride, d.y_coffset = oh, ow, yb.cstride, yb.coffset
+        return d
+
+    def _tuned_cfg(self, name: str, arr, n: int, ws: DeviceBuffer, parr=None, npool: int = 0) -> int:
         """Autotuned tile configuration of one grouped launch, remembered in $FCN_TUNE_CACHE (JSON) when that is set so
         that a profiled run replays the plan of an earlier run without the tuning launches."""
         import json
@@ -481,7 +515,7 @@ class Engine:
         ncfg = int(L.load().fcn_conv2d_num_configs())
         if cache is not None and key in cache and 0 <= int(cache[key]) < ncfg:
             return int(cache[key])
-        cfg = self._pick_conv_cfg(arr, n, ws)
+        cfg = self._pick_conv_cfg(arr, n, ws, parr, npool)
         if cache is not None:
             cache[key] = cfg
             try:
@@ -491,7 +525,7 @@ class Engine:
                 pass
         return cfg
 
-    def _pick_conv_cfg(self, arr, n: int, ws: DeviceBuffer) -> int:
+    def _pick_conv_cfg(self, arr, n: int, ws: DeviceBuffer, parr=None, npool: int = 0) -> int:
         """Plan-time autotune of one grouped launch: time every tile configuration on the device, keep the fastest."""
         lib = L.load()
         if not hasattr(self, "_tune_events"):
@@ -503,7 +537,7 @@ class Engine:
         best, best_ms = -1, 1e30
         grp = L.ConvGroup()
         for cfg in range(int(lib.fcn_conv2d_num_configs())):
-            L.call("fcn_conv2d_group_prepare", arr, n, ws.ptr, cfg, C.byref(grp))
+            L.call("fcn_conv2d_group_prepare_fused", arr, n, parr, npool, ws.ptr, cfg, C.byref(grp))
             for _ in range(2):
                 L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))
             L.call("fcn_event_record", e0, self.stream)

@@ -43,6 +43,11 @@ class SolverSeg(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("count", C.c_uint64), ("lr_mult", C.c_float), ("decay_mult", C.c_float)]
 
 
+class PoolDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("idx", C.c_void_p)] + [(k, C.c_int32) for k in (
+        "N", "H", "W", "C", "x_cstride", "k", "stride", "pad", "OH", "OW", "y_cstride", "y_coffset")]
+
+
 class FlipSeg(C.Structure):
     _fields_ = [("w_offset", C.c_uint64), ("wt_offset", C.c_uint64), ("Cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("Cin", C.c_int32), ("Cin4", C.c_int32), ("Cout4", C.c_int32)]
@@ -97,6 +102,7 @@ PROTOTYPES = {
     "fcn_conv2d_group_workspace_bytes": (_sz, [_i]),
     "fcn_conv2d_num_configs": (_i, []),
     "fcn_conv2d_group_prepare": (_i, [C.POINTER(ConvDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),
+    "fcn_conv2d_group_prepare_fused": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(PoolDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),
     "fcn_conv2d_fwd_group_f32": (_i, [C.POINTER(ConvGroup), _vp]),
     "fcn_maxpool_fwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "fcn_avepool_fwd_f32": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),

@@ -121,6 +121,15 @@ size_t fcn_conv2d_group_workspace_bytes(int n);
 int  fcn_conv2d_num_configs(void);
 int  fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out);
 int  fcn_conv2d_fwd_group_f32(const fcn_conv_group* h_group, fcn_stream_t s);
+/* MAX poolings that read the same bottoms as the group's convolutions (an inception module's 3x3 stride-1 pool beside
+ * its 1x1 convolutions) can ride in the group's launch as extra workgroups instead of a launch of their own.
+ * Needs C, x_cstride, y_cstride, y_coffset multiples of 4 and 16-byte aligned pointers; idx may be NULL. */
+typedef struct fcn_pool_desc {
+    const float* x; float* y; int32_t* idx;
+    int32_t N, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride, y_coffset;
+} fcn_pool_desc;
+int  fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fcn_pool_desc* h_pools, int npools, void* d_workspace,
+                                    int cfg_request, fcn_conv_group* h_out);
 
 /* ---- Pooling / LRN / pointwise: Caffe PoolingLayer, LRNLayer, EltwiseLayer ---- */
 /* MAX pool, ceil-mode output size computed by the caller (OH, OW), window clipped to the

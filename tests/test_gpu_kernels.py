@@ -235,3 +235,54 @@ def test_depthwise_deconv_matches_oracle(gpu, c, k, s, p, h):
     L.call("fcn_deconv_depthwise_fwd_f32", xd.ptr, wd.ptr, None, yd.ptr, 2, h, h, c, cs, k, s, p, oh, oh, cs, 0, None)
     y = nchw(dev_to(yd, (2, oh, oh, cs)), c)
     assert rel_err(y, R.deconv2d(x, w, None, p, s, group=c)) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [2, 5, 8, 13])
+@pytest.mark.parametrize("with_idx", [False, True])
+def test_maxpool_fused_into_conv_group(gpu, cfg, with_idx):
+    """Two MAX poolings ride in a grouped convolution launch (fcn_conv2d_group_prepare_fused): conv outputs unchanged,
+    pool outputs / argmax equal to the oracle's (an inception module's 3x3 s1 pool beside its 1x1 convolutions)."""
+    rng = np.random.default_rng(31)
+    n, h, w, cin = 2, 14, 11, 24
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    x[0, :, 2, 2] = x[0, :, 2, 3]                                   # ties: the first maximum in raster order wins
+    xd = dev_from(nhwc(x, cin))
+    descs, keep, refs = [], [], []
+    for cout, k, pad in ((40, 1, 0), (16, 3, 1)):
+        wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        wd, bd, yd = dev_from(pack_ohwi(wt)), dev_from(b), dev_from(np.zeros((n, h, w, cout), np.float32))
+        keep += [wd, bd, yd]
+        descs.append(conv_desc(xd, wd, bd, yd, n, h, w, cin, cin, cout, k, pad, 1, h, w, cout, 0, L.CONV_RELU))
+        refs.append((yd, cout, np.maximum(R.conv2d(x, wt, b, pad, 1), 0)))
+    pools, pool_refs = [], []
+    for k, s, p, cs, co in ((3, 1, 1, 32, 8), (3, 2, 0, 24, 0)):
+        y, idx = R.max_pool(x, k, s, p, return_index=True)
+        oh, ow = y.shape[2:]
+        yd = dev_from(np.full((n, oh, ow, cs), -7.0, np.float32))
+        idd = dev_from(np.zeros((n, oh, ow, cin), np.int32)) if with_idx else None
+        d = L.PoolDesc()
+        d.x, d.y, d.idx = xd.ptr, yd.ptr, (idd.ptr if idd is not None else None)
+        d.N, d.H, d.W, d.C, d.x_cstride, d.k, d.stride, d.pad = n, h, w, cin, cin, k, s, p
+        d.OH, d.OW, d.y_cstride, d.y_coffset = oh, ow, cs, co
+        pools.append(d)
+        pool_refs.append((yd, idd, cs, co, y, idx))
+    arr = (L.ConvDesc * 2)(*descs)
+    parr = (L.PoolDesc * 2)(*pools)
+    ws = DeviceBuffer(int(L.load().fcn_conv2d_group_workspace_bytes(2)), zero=False)
+    grp = L.ConvGroup()
+    L.call("fcn_conv2d_group_prepare_fused", arr, 2, parr, 2, ws.ptr, cfg, C.byref(grp))
+    L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+    for yd, cout, ref in refs:
+        assert rel_err(nchw(dev_to(yd, (n, h, w, cout)), cout), ref) < 1e-5
+    for yd, idd, cs, co, y, idx in pool_refs:
+        oh, ow = y.shape[2:]
+        got = dev_to(yd, (n, oh, ow, cs))
+        assert np.array_equal(nchw(got, cin, co), y)
+        assert np.all(got[..., :co] == -7.0) and np.all(got[..., co + cin:] == -7.0)       # neighbours of the slice untouched
+        if idd is not None:
+            assert np.array_equal(dev_to(idd, (n, oh, ow, cin), np.int32).transpose(0, 3, 1, 2), idx)
+    # misaligned poolings are refused, not silently mis-computed
+    pools[0].y_coffset = 2
+    bad = (L.PoolDesc * 1)(pools[0])
+    assert L.load().fcn_conv2d_group_prepare_fused(arr, 2, bad, 1, ws.ptr, cfg, C.byref(grp)) == 2      # FCN_E_ALIGN
