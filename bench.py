@@ -107,13 +107,13 @@ def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
     losses = []
     for it in range(max(warmup, 1)):
         eng.set_targets(*synth_boxes(np.random.default_rng(42 + it * world + rank), n), stride=16)
-        losses.append(eng.step(seed=it, upload=False)["loss"])
+        losses.append(eng.step(seed=it, upload=False)["total_loss"])
     L.call("fcn_device_sync")
     cp.barrier()
     t0 = time.perf_counter()
     for it in range(steps):
         eng.set_targets(*synth_boxes(np.random.default_rng(4242 + it * world + rank), n), stride=16)
-        losses.append(eng.step(seed=1000 + it, upload=False)["loss"])
+        losses.append(eng.step(seed=1000 + it, upload=False)["total_loss"])
     L.call("fcn_device_sync")
     t_local = time.perf_counter() - t0
     cp.barrier()

@@ -259,6 +259,20 @@ __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restr
 // depthwise transposed convolution (Caffe Deconvolution with group == channels), gather form:
 // y[oy][ox][c] = b[c] + sum over (r, q) with (oy + p - r) % s == 0, (ox + p - q) % s == 0 of
 //                x[(oy+p-r)/s][(ox+p-q)/s][c] * w[c][r][q]
+// Softmax over the channels of every pixel (Caffe SoftmaxLayer, axis 1): channels are contiguous in NHWC, one lane per pixel
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ x, float* __restrict__ y, long long pixels, int C,
+                                                      int x_cstride, int y_cstride) {
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < pixels; pix += (long long)gridDim.x * blockDim.x) {
+        const float* xp = x + (size_t)pix * x_cstride;
+        float* yp = y + (size_t)pix * y_cstride;
+        float m = xp[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, xp[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(xp[c] - m);
+        for (int c = 0; c < C; ++c) yp[c] = expf(xp[c] - m) / sum;
+    }
+}
+
 __global__ __launch_bounds__(256) void deconv_dw_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int N, int H, int W, int C,
                                                         int x_cstride, int k, int stride, int pad, int OH, int OW, int y_cstride,
@@ -414,6 +428,14 @@ int fcn_copy_channels_f32(const float* src, float* dst, int pixels, int C, int s
     hipLaunchKernelGGL(copy_channels_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, as_stream(s), src, dst,
                        (long long)pixels, C, src_cstride, src_coffset, dst_cstride, dst_coffset);
     FCN_LAUNCH_CHECK("copy_channels");
+    return 0;
+}
+
+int fcn_softmax_fwd_f32(const float* x, float* y, int pixels, int C, int x_cstride, int y_cstride, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && pixels > 0 && C > 0 && x_cstride >= C && y_cstride >= C, FCN_E_ARG, "softmax: bad args");
+    hipLaunchKernelGGL(softmax_kernel, dim3(stream_grid(pixels, 256)), dim3(256), 0, as_stream(s), x, y, (long long)pixels, C, x_cstride,
+                       y_cstride);
+    FCN_LAUNCH_CHECK("softmax");
     return 0;
 }
 

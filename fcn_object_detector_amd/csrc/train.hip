@@ -478,6 +478,103 @@ __global__ __launch_bounds__(256) void lrn5_bwd_kernel(const float* __restrict__
     }
 }
 
+// Depthwise (group == channels) deconvolution, gradient w.r.t. the input: the forward convolution of dY with the same filter
+//   dX[n][iy][ix][c] = sum_{r,q} dY[n][iy*s - p + r][ix*s - p + q][c] * w[c][r][q]
+__global__ __launch_bounds__(256) void deconv_dw_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                            int N, int H, int W, int C, int dx_cstride, int k, int stride, int pad, int OH,
+                                                            int OW, int dy_cstride, int dy_coffset, int accumulate) {
+    const long long total = (long long)N * H * W * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        long long pix = t / C;
+        const int ix = (int)(pix % W);
+        const long long row = pix / W;
+        const int iy = (int)(row % H);
+        const int n = (int)(row / H);
+        const float* wc = w + (size_t)c * k * k;
+        const float* dyb = dy + (size_t)n * OH * OW * dy_cstride + dy_coffset + c;
+        float acc = 0.f;
+        for (int r = 0; r < k; ++r) {
+            const int oy = iy * stride - pad + r;
+            if ((unsigned)oy >= (unsigned)OH) continue;
+            for (int q = 0; q < k; ++q) {
+                const int ox = ix * stride - pad + q;
+                if ((unsigned)ox >= (unsigned)OW) continue;
+                acc += dyb[((size_t)oy * OW + ox) * dy_cstride] * wc[r * k + q];
+            }
+        }
+        float* d = dx + (size_t)pix * dx_cstride + c;
+        *d = accumulate ? *d + acc : acc;
+    }
+}
+
+// SoftmaxWithLoss (Caffe, legacy `normalize` flag), three passes so that any number of pixels reduces in a fixed order:
+//   1. per pixel: p = softmax(x); loss -= log(max(p[label], FLT_MIN)); dx = p - onehot(label) (zero if ignored);
+//      per-workgroup partial (loss, valid count) in double
+//   2. one workgroup: fixed-order sum of the partials -> loss / denom, scale = weight / denom
+//      (denom = valid count if normalize else N)
+//   3. dx *= scale
+constexpr int SML_MAX_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void softmax_loss_partial_kernel(const float* __restrict__ x, const float* __restrict__ label,
+                                                                   float* __restrict__ dx, double* __restrict__ partial, long long pixels,
+                                                                   int C, int x_cstride, int label_cstride, int has_ignore, int ignore_label) {
+    __shared__ double sl[256], sc[256];
+    double loss = 0.0, cnt = 0.0;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < pixels; pix += (long long)gridDim.x * blockDim.x) {
+        const float* xp = x + (size_t)pix * x_cstride;
+        float m = xp[0];
+        for (int c = 1; c < C; ++c) m = fmaxf(m, xp[c]);
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) sum += expf(xp[c] - m);
+        int lab = (int)label[(size_t)pix * label_cstride];
+        const bool ignored = has_ignore && lab == ignore_label;
+        lab = min(max(lab, 0), C - 1);      // Caffe DCHECKs the range; never index outside the pixel
+        if (!ignored) {
+            loss -= (double)logf(fmaxf(expf(xp[lab] - m) / sum, 1.175494351e-38f));
+            cnt += 1.0;
+        }
+        if (dx) {
+            float* dp = dx + (size_t)pix * x_cstride;
+            for (int c = 0; c < C; ++c) dp[c] = ignored ? 0.f : expf(xp[c] - m) / sum - (c == lab ? 1.f : 0.f);
+        }
+    }
+    sl[threadIdx.x] = loss;
+    sc[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sl[threadIdx.x] += sl[threadIdx.x + o];
+            sc[threadIdx.x] += sc[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sl[0];
+        partial[2 * blockIdx.x + 1] = sc[0];
+    }
+}
+
+__global__ void softmax_loss_final_kernel(const double* __restrict__ partial, int nblocks, float* __restrict__ d_loss, float* __restrict__ d_scale,
+                                          int N, int normalize, float weight) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double loss = 0.0, cnt = 0.0;
+    for (int i = 0; i < nblocks; ++i) {
+        loss += partial[2 * i];
+        cnt += partial[2 * i + 1];
+    }
+    const double denom = normalize ? (cnt > 1.0 ? cnt : 1.0) : (double)N;
+    *d_loss = (float)(loss / denom);
+    *d_scale = (float)((double)weight / denom);
+}
+
+__global__ __launch_bounds__(256) void scale_view_kernel(float* __restrict__ x, const float* __restrict__ d_scale, long long pixels, int C,
+                                                         int cstride) {
+    const float sc = *d_scale;
+    const long long total = pixels * C;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x)
+        x[(size_t)(t / C) * cstride + (t % C)] *= sc;
+}
+
 // counter-based dropout mask (oracle/caffe_ref.py::dropout_hash): element index = NCHW linear index
 __device__ __forceinline__ unsigned dropout_hash(unsigned index, unsigned seed) {
     unsigned x = index + seed * 0x9E3779B9u;
@@ -708,6 +805,39 @@ int fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, i
         hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((long long)N * H * W * C, 256)), dim3(256), 0, as_stream(s), dy, idx, dx, N, H, W, C,
                            dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate);
     FCN_LAUNCH_CHECK("maxpool_bwd");
+    return 0;
+}
+
+int fcn_deconv_depthwise_bwd_f32(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int dx_cstride, int k, int stride,
+                                 int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, fcn_stream_t s) {
+    FCN_REQUIRE(dy && w && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0, FCN_E_ARG, "deconv_bwd: bad args");
+    FCN_REQUIRE(OH == stride * (H - 1) + k - 2 * pad && OW == stride * (W - 1) + k - 2 * pad, FCN_E_ARG,
+                "deconv_bwd: OH/OW do not match s(H-1)+k-2p");
+    FCN_REQUIRE(dx_cstride >= C && dy_coffset >= 0 && dy_cstride >= dy_coffset + C, FCN_E_ARG, "deconv_bwd: channel slice out of range");
+    hipLaunchKernelGGL(deconv_dw_bwd_kernel, dim3(stream_grid((long long)N * H * W * C, 256)), dim3(256), 0, as_stream(s), dy, w, dx, N, H, W, C,
+                       dx_cstride, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate);
+    FCN_LAUNCH_CHECK("deconv_depthwise_bwd");
+    return 0;
+}
+
+size_t fcn_softmax_loss_workspace_bytes(void) { return (size_t)SML_MAX_BLOCKS * 2 * sizeof(double) + 64; }
+
+int fcn_softmax_loss_f32(const float* x, const float* label, float* dx, float* d_loss, int N, int pixels, int C, int x_cstride,
+                         int label_cstride, int normalize, int has_ignore, int ignore_label, float weight, void* d_workspace, fcn_stream_t s) {
+    FCN_REQUIRE(x && label && d_loss && d_workspace && N > 0 && pixels > 0 && C > 0 && x_cstride >= C && label_cstride >= 1, FCN_E_ARG,
+                "softmax_loss: bad args");
+    FCN_REQUIRE(((uintptr_t)d_workspace & 7) == 0, FCN_E_ALIGN, "softmax_loss: workspace must be 8-byte aligned");
+    hipStream_t st = as_stream(s);
+    int blocks = cdiv(pixels, 256);
+    if (blocks > SML_MAX_BLOCKS) blocks = SML_MAX_BLOCKS;
+    double* partial = reinterpret_cast<double*>(d_workspace);
+    float* d_scale = reinterpret_cast<float*>(partial + (size_t)SML_MAX_BLOCKS * 2);
+    hipLaunchKernelGGL(softmax_loss_partial_kernel, dim3(blocks), dim3(256), 0, st, x, label, dx, partial, (long long)pixels, C, x_cstride,
+                       label_cstride, has_ignore, ignore_label);
+    hipLaunchKernelGGL(softmax_loss_final_kernel, dim3(1), dim3(64), 0, st, partial, blocks, d_loss, d_scale, N, normalize, weight);
+    if (dx) hipLaunchKernelGGL(scale_view_kernel, dim3(stream_grid((long long)pixels * C, 256)), dim3(256), 0, st, dx, d_scale, (long long)pixels, C,
+                               x_cstride);
+    FCN_LAUNCH_CHECK("softmax_loss");
     return 0;
 }
 

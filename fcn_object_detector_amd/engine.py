@@ -633,6 +633,27 @@ class Engine:
             out.append(Op("loss", l.name, lambda st: L.check(lib.fcn_loss_f32(
                 kind, ab.ptr, bb.ptr, da, lb.buf.ptr, ab.pixels, ab.channels, ab.cstride, ab.shape[0], weight, st)),
                 0.0, 8.0 * ab.pixels * ab.channels))
+        elif t == "Softmax":
+            xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+            if int(l.sub("softmax_param").get("axis", 1)) != 1:
+                raise NotImplementedError("Softmax over an axis other than channels (layer %s)" % l.name)
+            out.append(Op("softmax", l.name, lambda st: L.check(lib.fcn_softmax_fwd_f32(
+                xb.ptr, yb.ptr, xb.pixels, xb.channels, xb.cstride, yb.cstride, st)), 0.0, 8.0 * xb.pixels * xb.channels))
+        elif t == "SoftmaxWithLoss":
+            xb, lab, lb = B[l.bottoms[0]], B[l.bottoms[1]], B[l.tops[0]]
+            if lab.channels != 1 or lab.pixels != xb.pixels or xb.coffset:
+                raise NotImplementedError("SoftmaxWithLoss %s: needs one label per pixel of an unsliced score blob" % l.name)
+            lp = l.sub("loss_param")
+            normalize = 1 if bool(lp.get("normalize", True)) else 0
+            ign = lp.get("ignore_label", None)
+            weight = l.loss_weight[0] if l.loss_weight else 1.0
+            da = self._loss_grad_ptr(l.bottoms[0])
+            self.loss_blobs[l.tops[0]] = float(weight)
+            ws = DeviceBuffer(int(lib.fcn_softmax_loss_workspace_bytes()), zero=True)
+            self._keep.append(ws)
+            out.append(Op("loss", l.name, lambda st: L.check(lib.fcn_softmax_loss_f32(
+                xb.ptr, lab.ptr, da, lb.buf.ptr, xb.shape[0], xb.pixels, xb.channels, xb.cstride, lab.cstride, normalize,
+                0 if ign is None else 1, 0 if ign is None else int(ign), weight, ws.ptr, st)), 0.0, 8.0 * xb.pixels * xb.channels))
         elif t == "Concat":
             off = 0
             yb = B[l.tops[0]]

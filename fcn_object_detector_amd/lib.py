@@ -121,6 +121,10 @@ PROTOTYPES = {
     "fcn_conv2d_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc), C.POINTER(_i)]),
     "fcn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "fcn_conv_weights_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_softmax_fwd_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "fcn_softmax_loss_workspace_bytes": (_sz, []),
+    "fcn_softmax_loss_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "fcn_deconv_depthwise_bwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 13 + [_vp]),
     "fcn_conv_weights_flip_batch_f32": (_i, [_vp, _vp, _vp, _i, _vp]),
     "fcn_relu_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fcn_sigmoid_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),

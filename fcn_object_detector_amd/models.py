@@ -60,14 +60,14 @@ class _Writer:
 
 
 def _conv_body(num_output: int, k: int, pad: int = 0, stride: int = 1, bias_value: float = 0.2,
-               lr: Tuple[float, float] = (1.0, 2.0), decay: Tuple[float, float] = (1.0, 0.0)) -> str:
+               lr: Tuple[float, float] = (1.0, 2.0), decay: Tuple[float, float] = (1.0, 0.0), explicit: bool = False) -> str:
     s = ["  param { lr_mult: %g decay_mult: %g }" % (lr[0], decay[0]),
          "  param { lr_mult: %g decay_mult: %g }" % (lr[1], decay[1]),
          "  convolution_param {", "    num_output: %d" % num_output]
-    if pad:
+    if pad or explicit:
         s.append("    pad: %d" % pad)
     s.append("    kernel_size: %d" % k)
-    if stride != 1:
+    if stride != 1 or explicit:
         s.append("    stride: %d" % stride)
     s += ['    weight_filler { type: "xavier" }', '    bias_filler { type: "constant" value: %g }' % bias_value, "  }"]
     return "\n".join(s)
@@ -152,37 +152,73 @@ def googlenet_detectnet_train(module: str, layer: str, param_str: str, num_class
 VGG16 = [(1, 2, 64), (2, 2, 128), (3, 3, 256), (4, 3, 512), (5, 3, 512)]
 
 
-def vgg16_fcn_bbox_deploy(batch: int = 1, height: int = 448, width: int = 448, num_classes: int = 11) -> str:
-    """Inference form of reference train/fcn_bbox/train_val.prototxt: VGG16 -> ``upscore_pool5_bbox`` (bbox branch,
-    grouped bilinear Deconvolution k8 s4 p2) and the FCN-8s style score branch up to ``upscore_pool3``."""
-    w = _Writer()
-    w.raw('input: "data"\ninput_shape {\n  dim: %d\n  dim: 3\n  dim: %d\n  dim: %d\n}' % (batch, height, width))
-    prev = "data"
+def _vgg16_body(w: _Writer, data_blob: str) -> None:
+    prev = data_blob
     for blk, n, width_ in VGG16:
         for i in range(1, n + 1):
             nm = "conv%d_%d" % (blk, i)
-            w.layer(nm, "Convolution", [prev], [nm], _conv_body(width_, 3, 1, bias_value=0.0))
+            w.layer(nm, "Convolution", [prev], [nm], _conv_body(width_, 3, 1, explicit=True))
             w.layer("relu%d_%d" % (blk, i), "ReLU", [nm], [nm])
             prev = nm
         body = "  pooling_param { pool: MAX kernel_size: 2 stride: 2 }"
         w.layer("pool%d" % blk, "Pooling", [prev], ["pool%d" % blk], body)
         prev = "pool%d" % blk
-    w.layer("dropout5", "Dropout", ["pool5"], ["pool5"], "  dropout_param { dropout_ratio: 0.5 }")
+    w.layer("dropout5", "Dropout", ["pool5"], ["dropout5"], "  dropout_param { dropout_ratio: 0.5 }")
+
+
+def _frozen_bilinear_deconv(w: _Writer, name: str, bottom: str, ch: int, k: int, s: int, p: int) -> None:
+    body = ("  convolution_param {\n    kernel_size: %d\n    stride: %d\n    num_output: %d\n    group: %d\n    pad: %d\n"
+            "    weight_filler { type: \"bilinear\" }\n    bias_term: false\n  }\n  param { lr_mult: 0 decay_mult: 0 }") % (k, s, ch, ch, p)
+    w.layer(name, "Deconvolution", [bottom], [name], body)
+
+
+def _fcn_bbox_heads(w: _Writer, num_classes: int) -> None:
+    """bbox branch (stride 8 after a x4 bilinear deconvolution) and the FCN-8s style score branch of train/fcn_bbox."""
     c4 = 4 * num_classes
+    w.layer("score_conv5_bbox", "Convolution", ["dropout5"], ["score_conv5_bbox"], _conv_body(c4, 1, explicit=True))
+    _frozen_bilinear_deconv(w, "upscore_pool5_bbox", "score_conv5_bbox", c4, 8, 4, 2)
 
-    def deconv(name: str, bottom: str, ch: int, k: int, s: int, p: int) -> None:
-        body = ("  param { lr_mult: 0 decay_mult: 0 }\n  convolution_param {\n    num_output: %d\n    group: %d\n    bias_term: false\n"
-                "    pad: %d\n    kernel_size: %d\n    stride: %d\n    weight_filler { type: \"bilinear\" }\n  }") % (ch, ch, p, k, s)
-        w.layer(name, "Deconvolution", [bottom], [name], body)
 
-    w.layer("score_conv5_bbox", "Convolution", ["pool5"], ["score_conv5_bbox"], _conv_body(c4, 1, bias_value=0.0))
-    deconv("upscore_pool5_bbox", "score_conv5_bbox", c4, 8, 4, 2)
-    w.layer("score_conv5", "Convolution", ["pool5"], ["score_conv5"], _conv_body(num_classes, 1, bias_value=0.0))
-    deconv("upscore_pool5", "score_conv5", num_classes, 4, 2, 1)
-    w.layer("score_pool4", "Convolution", ["pool4"], ["score_pool4"], _conv_body(num_classes, 1, bias_value=0.0))
+def _fcn_bbox_scores(w: _Writer, num_classes: int) -> None:
+    w.layer("score_conv5", "Convolution", ["dropout5"], ["score_conv5"], _conv_body(num_classes, 1, explicit=True))
+    _frozen_bilinear_deconv(w, "upscore_pool5", "score_conv5", num_classes, 4, 2, 1)
+    w.layer("score_pool4", "Convolution", ["pool4"], ["score_pool4"], _conv_body(num_classes, 1, explicit=True))
     w.layer("fuse_pool4", "Eltwise", ["upscore_pool5", "score_pool4"], ["fuse_pool4"], "  eltwise_param { operation: SUM }")
-    deconv("upscore_pool4", "fuse_pool4", num_classes, 4, 2, 1)
-    w.layer("score_pool3", "Convolution", ["pool3"], ["score_pool3"], _conv_body(num_classes, 1, bias_value=0.0))
+    _frozen_bilinear_deconv(w, "upscore_pool4", "fuse_pool4", num_classes, 4, 2, 1)
+    w.layer("score_pool3", "Convolution", ["pool3"], ["score_pool3"], _conv_body(num_classes, 1, explicit=True))
     w.layer("fuse_pool3", "Eltwise", ["upscore_pool4", "score_pool3"], ["fuse_pool3"], "  eltwise_param { operation: SUM }")
-    deconv("upscore_pool3", "fuse_pool3", num_classes, 16, 8, 4)
+    _frozen_bilinear_deconv(w, "upscore_pool3", "fuse_pool3", num_classes, 16, 8, 4)
+
+
+def vgg16_fcn_bbox_train(module: str, layer: str, param_str: str, num_classes: int = 11) -> str:
+    """The reference's train/fcn_bbox/train_val.prototxt (the net HEAD's Python layer and the ROS node match): VGG16 ->
+    masked / normalised L1 loss on the x4-upsampled bbox map (stride 8) + SoftmaxWithLoss on the FCN-8s score map against
+    the full-resolution class mask the data layer emits as top[1]."""
+    w = _Writer()
+    tops = ["data", "label", "bbox-label", "size-block", "obj-block", "coverage-block"]
+    body = "  python_param {\n    module: '%s'\n    layer: '%s'\n    param_str: '%s'\n  }" % (module, layer, param_str)
+    w.layer("Argumentation", "Python", [], tops, body, quote="'")
+    _vgg16_body(w, "data")
+    _fcn_bbox_heads(w, num_classes)
+    prod = "  eltwise_param { operation: PROD }"
+    w.layer("bb-label-norm", "Eltwise", ["bbox-label", "size-block"], ["bbox-label-norm"], prod)
+    w.layer("bb-obj-norm", "Eltwise", ["bbox-label-norm", "obj-block"], ["bbox-obj-label-norm"], prod)
+    w.layer("bbox_mask", "Eltwise", ["upscore_pool5_bbox", "coverage-block"], ["bboxes-masked"], prod)
+    w.layer("bbox-norm", "Eltwise", ["bboxes-masked", "size-block"], ["bboxes-masked-norm"], prod)
+    w.layer("bbox-obj-norm", "Eltwise", ["bboxes-masked-norm", "obj-block"], ["bboxes-obj-masked-norm"], prod)
+    w.layer("bbox_loss", "L1Loss", ["bboxes-obj-masked-norm", "bbox-obj-label-norm"], ["loss_bbox"], extra="  loss_weight: 2.0")
+    _fcn_bbox_scores(w, num_classes)
+    w.layer("loss", "SoftmaxWithLoss", ["upscore_pool3", "label"], ["loss"], "  loss_param { normalize: false }")
+    return w.text()
+
+
+def vgg16_fcn_bbox_deploy(batch: int = 1, height: int = 448, width: int = 448, num_classes: int = 11) -> str:
+    """Inference form of train/fcn_bbox: the node (scripts/fcn_object_detector.py:89-90) reads ``pool_score`` (class
+    probabilities at stride 8: Softmax of ``fuse_pool3``) and ``upscore_pool5_bbox``."""
+    w = _Writer()
+    w.raw('input: "data"\ninput_shape {\n  dim: %d\n  dim: 3\n  dim: %d\n  dim: %d\n}' % (batch, height, width))
+    _vgg16_body(w, "data")
+    _fcn_bbox_heads(w, num_classes)
+    _fcn_bbox_scores(w, num_classes)
+    w.layer("pool_score", "Softmax", ["fuse_pool3"], ["pool_score"])
     return w.text()

@@ -152,14 +152,14 @@ class Solver(object):
             it = self.iter
             self._feed()
             out = self.engine.step()
-            self._losses.append(out["loss"])
+            self._losses.append(out["total_loss"])
             if p.display and it % p.display == 0:
                 self.log("Iteration %d, loss = %g" % (it, sum(self._losses) / len(self._losses)))
                 for j, (name, w) in enumerate(self.engine.loss_blobs.items()):
                     self.log("    Train net output #%d: %s = %g (* %g = %g loss)" % (j, name, out[name], w, w * out[name]))
                 self.log("Iteration %d, lr = %g" % (it, p.rate(it)))
-            if not np.isfinite(out["loss"]):
-                raise FloatingPointError("loss is %r at iteration %d" % (out["loss"], it))
+            if not np.isfinite(out["total_loss"]):
+                raise FloatingPointError("loss is %r at iteration %d" % (out["total_loss"], it))
             if p.snapshot and self.iter % p.snapshot == 0:
                 self.snapshot()
         return out

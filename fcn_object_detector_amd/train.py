@@ -184,7 +184,7 @@ class TrainEngine(Engine):
             t = l.type
             if t in DATA_TYPES or t in ("Concat", "Slice") or (t == "ReLU" and l.name in self._fused_relu_layers()):
                 continue
-            if t in ("L1Loss", "EuclideanLoss"):
+            if t in ("L1Loss", "EuclideanLoss", "SoftmaxWithLoss"):
                 g = G.get(l.bottoms[0])
                 if g is None:
                     continue
@@ -262,6 +262,25 @@ class TrainEngine(Engine):
                                   lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops))
                     mark(gbot)
                 continue
+            if t == "Eltwise" and str(l.sub("eltwise_param").get("operation", "SUM")) == "SUM":
+                p = l.sub("eltwise_param")
+                # d(bottom_i) = dY for every bottom (train/fcn_bbox fuse_pool4 / fuse_pool3: skip connections)
+                if any(float(c) != 1.0 for c in p.getall("coeff")):
+                    raise NotImplementedError("Eltwise SUM backward with coefficients (%s)" % l.name)
+                for bn in l.bottoms:
+                    gb = G.get(bn)
+                    if gb is None:
+                        continue
+                    if state(gb) == "full":
+                        if gtop.coffset or gb.coffset or gb.cstride != gtop.cstride:
+                            raise NotImplementedError("Eltwise SUM backward accumulating into a channel slice")
+                        ops.append(Op("eltwise_bwd", l.name + ":" + bn, lambda st, a=gtop, b=gb: L.check(lib.fcn_eltwise_fwd_f32(
+                            a.ptr, b.ptr, b.ptr, a.pixels * a.cstride, L.ELT_SUM, 1.0, 1.0, st))))
+                    else:
+                        ops.append(Op("eltwise_bwd", l.name + ":" + bn, lambda st, a=gtop, b=gb: L.check(lib.fcn_copy_channels_f32(
+                            a.buf.ptr, b.buf.ptr, a.pixels, a.channels, a.cstride, a.coffset, b.cstride, b.coffset, st))))
+                    mark(gb)
+                continue
             gbot = G.get(l.bottoms[0]) if l.bottoms else None
             if gbot is None:
                 continue
@@ -297,7 +316,8 @@ class TrainEngine(Engine):
                     self.dropout_index_offset, st))))
             elif t == "Eltwise":
                 p = l.sub("eltwise_param")
-                if str(p.get("operation", "SUM")) != "PROD" or len(l.bottoms) != 2:
+                opname = str(p.get("operation", "SUM"))
+                if opname != "PROD" or len(l.bottoms) != 2:
                     raise NotImplementedError("backward of Eltwise %s" % l.name)
                 if l.bottoms[1] in self.need_grad:
                     raise NotImplementedError("Eltwise PROD backward w.r.t. both bottoms (%s)" % l.name)
@@ -309,6 +329,18 @@ class TrainEngine(Engine):
                     raise NotImplementedError("Eltwise backward on channel slices")
                 ops.append(Op("eltwise_bwd", l.name, lambda st, a=gtop, o=other, b=gbot, n=count: L.check(lib.fcn_eltwise_fwd_f32(
                     a.ptr, o.ptr, b.ptr, n, L.ELT_PROD, 1.0, 1.0, st))))
+            elif t == "Deconvolution":
+                if any(m != 0.0 for m in l.lr_mult) or not l.lr_mult:
+                    raise NotImplementedError("learnable Deconvolution %s (the reference freezes its bilinear upsampling, lr_mult 0)" % l.name)
+                p = l.sub("convolution_param")
+                k, s, pad = kernel_stride_pad(p)
+                xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+                n, c, h, w = xb.shape
+                _, _, oh, ow = yb.shape
+                wdev = self.params_dev[l.name][0].ptr
+                ops.append(Op("deconv_bwd", l.name, lambda st, a=gtop, b=gbot, g=(n, h, w, c, k, s, pad, oh, ow), acc=acc, wdev=wdev: L.check(
+                    lib.fcn_deconv_depthwise_bwd_f32(a.buf.ptr, wdev, b.ptr, g[0], g[1], g[2], g[3], b.cstride, g[4], g[5], g[6], g[7], g[8],
+                                                     a.cstride, a.coffset, acc, st))))
             elif t == "Sigmoid":
                 yb = B[l.tops[0]]
                 ops.append(Op("sigmoid_bwd", l.name, lambda st, y=yb, a=gtop, b=gbot, acc=acc: L.check(
@@ -413,7 +445,8 @@ class TrainEngine(Engine):
     def step(self, seed: Optional[int] = None, upload: bool = True) -> Dict[str, float]:
         """Solver::Step for one iteration.  Inputs come from the input blobs' host arrays (upload=True), except label
         blobs staged with set_targets(), which are generated on the device; upload=False reuses what is already in HBM.
-        Returns {loss blob: value} plus 'loss' = sum of loss_weight * value (what `caffe train` prints)."""
+        Returns {loss blob: value} plus 'total_loss' = sum of loss_weight * value (what `caffe train` prints; also under
+        'loss' when no blob has that name)."""
         lib = L.load()
         with self.lock:
             L.call("fcn_init", self.device)
@@ -451,7 +484,8 @@ class TrainEngine(Engine):
                 for nm in self._tgt["tops"]:
                     self.blobs[nm].host_valid = False      # generated in HBM, never on the host
             out = {k: float(v[0]) for k, v in self.loss_host.items()}
-            out["loss"] = float(sum(self.loss_blobs[k] * out[k] for k in self.loss_blobs))
+            out["total_loss"] = float(sum(self.loss_blobs[k] * out[k] for k in self.loss_blobs))
+            out.setdefault("loss", out["total_loss"])      # shorthand, unless a blob is itself called "loss" (train/fcn_bbox)
             self.iter += 1
             return out
 

@@ -157,6 +157,8 @@ int  fcn_copy_channels_f32(const float* src, float* dst, int pixels, int C, int 
                            int src_coffset, int dst_cstride, int dst_coffset, fcn_stream_t s);
 /* grouped bilinear-style Deconvolution, group == channels, one filter [k][k] per channel:
  * Caffe DeconvolutionLayer with `group: C` as in train/fcn_bbox/train_val.prototxt:544-565 */
+/* Softmax over the channels of every pixel (Caffe SoftmaxLayer, axis 1) */
+int  fcn_softmax_fwd_f32(const float* x, float* y, int pixels, int C, int x_cstride, int y_cstride, fcn_stream_t s);
 int  fcn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* bias, float* y,
                                   int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
                                   int OH, int OW, int y_cstride, int y_coffset, fcn_stream_t s);
@@ -246,6 +248,16 @@ int  fcn_dropout_f32(const float* x, float* y, int N, int C, int H, int W, int x
  * kind 1 = EuclideanLoss: loss = sum(a-b)^2/(2 num), da = (a-b) * weight/num.  da may be NULL; d_loss is one device float. */
 int  fcn_loss_f32(int kind, const float* a, const float* b, float* da, float* d_loss, int pixels, int C, int cstride, int num,
                   float weight, fcn_stream_t s);
+/* SoftmaxWithLoss (train/fcn_bbox/train_val.prototxt:838-847): x NHWC scores, label one float per pixel (class id);
+ * loss = -sum log p[label] / (valid pixels if normalize else N); dx (may be NULL) = (p - onehot) * weight / denom.
+ * d_workspace: fcn_softmax_loss_workspace_bytes() bytes, 8-byte aligned.  The reduction order is fixed. */
+size_t fcn_softmax_loss_workspace_bytes(void);
+int  fcn_softmax_loss_f32(const float* x, const float* label, float* dx, float* d_loss, int N, int pixels, int C, int x_cstride,
+                          int label_cstride, int normalize, int has_ignore, int ignore_label, float weight, void* d_workspace,
+                          fcn_stream_t s);
+/* Gradient w.r.t. the input of the depthwise deconvolution (fcn_deconv_depthwise_fwd_f32): H, W are the INPUT extents */
+int  fcn_deconv_depthwise_bwd_f32(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int dx_cstride, int k,
+                                  int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, fcn_stream_t s);
 /* Solver update over one flat parameter buffer cut into segments (one per learnable blob). */
 typedef struct fcn_solver_seg { uint64_t offset, count; float lr_mult, decay_mult; } fcn_solver_seg;
 /* SGD: g' = g*grad_scale + wd*decay_mult*w ; hist = momentum*hist + rate*lr_mult*g' ; w -= hist */

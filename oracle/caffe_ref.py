@@ -234,22 +234,43 @@ def euclidean_loss_grad(a: np.ndarray, b: np.ndarray, w: float = 1.0) -> np.ndar
     return ((a - b) * F32(w / a.shape[0])).astype(F32)
 
 
+def _softmax_loss_terms(x: np.ndarray, label: np.ndarray, ignore_label: Optional[int]):
+    p = softmax(x, 1)
+    n, c = x.shape[:2]
+    lab = label.reshape(n, 1, -1).astype(np.int64)
+    valid = np.ones(lab.shape, bool) if ignore_label is None else (lab != ignore_label)
+    lab_c = np.clip(lab, 0, c - 1)
+    return p, lab_c, valid
+
+
 def softmax_loss(x: np.ndarray, label: np.ndarray, normalize: bool = True,
                  ignore_label: Optional[int] = None) -> float:
-    """Caffe SoftmaxWithLoss (legacy `normalize` flag): -sum log p[label] / (count_valid if normalize else N)."""
-    p = softmax(x, 1).astype(np.float64)
+    """Caffe SoftmaxWithLoss (legacy `normalize` flag): -sum log p[label] / (count_valid if normalize else N)
+    (softmax_loss_layer.cpp Forward_cpu: prob clamped at FLT_MIN before the log)."""
+    p, lab, valid = _softmax_loss_terms(x, label, ignore_label)
     n, c = x.shape[:2]
-    lab = label.reshape(n, -1).astype(np.int64)
-    pr = p.reshape(n, c, -1)
-    loss, cnt = 0.0, 0
-    for i in range(n):
-        for j in range(lab.shape[1]):
-            l_ = lab[i, j]
-            if ignore_label is not None and l_ == ignore_label:
-                continue
-            loss -= math.log(max(pr[i, l_, j], np.finfo(F32).tiny))
-            cnt += 1
-    return loss / (max(cnt, 1) if normalize else n)
+    pl = np.take_along_axis(p.reshape(n, c, -1), lab, axis=1)
+    terms = -np.log(np.maximum(pl, np.finfo(F32).tiny).astype(F32)).astype(np.float64)
+    cnt = int(valid.sum())
+    return float((terms * valid).sum() / (max(cnt, 1) if normalize else n))
+
+
+def softmax_loss_grad(x: np.ndarray, label: np.ndarray, normalize: bool = True, ignore_label: Optional[int] = None,
+                      w: float = 1.0) -> np.ndarray:
+    """Backward_cpu: (p - onehot(label)) * loss_weight / denom, zero at ignored pixels."""
+    p, lab, valid = _softmax_loss_terms(x, label, ignore_label)
+    n, c = x.shape[:2]
+    g = p.reshape(n, c, -1).copy()
+    np.put_along_axis(g, lab, np.take_along_axis(g, lab, axis=1) - F32(1.0), axis=1)
+    g = g * valid
+    denom = max(int(valid.sum()), 1) if normalize else n
+    return (g * F32(w / denom)).reshape(x.shape).astype(F32)
+
+
+def deconv2d_backward_data(dy: np.ndarray, w: np.ndarray, pad: int, stride: int, group: int = 1) -> np.ndarray:
+    """Deconvolution backward w.r.t. the input = the forward convolution of dY with the same blob
+    (deconv weights are (Cin, Cout/g, kh, kw) = a conv bank with num_output Cin)."""
+    return conv2d(dy, w, None, pad, stride, group)
 
 
 # --------------------------------------------------------------------------

@@ -245,7 +245,11 @@ class RefNet:
                 acc(bots[1], -g)
                 continue
             if t == "SoftmaxWithLoss":
-                raise NotImplementedError("oracle backward: SoftmaxWithLoss")
+                lp = l.get("loss_param")
+                norm = bool(lp.get("normalize", True)) if lp else True
+                ign = lp.get("ignore_label", None) if lp else None
+                acc(bots[0], R.softmax_loss_grad(B[bots[0]], B[bots[1]], norm, ign, lw.get(tops[0], 0.0)))
+                continue
             if tops[0] not in D:
                 continue   # nothing flows back through this layer
             dy = D[tops[0]]
@@ -257,6 +261,13 @@ class RefNet:
                 grads[name] = [dw] + ([db] if len(self.params[name]) > 1 else [])
                 if need_dx:
                     acc(bots[0], dx)
+            elif t == "Deconvolution":
+                # the reference freezes its (bilinear) deconvolutions (lr_mult 0): only the data gradient is restated
+                p = l.get("convolution_param")
+                k, s, pad = _ksp(p)
+                grads[name] = [np.zeros_like(a) for a in self.params[name]]
+                if bots[0] not in data_tops and self._needs_grad(bots[0], data_tops):
+                    acc(bots[0], R.deconv2d_backward_data(dy, self.params[name][0], pad, s, int(p.get("group", 1))))
             elif t == "ReLU":
                 g = dy * (B[tops[0]] > 0)
                 if bots[0] == tops[0]:

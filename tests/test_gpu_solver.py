@@ -129,3 +129,17 @@ def test_pycaffe_solver_entry_points(gpu, tmp_path):
     w = s.net.params["conv1/7x7_s2"][0].data
     assert w.shape == (64, 3, 7, 7) and np.isfinite(w).all()
     s.close()
+
+
+def test_caffe_train_tool_on_the_fcn_bbox_net(gpu, tmp_path):
+    """train/fcn_bbox (VGG16 + SoftmaxWithLoss on the class mask the data layer emits as top[1], HEAD's 6-field param_str)."""
+    net = tmp_path / "train_val.prototxt"
+    net.write_text(models.vgg16_fcn_bbox_train("data_argumentation_layer", "DataArgumentationLayer", "64,64,8,3,2,synthetic:2", num_classes=3))
+    solver = tmp_path / "solver.prototxt"
+    solver.write_text('net: "%s"\nsnapshot_prefix: "%s"\ndisplay: 1\naverage_loss: 20\nlr_policy: "fixed"\nbase_lr: 1e-10\nmomentum: 0.90\n'
+                      'iter_size: 1\nmax_iter: 2\nweight_decay: 1e-7\nsnapshot: 10000\nsolver_mode: GPU\n' % (net, tmp_path / "snap"))
+    r = run_tool(["train", "--solver=%s" % solver, "--gpu=0"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "Train net output #0: loss_bbox" in r.stderr and "Train net output #1: loss = " in r.stderr
+    assert "Iteration 1, loss = " in r.stderr and "Optimization Done." in r.stderr
+    assert os.path.isfile(str(tmp_path / "snap_iter_2.caffemodel"))

@@ -155,3 +155,30 @@ def test_solver_matches_torch_optim(kind):
         for a, p in zip(net.params[k], P[k]):
             assert np.abs(a - p.detach().numpy()).max() < 2e-4 * max(np.abs(a).max(), 1e-6), k
     assert losses[-1] < losses[0]
+
+
+def test_softmax_loss_and_deconvolution_backward_against_torch():
+    """The two backward restatements the VGG-FCN nets add (train/fcn_bbox/train_val.prototxt:544-565,838-847)."""
+    import torch
+    from oracle import caffe_ref as R
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 5, 4, 3)).astype(np.float32)
+    lab = rng.integers(0, 5, (2, 1, 4, 3)).astype(np.float32)
+    xt = torch.tensor(x, requires_grad=True)
+    tl = torch.tensor(lab[:, 0]).long()
+    for norm in (True, False):
+        loss = torch.nn.functional.cross_entropy(xt, tl, reduction="sum") / (24 if norm else 2)
+        g, = torch.autograd.grad(loss, xt)
+        assert abs(R.softmax_loss(x, lab, norm) - loss.item()) < 1e-6
+        assert np.abs(R.softmax_loss_grad(x, lab, norm, None, 1.0) - g.numpy()).max() < 1e-7
+    loss = torch.nn.functional.cross_entropy(xt, tl, reduction="sum", ignore_index=2) / max(int((lab != 2).sum()), 1)
+    g, = torch.autograd.grad(loss, xt)
+    assert abs(R.softmax_loss(x, lab, True, 2) - loss.item()) < 1e-6
+    assert np.abs(R.softmax_loss_grad(x, lab, True, 2, 1.0) - g.numpy()).max() < 1e-7
+    w = R.bilinear_filler((6, 1, 4, 4))
+    xi = rng.standard_normal((2, 6, 5, 4)).astype(np.float32)
+    xt = torch.tensor(xi, requires_grad=True)
+    y = torch.nn.functional.conv_transpose2d(xt, torch.tensor(w), None, stride=2, padding=1, groups=6)
+    dy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    g, = torch.autograd.grad(y, xt, torch.tensor(dy))
+    assert np.abs(R.deconv2d_backward_data(dy, w, 1, 2, 6) - g.numpy()).max() < 1e-5

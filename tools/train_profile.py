@@ -27,7 +27,7 @@ def main():
     eng.upload_inputs()
     for it in range(2):
         eng.set_targets(*synth_boxes(np.random.default_rng(it), n), stride=16)
-        print("loss", eng.step(seed=it, upload=False)["loss"])
+        print("loss", eng.step(seed=it, upload=False)["total_loss"])
     tot = {}
     for label, ops in (("fwd", eng.ops), ("bwd", eng.bwd_ops)):
         rows = eng.time_ops(reps=5, ops=ops)
