@@ -16,6 +16,7 @@ blob mapping is a parameter (:class:`HeadMapping`) with both presets.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -158,6 +159,23 @@ def generate_targets(rects_per_image: Sequence[Sequence[Sequence[int]]], labels_
         L.call("fcn_memcpy_d2h_async", o.ctypes.data, d.ptr, o.nbytes, None)
     L.call("fcn_device_sync")
     return tuple(outs)
+
+
+def load_label_manifest(path: Optional[str], num_outputs: int = 0) -> List[str]:
+    """Class names for the detections (scripts/fcn_object_detector.py:441-461).  The node expects three fields per line
+    (`idx <anything> name`); the data layer writes two (`index label`, data_argumentation_layer.py:181-188) - both are read.
+    Without a file the node's fallback names `object_<k-1>` are produced."""
+    if path is None or not os.path.isfile(str(path)):
+        return ["object_%d" % (i - 1) for i in range(num_outputs)]
+    names = []
+    with open(path) as f:
+        for line in f:
+            parts = line.rstrip("\n").split(" ")
+            if len(parts) >= 3:
+                names.append(parts[2])
+            elif len(parts) == 2:
+                names.append(parts[1])
+    return names
 
 
 def resize_detection(in_size: Sequence[int], boxes: np.ndarray, net_w: int, net_h: int) -> np.ndarray:

@@ -222,3 +222,40 @@ def vgg16_fcn_bbox_deploy(batch: int = 1, height: int = 448, width: int = 448, n
     _fcn_bbox_scores(w, num_classes)
     w.layer("pool_score", "Softmax", ["fuse_pool3"], ["pool_score"])
     return w.text()
+
+
+def vgg16_bounding_box_train(module: str, layer: str, param_str: str, num_classes: int = 11) -> str:
+    """The reference's train/bounding_box/train_val.prototxt (solver: ADAM, step policy): VGG16 with conv1_1..conv3_3
+    frozen (lr_mult 0), no ReLU after conv5_3, a frozen x2 bilinear deconvolution back to stride 8, dropout, the
+    DetectNet coverage / bbox heads and their L1 + Euclidean losses."""
+    w = _Writer()
+    tops = ["data", "coverage-label", "bbox-label", "size-block", "obj-block", "coverage-block"]
+    body = "  python_param {\n    module: '%s'\n    layer: '%s'\n    param_str: '%s'\n  }" % (module, layer, param_str)
+    w.layer("Argumentation", "Python", [], tops, body, quote="'")
+    prod = "  eltwise_param { operation: PROD }"
+    w.layer("bb-label-norm", "Eltwise", ["bbox-label", "size-block"], ["bbox-label-norm"], prod)
+    w.layer("bb-obj-norm", "Eltwise", ["bbox-label-norm", "obj-block"], ["bbox-obj-label-norm"], prod)
+    prev = "data"
+    for blk, n, width_ in VGG16:
+        frozen = blk <= 3
+        for i in range(1, n + 1):
+            nm = "conv%d_%d" % (blk, i)
+            w.layer(nm, "Convolution", [prev], [nm], _conv_body(width_, 3, 1, bias_value=0.0, lr=(0.0, 0.0) if frozen else (1.0, 2.0),
+                                                                decay=(0.0, 0.0) if frozen else (1.0, 0.0)))
+            if (blk, i) != (5, 3):
+                w.layer("relu%d_%d" % (blk, i), "ReLU", [nm], [nm])
+            prev = nm
+        if blk < 5:
+            w.layer("pool%d" % blk, "Pooling", [prev], ["pool%d" % blk], "  pooling_param { pool: MAX kernel_size: 2 stride: 2 }")
+            prev = "pool%d" % blk
+    _frozen_bilinear_deconv(w, "conv5_3/upsample", "conv5_3", 512, 4, 2, 1)
+    w.layer("dropout5", "Dropout", ["conv5_3/upsample"], ["dropout5"], "  dropout_param { dropout_ratio: 0.5 }")
+    w.layer("cvg/classifier", "Convolution", ["dropout5"], ["cvg/classifier"], _conv_body(num_classes, 1, bias_value=0.0))
+    w.layer("coverage/sig", "Sigmoid", ["cvg/classifier"], ["coverage"])
+    w.layer("bbox/regressor", "Convolution", ["dropout5"], ["bboxes"], _conv_body(4 * num_classes, 1, bias_value=0.0))
+    w.layer("bbox_mask", "Eltwise", ["bboxes", "coverage-block"], ["bboxes-masked"], prod)
+    w.layer("bbox-norm", "Eltwise", ["bboxes-masked", "size-block"], ["bboxes-masked-norm"], prod)
+    w.layer("bbox-obj-norm", "Eltwise", ["bboxes-masked-norm", "obj-block"], ["bboxes-obj-masked-norm"], prod)
+    w.layer("bbox_loss", "L1Loss", ["bboxes-obj-masked-norm", "bbox-obj-label-norm"], ["loss_bbox"], extra="  loss_weight: 2.0")
+    w.layer("coverage_loss", "EuclideanLoss", ["coverage", "coverage-label"], ["loss_coverage"])
+    return w.text()

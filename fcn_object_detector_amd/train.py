@@ -76,13 +76,22 @@ class TrainEngine(Engine):
         self._build_backward()
 
     # ------------------------------------------------------------------ gradient buffers
+    def _learns(self, l: Layer) -> bool:
+        """True if the solver will move any blob of this layer: Caffe's param_propagate_down (lr_mult != 0)."""
+        if l.name not in self.spec.param_shapes:
+            return False
+        n = len(self.spec.param_shapes[l.name])
+        return any((l.lr_mult[i] if i < len(l.lr_mult) else 1.0) != 0.0 for i in range(n))
+
     def _needs_grad(self) -> set:
-        """Blobs downstream of a learnable layer (Caffe's propagate_down): only those carry gradients."""
+        """Blobs downstream of a layer that learns (Caffe's propagate_down): only those carry gradients.  Frozen layers
+        (lr_mult 0: conv1_1..conv3_3 of train/bounding_box, every bilinear deconvolution) neither get a weight gradient
+        nor pull the backward pass below them."""
         need = set()
         for l in self.spec.layers:
             if l.type in DATA_TYPES:
                 continue
-            if l.name in self.spec.param_shapes or any(b in need for b in l.bottoms):
+            if self._learns(l) or any(b in need for b in l.bottoms):
                 need.update(l.tops)
         return need
 
@@ -227,13 +236,14 @@ class TrainEngine(Engine):
                 d.y_cstride, d.y_coffset = gtop.cstride, gtop.coffset
                 if gtop.coffset % 4 or gtop.cstride % 4:
                     raise NotImplementedError("gradient view of %s is not 16-byte aligned" % l.tops[0])
-                ws_floats = max(ws_floats, int(lib.fcn_conv2d_wgrad_workspace_floats(C.byref(d), None)))
-                dw = self._grad_view(l.name, 0)
-                db = self._grad_view(l.name, 1) if len(self.params_dev[l.name]) > 1 else None
-                self._keep.append(d)
                 flops = 2.0 * n * cout * oh * ow * cin * k * k
-                ops.append(Op("wgrad", l.name, lambda st, d=d, dw=dw, db=db: L.check(lib.fcn_conv2d_wgrad_f32(
-                    C.byref(d), dw.ptr, db.ptr if db else None, self._ws.ptr, st)), flops))
+                if self._learns(l):
+                    ws_floats = max(ws_floats, int(lib.fcn_conv2d_wgrad_workspace_floats(C.byref(d), None)))
+                    dw = self._grad_view(l.name, 0)
+                    db = self._grad_view(l.name, 1) if len(self.params_dev[l.name]) > 1 else None
+                    self._keep.append(d)
+                    ops.append(Op("wgrad", l.name, lambda st, d=d, dw=dw, db=db: L.check(lib.fcn_conv2d_wgrad_f32(
+                        C.byref(d), dw.ptr, db.ptr if db else None, self._ws.ptr, st)), flops))
                 gbot = G.get(l.bottoms[0])
                 if gbot is not None:
                     if s != 1:

@@ -127,3 +127,18 @@ def test_reference_module_name_resolves():
         assert m.DataArgumentationLayer is D.DataArgumentationLayer
     finally:
         sys.path.pop(0)
+
+
+def test_label_manifest_round_trip(tmp_path):
+    from fcn_object_detector_amd.detector import load_label_manifest
+    fn = tmp_path / "train.txt"
+    with open(fn, "w") as f:
+        for lab in (12, 5, 12, 9):
+            f.write("a.jpg m.png %d 1 2 3 4\n\n" % lab)
+    D.read_data_from_textfile2(str(fn), manifest_dir=str(tmp_path / "labels"))
+    manifest = os.path.join(str(tmp_path / "labels"), os.listdir(tmp_path / "labels")[0])
+    assert load_label_manifest(manifest) == ["5", "9", "12"]             # the data layer's 2-field lines
+    three = tmp_path / "three.txt"
+    three.write_text("1 0 mug\n2 0 bottle\n")
+    assert load_label_manifest(str(three)) == ["mug", "bottle"]          # the node's 3-field lines
+    assert load_label_manifest(None, 3) == ["object_-1", "object_0", "object_1"]

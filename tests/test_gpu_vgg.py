@@ -155,3 +155,53 @@ def test_fcn_bbox_deploy_forward_and_detection_heads(gpu):
         assert rel_err(eng.read_blob(name), ref.blobs[name]) < 1e-3, name
     assert np.allclose(out["pool_score"].sum(axis=1), 1.0, atol=1e-5)
     eng.close()
+
+
+def test_bounding_box_train_net_frozen_layers_and_adam(gpu):
+    """train/bounding_box/train_val.prototxt at reduced size: conv1_1..conv3_3 frozen (lr_mult 0) get no weight gradient and
+    the backward pass stops above them (Caffe's propagate_down); the rest matches the oracle; Adam moves only what learns."""
+    classes, n, size = 2, 2, 64
+    msg = proto.parse_text(models.vgg16_bounding_box_train("m", "L", "unused", num_classes=classes))
+    rng = np.random.default_rng(6)
+    data = _vgg_batch(rng, n, size, classes)
+    data["coverage-label"] = (data["coverage-block"][:, ::4] > 0).astype(np.float32)
+    del data["label"]
+    shapes = {k: v.shape for k, v in data.items()}
+    spec = NetSpec(msg, "TRAIN")
+    spec.infer(shapes)
+    params = fill_params(spec, seed=5)
+    eng = TrainEngine(NetSpec(msg, "TRAIN"), shapes, params={k: [a.copy() for a in v] for k, v in params.items()}, device=0,
+                      solver=SolverParams(base_lr=1e-4, momentum=0.9, momentum2=0.999, solver_type="ADAM", lr_policy="step", gamma=0.1,
+                                          stepsize=10000), autotune=False)
+    kinds = [(op.kind, op.name.split(" ")[0]) for op in eng.bwd_ops]
+    wg = {nm for k, nm in kinds if k == "wgrad"}
+    assert "conv4_1" in wg and "cvg/classifier" in wg and not any(nm.startswith(("conv1_", "conv2_", "conv3_")) for nm in wg)
+    assert not any(k == "dgrad" and nm.startswith(("conv4_1", "conv3_", "conv2_", "conv1_")) for k, nm in kinds)
+    assert "pool3" not in eng.grad_blobs and "conv4_1" in eng.grad_blobs
+    ref = RefNet(msg, "TRAIN", {k: [a.copy() for a in v] for k, v in params.items()})
+    for k, v in data.items():
+        eng.host_array(k)[...] = v
+    out = eng.step(seed=9)
+    ref.blobs.update(data)
+    ref.dropout_seed = 9
+    ref.forward()
+    assert abs(out["total_loss"] - ref.total_loss()) < 1e-3 * abs(ref.total_loss())
+    for name in ("conv5_3/upsample", "coverage", "bboxes"):
+        assert rel_err(eng.read_blob(name), ref.blobs[name]) < 1e-3, name
+    for name in list(ref.blobs):
+        if name in eng.blobs and len(eng.blobs[name].shape) == 4 and name not in data:
+            ref.blobs[name] = eng.read_blob(name).copy()
+    for l in spec.layers:
+        if l.type == "Pooling":
+            ref.aux[l.name] = R.max_pool(ref.blobs[l.bottoms[0]], 2, 2, 0, return_index=True)[1]
+    grads = ref.backward()
+    got = eng.download_grads()
+    for name in ("conv4_1", "conv5_3", "cvg/classifier", "bbox/regressor"):
+        for g, r in zip(got[name], grads[name]):
+            assert rel_err(g, r) < 2e-4, name
+    assert not np.any(got["conv3_3"][0]) and not np.any(got["conv1_1"][0])
+    after = eng.download_params()
+    for name in ("conv1_1", "conv3_3", "conv5_3/upsample"):
+        assert np.array_equal(after[name][0], params[name][0]), name
+    assert not np.array_equal(after["conv4_1"][0], params["conv4_1"][0])
+    eng.close()

@@ -135,6 +135,17 @@ def test_builder_equals_reference_fcn_bbox_train():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+def test_builder_equals_reference_bounding_box_train():
+    ref = proto.parse_file(os.path.join(REF, "train/bounding_box/train_val.prototxt"))
+    param_str = [l for l in ref.getall("layer") if l.get("type") == "Python"][0].get("python_param").get("param_str")
+    a = _signature(ref, "TRAIN")
+    b = _signature(proto.parse_text(models.vgg16_bounding_box_train("data_argumentation_layer", "DataArgumentationLayer", param_str)), "TRAIN")
+    assert len(a[1]) == len(b[1]) == 42
+    for x, y in zip(a[1], b[1]):
+        assert x == y
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
 def test_all_reference_prototxts_parse():
     for rel in ("models/deploy.prototxt", "models/train_val.prototxt", "models/train_val2.prototxt",
                 "train/fcn_bbox/train_val.prototxt", "train/bounding_box/train_val.prototxt",
