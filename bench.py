@@ -130,6 +130,66 @@ def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
     return res
 
 
+def bench_vgg(steps: int = 5):
+    """The reference's secondary net train/fcn_bbox (VGG16 + FCN-8s scores + x4 bilinear bbox branch):
+    forward of its inference form at 448x448 and one training step at its native shape (288x288, stride 8, 11 classes,
+    batch 24 as in the reference's param_str).  3x3 convolutions with large M: what the convolution kernels sustain
+    when the launches are not latency-bound."""
+    from fcn_object_detector_amd import lib as L, models, proto
+    from fcn_object_detector_amd.engine import Engine
+    from fcn_object_detector_amd.netspec import NetSpec, fill_params
+    from fcn_object_detector_amd.train import SolverParams, TrainEngine
+
+    def conv_flops(spec, shapes):
+        f = 0.0
+        for l in spec.layers:
+            if l.type == "Convolution":
+                n, co, oh, ow = shapes[l.tops[0]]
+                k = int(l.sub("convolution_param").get("kernel_size"))
+                f += 2.0 * n * co * oh * ow * shapes[l.bottoms[0]][1] * k * k
+        return f
+
+    msg = proto.parse_text(models.vgg16_fcn_bbox_deploy(1, 448, 448, 11))
+    spec = NetSpec(msg, "TEST")
+    shapes = spec.infer()
+    eng = Engine(NetSpec(msg, "TEST"), params=fill_params(spec, seed=1), device=0)
+    eng.host_array("data")[...] = np.random.default_rng(0).random((1, 3, 448, 448), dtype=np.float32)
+    eng.upload_inputs()
+    eng.forward_resident(3)
+    ms = eng.forward_resident(20) / 20
+    fl = conv_flops(spec, shapes)
+    out = {"net": "train/fcn_bbox (VGG16-FCN), f32", "forward_448_b1": {"frames_per_s": round(1e3 / ms, 1), "ms_per_frame": round(ms, 3),
+           "gflop_per_frame": round(fl / 1e9, 2), "achieved_tflops": round(fl / ms / 1e9, 1), "frac_of_f32_mfma_peak": round(fl / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 3)}}
+    eng.close()
+    n, size, classes = 24, 288, 11
+    msg = proto.parse_text(models.vgg16_fcn_bbox_train("synthetic", "Boxes", "288,288,8,11,%d,none" % n, num_classes=classes))
+    shapes = {"data": (n, 3, size, size), "label": (n, 1, size, size)}
+    for k in ("bbox-label", "size-block", "obj-block", "coverage-block"):
+        shapes[k] = (n, 4 * classes, size // 8, size // 8)
+    spec = NetSpec(msg, "TRAIN")
+    full = spec.infer(shapes)
+    te = TrainEngine(NetSpec(msg, "TRAIN"), shapes, params=fill_params(spec, seed=2), device=0,
+                     solver=SolverParams(base_lr=1e-10, momentum=0.9, weight_decay=1e-7))
+    rng = np.random.default_rng(1)
+    te.host_array("data")[...] = rng.random((n, 3, size, size), dtype=np.float32)
+    te.host_array("label")[...] = rng.integers(0, classes, (n, 1, size, size)).astype(np.float32)
+    te.upload_inputs()
+    fl = conv_flops(spec, full)
+    for it in range(2):
+        te.step(seed=it, upload=False)
+    L.call("fcn_device_sync")
+    t0 = time.perf_counter()
+    for it in range(steps):
+        te.step(seed=10 + it, upload=False)
+    L.call("fcn_device_sync")
+    dt = (time.perf_counter() - t0) / steps
+    out["train_288_b24"] = {"imgs_per_s": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 2), "fwd_conv_gflop_per_step": round(fl / 1e9, 1),
+                            "achieved_tflops": round(3 * fl / dt / 1e12, 1), "frac_of_f32_mfma_peak": round(3 * fl / dt / 1e12 / F32_MFMA_PEAK_TFLOPS, 3),
+                            "note": "fwd + dgrad + wgrad counted as 3x the forward convolution FLOPs (conv1_1 has no dgrad)"}
+    te.close()
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,6 +201,7 @@ def main() -> None:
     ap.add_argument("--train-batch", type=int, default=8, help="images per GPU per training step (BASELINE configs[2]/[3])")
     ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (default: min(steps, 30))")
     ap.add_argument("--per-op", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the VGG16-FCN (train/fcn_bbox) measurements reported under 'secondary'")
     args = ap.parse_args()
 
     from fcn_object_detector_amd import dp, lib as L, models, proto
@@ -243,6 +304,22 @@ def main() -> None:
         tr = bench_train(cp, rank, world, local, args.train_batch, tsteps, max(min(args.warmup, 5), 2))
         if out is not None:
             out["train"] = tr
+    if out is not None and world == 1 and not args.no_secondary:
+        # the same DetectNet forward at batch 8 (not the headline configuration): M is 8x larger, launches stop being latency-bound
+        msg8 = proto.parse_text(models.googlenet_detectnet_deploy(8, 448, 448, 4))
+        spec8 = NetSpec(msg8, "TEST")
+        spec8.infer()
+        eng8 = Engine(NetSpec(msg8, "TEST"), params=fill_params(spec8, seed=1234), device=local)
+        eng8.host_array("data")[...] = np.random.default_rng(3).random((8, 3, 448, 448), dtype=np.float32)
+        eng8.upload_inputs()
+        eng8.forward_resident(3)
+        ms8 = eng8.forward_resident(20) / 20
+        ops8 = [o for o in eng8.time_ops(reps=5) if o[0].startswith("conv")]
+        conv8 = sum(o[3] for o in ops8) / (sum(o[2] for o in ops8) * 1e-3) / 1e12
+        out["forward_batch8"] = {"frames_per_s": round(8e3 / ms8, 1), "ms_per_step": round(ms8, 4), "conv_family_tflops": round(conv8, 2),
+                                 "conv_family_frac_of_f32_mfma_peak": round(conv8 / F32_MFMA_PEAK_TFLOPS, 4)}
+        eng8.close()
+        out["secondary"] = bench_vgg()
     cp.close()
     if out is not None:
         print(json.dumps(out))

@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 export FCN_TUNE_CACHE=$OUT/${TAG}_tune.json
-ARGS="--steps 50 --warmup 5 --no-cpu-baseline $*"
+ARGS="--steps 50 --warmup 5 --no-cpu-baseline --no-secondary $*"
 cd "$ROOT"
 python3 bench.py $ARGS > "$OUT/${TAG}_bench_plain.json"            # fills the tune cache: profiled runs replay the plan
 export TMPDIR=/tmp
