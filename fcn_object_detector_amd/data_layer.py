@@ -201,6 +201,7 @@ class DataArgumentationLayer(Layer):
     MAX_PLACEMENT_RETRIES = 100      # ArgumentationEngineMapping.__max_counter
     PLACEMENT_IOU = 0.05             # ArgumentationEngineMapping.__iou_thresh
     supports_device_targets = True   # forward() can stop at the boxes; the solver then builds the label grids in HBM
+    supports_device_scenes = True    # bind_device(): scenes are composed and normalised on the device
 
     def setup(self, bottom, top):
         if len(bottom) > 0:
@@ -223,8 +224,10 @@ class DataArgumentationLayer(Layer):
                 raise ValueError("Provide the dataset textfile")
             self.dataset = True
         bg = _load_image(os.environ.get("FCN_BACKGROUND", ""))
+        if bg is None:      # the reference hard-codes a JPEG path (:86); without one, a seeded noise image plays the background
+            bg = np.random.default_rng(1234).integers(0, 256, (960, 1280, 3), dtype=np.uint8)
         self.background = bg
-        self._noise = np.random.default_rng(1234)
+        self._sources = {}
         if self.randomize:
             random.seed(int(os.environ["FCN_DATA_SEED"])) if "FCN_DATA_SEED" in os.environ else random.seed()
 
@@ -240,18 +243,30 @@ class DataArgumentationLayer(Layer):
         for i in range(2, 6):
             top[i].reshape(n, ch, gy, gx)
 
-    # -- scene synthesis: ArgumentationEngineMapping.argument (argumentation_engine.py:651-746), vectorised paste -----
-    def _object(self):
+    # -- scene synthesis: ArgumentationEngineMapping.argument (argumentation_engine.py:651-746) -------------------------
+    # The random DECISIONS (plan_scene) are separate from the pixel work, which has two renderers that produce the
+    # same bytes: numpy on the host (render_host) and one kernel launch per sample on the device (DeviceRenderer).
+    SCENE_H, SCENE_W = 480, 640      # the reference composes at the background's 640x480 and resizes to the net input later
+
+    def _source(self, idx: int):
+        """(image uint8 HxWx3 BGR, mask uint8 HxW in {0,255}, label, rect) of dataset entry idx, cached on the host."""
+        hit = self._sources.get(idx)
+        if hit is not None:
+            return hit
         if self.dataset is None:
-            tex, mask, label = self.objects.items[random.randint(0, len(self.objects.items) - 1)]
+            tex, mask, label = self.objects.items[idx]
             h, w = mask.shape
-            return tex.copy(), np.repeat(mask[:, :, None], 3, axis=2), label, np.array([0, 0, w, h])
-        idx = random.randint(0, len(self.img_paths) - 1)
-        image, mask = _load_image(self.img_paths[idx]), _load_image(self.mask_imgs[idx])
-        if image is None or mask is None:
-            raise IOError("cannot read %s / %s" % (self.img_paths[idx], self.mask_imgs[idx]))
-        mask = np.where(mask > 0, 255, 0).astype(np.uint8)
-        return image, mask, int(self.labels[idx]), self.rects[idx].copy()
+            item = (tex, mask, label, np.array([0, 0, w, h]))
+        else:
+            image, mask = _load_image(self.img_paths[idx]), _load_image(self.mask_imgs[idx])
+            if image is None or mask is None:
+                raise IOError("cannot read %s / %s" % (self.img_paths[idx], self.mask_imgs[idx]))
+            item = (image, np.where(mask[:, :, 0] > 0, 255, 0).astype(np.uint8), int(self.labels[idx]), self.rects[idx].copy())
+        self._sources[idx] = item
+        return item
+
+    def _num_sources(self) -> int:
+        return len(self.objects.items) if self.dataset is None else len(self.img_paths)
 
     def _iou(self, a, b) -> float:
         x, y = max(a[0], b[0]), max(a[1], b[1])
@@ -264,25 +279,29 @@ class DataArgumentationLayer(Layer):
             ratio = np.float32(a[2] * a[3]) / np.float32(b[2] * b[3])
             return float(np.float32(w * h) / np.float32(uw * uh) / ratio)
 
-    def synthesize(self, num_proposals: int, im_bg: np.ndarray):
-        im_y, im_x = im_bg.shape[:2]
-        img_out = im_bg.copy()
-        mask_out = np.zeros((im_y, im_x, 1), np.uint8)
-        placed: List[np.ndarray] = []
-        labels: List[int] = []
-        for _ in range(num_proposals):
-            image, mask, label, rect = self._object()
+    def plan_scene(self) -> dict:
+        """All random draws of one sample, in the reference's order: background crop, number of objects, per object
+        (entry, flip, rescale, position with up to 100 retries against the boxes already placed), whole-image flip."""
+        im_y, im_x = self.SCENE_H, self.SCENE_W
+        bgh, bgw = self.background.shape[:2]
+        hh, ww = bgh // 2, bgw // 2
+        bx, by = random.randint(0, ww), random.randint(0, hh)
+        bx = bx - (bx + ww - bgw) if bx + ww > bgw else bx
+        by = by - (by + hh - bgh) if by + hh > bgh else by
+        objs, placed, labels = [], [], []
+        for _ in range(random.randint(1, 3)):
+            idx = random.randint(0, self._num_sources() - 1)
+            image, _mask, label, rect = self._source(idx)
+            sh, sw = image.shape[:2]
             flip_flag = random.randint(-1, 2)
             if -2 < flip_flag < 2:
-                rect = np.array(flip_rects(image.shape[:2], [rect], flip_flag)[0])
-                image, mask = flip_image(image, flip_flag), flip_image(mask, flip_flag)
+                rect = np.array(flip_rects((sh, sw), [rect], flip_flag)[0])
             x, y, w, h = (int(v) for v in rect)
-            im_roi, im_msk = image[y:y + h, x:x + w].copy(), mask[y:y + h, x:x + w].copy()
-            h, w = im_roi.shape[:2]
+            w, h = max(min(x + w, sw) - x, 0), max(min(y + h, sh) - y, 0)      # numpy slicing clips the crop to the image
+            roi = (x, y, w, h)
             if random.randint(0, 1):
                 scale = random.uniform(1.0, 2.2)
                 w, h = int(w * scale), int(h * scale)
-                im_roi, im_msk = resize_bilinear(im_roi, w, h), resize_bilinear(im_msk, w, h)
 
             def draw():
                 cx, cy = random.randint(0, im_x - 1), random.randint(0, im_y - 1)
@@ -300,52 +319,74 @@ class DataArgumentationLayer(Layer):
                     if not any(self._iou(b, nrect) > self.PLACEMENT_IOU for b in placed):
                         found = True
                         break
-            if not found:
+            if not found or roi[2] <= 0 or roi[3] <= 0 or w <= 0 or h <= 0:
                 continue
-            x0, y0 = max(cx, 0), max(cy, 0)
-            x1, y1 = min(cx + w, im_x), min(cy + h, im_y)
-            if x1 <= x0 or y1 <= y0:
+            if min(cx + w, im_x) <= max(cx, 0) or min(cy + h, im_y) <= max(cy, 0):
                 continue
-            sel = im_msk[y0 - cy:y1 - cy, x0 - cx:x1 - cx, 0] > 0
-            img_out[y0:y1, x0:x1][sel] = im_roi[y0 - cy:y1 - cy, x0 - cx:x1 - cx][sel]
-            mask_out[y0:y1, x0:x1, 0][sel] = label + 1
+            objs.append(dict(idx=idx, flip=flip_flag, roi=roi, out=(w, h), pos=(cx, cy), label=label))
             placed.append(nrect)
             labels.append(label)
-        return img_out, mask_out, [tuple(int(v) for v in r) for r in placed], labels
+        rects = [tuple(int(v) for v in r) for r in placed]
+        final_flip = random.randint(-1, 2)                        # random_argumentation (argumentation_engine.py:143-188)
+        if -2 < final_flip < 2 and rects:
+            rects = [tuple(r) for r in flip_rects((im_y, im_x), rects, final_flip)]
+        else:
+            final_flip = 2
+        rects = resize_rects((im_y, im_x), (self.image_size_x, self.image_size_y), rects)
+        return dict(bg_crop=(bx, by, ww, hh), objects=objs, final_flip=final_flip, rects=rects, labels=labels)
 
-    def _background(self, h: int = 480, w: int = 640) -> np.ndarray:
-        if self.background is None:
-            return self._noise.integers(0, 256, (h, w, 3), dtype=np.uint8)
-        im = self.background
-        hh, ww = im.shape[0] // 2, im.shape[1] // 2
-        x, y = random.randint(0, ww), random.randint(0, hh)
-        x = x - (x + ww - im.shape[1]) if x + ww > im.shape[1] else x
-        y = y - (y + hh - im.shape[0]) if y + hh > im.shape[0] else y
-        return resize_bilinear(im[y:y + hh, x:x + ww], w, h)
+    def render_host(self, plan: dict):
+        """The decided scene as (image uint8 480x640x3, class mask uint8 480x640), with numpy."""
+        bx, by, ww, hh = plan["bg_crop"]
+        img_out = resize_bilinear(self.background[by:by + hh, bx:bx + ww], self.SCENE_W, self.SCENE_H)
+        mask_out = np.zeros((self.SCENE_H, self.SCENE_W), np.uint8)
+        for o in plan["objects"]:
+            image, mask, _label, _rect = self._source(o["idx"])
+            if -2 < o["flip"] < 2:
+                image, mask = flip_image(image, o["flip"]), flip_image(mask, o["flip"])
+            x, y, w, h = o["roi"]
+            im_roi, im_msk = image[y:y + h, x:x + w], mask[y:y + h, x:x + w]
+            ow, oh = o["out"]
+            if (ow, oh) != (w, h):
+                im_roi, im_msk = resize_bilinear(im_roi, ow, oh), resize_bilinear(im_msk, ow, oh)
+            cx, cy = o["pos"]
+            x0, y0 = max(cx, 0), max(cy, 0)
+            x1, y1 = min(cx + ow, self.SCENE_W), min(cy + oh, self.SCENE_H)
+            sel = im_msk[y0 - cy:y1 - cy, x0 - cx:x1 - cx] > 0
+            img_out[y0:y1, x0:x1][sel] = im_roi[y0 - cy:y1 - cy, x0 - cx:x1 - cx][sel]
+            mask_out[y0:y1, x0:x1][sel] = o["label"] + 1
+        if -2 < plan["final_flip"] < 2:
+            img_out, mask_out = flip_image(img_out, plan["final_flip"]), flip_image(mask_out, plan["final_flip"])
+        return img_out, mask_out
 
     def make_sample(self):
-        """One training sample: (image float32 HxWx3 in [0,1], class mask HxW uint8, rects at net resolution, labels)."""
-        bg = self._background()
-        img, mask, rects, labels = self.synthesize(random.randint(1, 3), bg)
-        flip_flag = random.randint(-1, 2)                       # random_argumentation (argumentation_engine.py:143-188)
-        if -2 < flip_flag < 2 and rects:
-            rects = [tuple(r) for r in flip_rects(img.shape[:2], rects, flip_flag)]
-            img, mask = flip_image(img, flip_flag), flip_image(mask, flip_flag)
-        src_hw = img.shape[:2]
-        img = demean_rgb_image(img)
-        img = resize_bilinear(img, self.image_size_x, self.image_size_y)
-        rects = resize_rects(src_hw, (self.image_size_x, self.image_size_y), rects)
-        mask = resize_nearest(mask[:, :, 0], self.image_size_x, self.image_size_y)
-        return img, mask, rects, labels
+        """One training sample on the host: (image float32 HxWx3 in [0,1], class mask HxW uint8, rects at net resolution, labels)."""
+        plan = self.plan_scene()
+        img, mask = self.render_host(plan)
+        img = resize_bilinear(demean_rgb_image(img), self.image_size_x, self.image_size_y)
+        mask = resize_nearest(mask, self.image_size_x, self.image_size_y)
+        return img, mask, plan["rects"], plan["labels"]
+
+    def bind_device(self, engine, top_names: Sequence[str]) -> None:
+        """Called by the solver: from now on forward() renders `data` (and the class mask of HEAD's mode) straight into the
+        engine's input blobs on the device instead of into the host tops."""
+        self._renderer = DeviceRenderer(self, engine, top_names[0], top_names[1] if self.mode != "detectnet" else None)
+        self.device_tops = {top_names[0]} | ({top_names[1]} if self.mode != "detectnet" else set())
 
     def forward(self, bottom, top):
         from .detector import generate_targets
         all_rects, all_labels = [], []
+        renderer = getattr(self, "_renderer", None)
         for index in range(self.batch_size):
-            img, mask, rects, labels = self.make_sample()
-            top[0].data[index] = img.transpose((2, 0, 1))
-            if self.mode != "detectnet":
-                top[1].data[index, 0] = mask
+            if renderer is not None:
+                plan = self.plan_scene()
+                renderer.render(index, plan)
+                rects, labels = plan["rects"], plan["labels"]
+            else:
+                img, mask, rects, labels = self.make_sample()
+                top[0].data[index] = img.transpose((2, 0, 1))
+                if self.mode != "detectnet":
+                    top[1].data[index, 0] = mask
             all_rects.append(rects)
             all_labels.append(labels)
         self.last_rects, self.last_labels = all_rects, all_labels
@@ -361,3 +402,75 @@ class DataArgumentationLayer(Layer):
 
     def backward(self, top, propagate_down, bottom):
         pass
+
+
+class DeviceRenderer(object):
+    """Renders planned scenes on the device (csrc/scene.hip + fcn_preprocess_bgr8): the background and every dataset
+    entry are uploaded once and stay in HBM; a sample costs one 64-byte record per object, one compose launch, the
+    normalise + resize launch into the engine's `data` blob and, in mask mode, the nearest-neighbour label launch."""
+
+    def __init__(self, layer: DataArgumentationLayer, engine, data_top: str, label_top: Optional[str]):
+        import ctypes as C
+        from . import lib as L
+        from .engine import DeviceBuffer
+        self.C, self.L, self.DeviceBuffer = C, L, DeviceBuffer
+        self.layer, self.engine = layer, engine
+        self.data, self.label = engine.blobs[data_top], (engine.blobs[label_top] if label_top else None)
+        L.call("fcn_init", engine.device)
+        self.bg = self._upload(layer.background)
+        self.entries = {}
+        n = layer.batch_size
+        h, w = layer.SCENE_H, layer.SCENE_W
+        self.scene = [DeviceBuffer(h * w * 3, zero=False) for _ in range(n)]
+        self.mask = [DeviceBuffer(h * w, zero=False) for _ in range(n)]
+        self.recs_host = [(L.SceneObj * 4)() for _ in range(n)]
+        self.recs_dev = [DeviceBuffer(C.sizeof(L.SceneObj) * 4, zero=True) for _ in range(n)]
+        self.minmax = DeviceBuffer(64, zero=True)
+
+    def _upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        d = self.DeviceBuffer(max(a.nbytes, 16), zero=False)
+        self.L.call("fcn_memcpy_h2d_async", d.ptr, a.ctypes.data, a.nbytes, None)
+        self.L.call("fcn_device_sync")
+        return d
+
+    def _entry(self, idx: int):
+        e = self.entries.get(idx)
+        if e is None:
+            image, mask, _label, _rect = self.layer._source(idx)
+            e = (self._upload(image), self._upload(mask), image.shape[0], image.shape[1])
+            self.entries[idx] = e
+        return e
+
+    def render(self, index: int, plan: dict) -> None:
+        L, C, lay, st = self.L, self.C, self.layer, self.engine.stream
+        recs = self.recs_host[index]
+        objs = plan["objects"][:4]
+        for i, o in enumerate(objs):
+            img, msk, sh, sw = self._entry(o["idx"])
+            recs[i] = L.SceneObj(img.ptr, msk.ptr, sh, sw, o["flip"], o["roi"][0], o["roi"][1], o["roi"][2], o["roi"][3], o["out"][0],
+                                 o["out"][1], o["pos"][0], o["pos"][1], o["label"] + 1)
+        if objs:
+            L.call("fcn_memcpy_h2d_async", self.recs_dev[index].ptr, C.addressof(recs), C.sizeof(L.SceneObj) * len(objs), st)
+        bx, by, ww, hh = plan["bg_crop"]
+        bgh, bgw = lay.background.shape[:2]
+        L.call("fcn_compose_scene_bgr8", self.bg.ptr, bgh, bgw, bx, by, ww, hh, self.recs_dev[index].ptr, len(objs), plan["final_flip"],
+               self.scene[index].ptr, self.mask[index].ptr, lay.SCENE_H, lay.SCENE_W, st)
+        d = self.data
+        n, c, H, W = d.shape
+        L.call("fcn_preprocess_bgr8", self.scene[index].ptr, lay.SCENE_H, lay.SCENE_W, d.ptr + 4 * index * H * W * d.cstride, H, W, d.cstride,
+               float(getattr(d, "upload_shift", 0.0) or 0.0), self.minmax.ptr, st)
+        if self.label is not None:
+            lb = self.label
+            L.call("fcn_mask_to_label_f32", self.mask[index].ptr, lay.SCENE_H, lay.SCENE_W, lb.ptr + 4 * index * H * W * lb.cstride, H, W,
+                   lb.cstride, st)
+
+    def read_scene(self, index: int):
+        """Host copies of the composed uint8 scene and class mask of batch slot `index` (tests)."""
+        lay = self.layer
+        img = np.empty((lay.SCENE_H, lay.SCENE_W, 3), np.uint8)
+        msk = np.empty((lay.SCENE_H, lay.SCENE_W), np.uint8)
+        self.L.call("fcn_memcpy_d2h_async", img.ctypes.data, self.scene[index].ptr, img.nbytes, self.engine.stream)
+        self.L.call("fcn_memcpy_d2h_async", msk.ctypes.data, self.mask[index].ptr, msk.nbytes, self.engine.stream)
+        self.L.call("fcn_stream_sync", self.engine.stream)
+        return img, msk

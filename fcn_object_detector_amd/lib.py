@@ -48,6 +48,11 @@ class PoolDesc(C.Structure):
         "N", "H", "W", "C", "x_cstride", "k", "stride", "pad", "OH", "OW", "y_cstride", "y_coffset")]
 
 
+class SceneObj(C.Structure):
+    _fields_ = [("img", C.c_void_p), ("mask", C.c_void_p)] + [(k, C.c_int32) for k in (
+        "src_h", "src_w", "flip", "roi_x", "roi_y", "roi_w", "roi_h", "out_w", "out_h", "cx", "cy", "label1")]
+
+
 class FlipSeg(C.Structure):
     _fields_ = [("w_offset", C.c_uint64), ("wt_offset", C.c_uint64), ("Cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("Cin", C.c_int32), ("Cin4", C.c_int32), ("Cout4", C.c_int32)]
@@ -121,6 +126,8 @@ PROTOTYPES = {
     "fcn_conv2d_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc), C.POINTER(_i)]),
     "fcn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "fcn_conv_weights_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_compose_scene_bgr8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "fcn_mask_to_label_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "fcn_softmax_fwd_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "fcn_softmax_loss_workspace_bytes": (_sz, []),
     "fcn_softmax_loss_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),

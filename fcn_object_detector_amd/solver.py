@@ -118,7 +118,12 @@ class Solver(object):
         self.net = TrainNet(self)
         self._losses: deque = deque(maxlen=max(self.param.average_loss, 1))
         self._device_label_tops = {}
+        self.engine.device_fed = set()
         for l, inst, bottoms, tops in self.py_layers:
+            # a data layer that can render its scenes on the device writes `data` (and HEAD's class mask) straight into HBM
+            if getattr(inst, "supports_device_scenes", False) and os.environ.get("FCN_DEVICE_SCENES", "1") != "0":
+                inst.bind_device(self.engine, [t.name for t in tops])
+                self.engine.device_fed |= set(inst.device_tops)
             # a data layer that can hand over ground-truth boxes gets its label grids generated in HBM (fcn_gen_targets_nhwc)
             if getattr(inst, "supports_device_targets", False) and getattr(inst, "mode", None) == "detectnet" and len(tops) >= 6:
                 inst.device_targets = True
@@ -140,7 +145,7 @@ class Solver(object):
             for t in tops:
                 if tuple(t.shape_) != tuple(eng.shapes[t.name]):
                     raise NotImplementedError("Python layer %s changed the shape of %s" % (l.name, t.name))
-                if t.name not in label_tops:
+                if t.name not in label_tops and t.name not in getattr(inst, "device_tops", ()):
                     eng.host_array(t.name)[...] = t.data
             if label_tops:
                 eng.set_targets(inst.last_rects, inst.last_labels, inst.stride, tops=label_tops)

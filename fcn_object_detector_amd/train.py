@@ -462,8 +462,9 @@ class TrainEngine(Engine):
             L.call("fcn_init", self.device)
             self.dropout_seed = int(seed if seed is not None else self.iter) & 0xFFFFFFFF
             dev_targets = getattr(self, "_tgt", None) is not None and self._tgt.get("pending")
+            fed = set(getattr(self, "device_fed", ()))      # inputs some producer already wrote in HBM (device scene renderer)
             if upload:
-                skip = set(self._tgt["tops"]) if dev_targets else set()
+                skip = (set(self._tgt["tops"]) if dev_targets else set()) | fed
                 for nm in self.inputs:
                     if nm not in skip:
                         self._enqueue_upload(nm, self.stream)
@@ -490,9 +491,8 @@ class TrainEngine(Engine):
             L.call("fcn_stream_sync", self.stream)
             for b in self.blobs.values():
                 b.host_valid = b.is_input
-            if dev_targets:
-                for nm in self._tgt["tops"]:
-                    self.blobs[nm].host_valid = False      # generated in HBM, never on the host
+            for nm in (list(self._tgt["tops"]) if dev_targets else []) + list(fed):
+                self.blobs[nm].host_valid = False          # generated in HBM, never on the host
             out = {k: float(v[0]) for k, v in self.loss_host.items()}
             out["total_loss"] = float(sum(self.loss_blobs[k] * out[k] for k in self.loss_blobs))
             out.setdefault("loss", out["total_loss"])      # shorthand, unless a blob is itself called "loss" (train/fcn_bbox)

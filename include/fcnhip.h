@@ -172,6 +172,29 @@ int  fcn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* b
 int  fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride,
                          float shift, float* d_minmax, fcn_stream_t s);
 
+/* ---- training-scene synthesis on the device: the pixel work of ArgumentationEngineMapping.argument
+ *      (scripts/data_argumentation_layer/argumentation_engine.py:651-746) and the whole-image flip of
+ *      random_argumentation (:143-188).  The random decisions stay on the host; images live in HBM. ---- */
+typedef struct fcn_scene_obj {
+    const uint8_t* img;    /* src_h x src_w x 3 BGR, as stored (unflipped)                                   */
+    const uint8_t* mask;   /* src_h x src_w, nonzero = object                                                */
+    int32_t src_h, src_w;
+    int32_t flip;          /* cv.flip code applied to the object before cropping: 0, 1, -1; anything else: none */
+    int32_t roi_x, roi_y, roi_w, roi_h;   /* crop in the flipped image                                          */
+    int32_t out_w, out_h;  /* size after the optional bilinear rescale                                        */
+    int32_t cx, cy;        /* paste position in the scene (may be negative / hang over the border)            */
+    int32_t label1;        /* value written to the class mask (label + 1)                                     */
+} fcn_scene_obj;
+/* out_img (H x W x 3) = bilinear resize of the background crop, then the objects pasted in order where their (resized)
+ * mask is nonzero, then the whole-image flip `final_flip` (0, 1, -1; else none); out_mask (H x W, may be NULL) = label1
+ * of the last object covering the pixel, 0 elsewhere.  d_objs: nobj records in device memory. */
+int  fcn_compose_scene_bgr8(const uint8_t* bg, int bg_h, int bg_w, int crop_x, int crop_y, int crop_w, int crop_h,
+                            const fcn_scene_obj* d_objs, int nobj, int final_flip, uint8_t* out_img, uint8_t* out_mask,
+                            int H, int W, fcn_stream_t s);
+/* class mask (h x w uint8) -> H x W label blob, one float per pixel at stride dst_cstride (nearest neighbour: top[1] of
+ * the data layer in HEAD's mask mode, data_argumentation_layer.py:113-121) */
+int  fcn_mask_to_label_f32(const uint8_t* mask, int h, int w, float* dst, int H, int W, int dst_cstride, fcn_stream_t s);
+
 /* ---- DetectNet post-processing: gridbox_to_boxes + vote_boxes -> cv.groupRectangles
  *      (fcn_object_detector.py:337-394; OpenCV 3 objdetect groupRectangles/partition) ---- */
 #define FCN_RECT_ROUND_NEAREST_EVEN 0  /* OpenCV vector<Rect> converter: saturate_cast<int>(double) = cvRound */
