@@ -125,9 +125,50 @@ def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
                        % (2 if world == 1 else 3, "RCCL all-reduce of 23.9 MB grads" if world > 1 else "no collective", n)}
     res["achieved_tflops"] = round(45.9e-3 * res["imgs_per_s"], 2)
     eng.close()
+    # The same step driven by the reference's data layer (BASELINE configs[2] names it): DataArgumentationLayer plans a
+    # scene per image on the host (RNG + box bookkeeping), the device composes / normalises it from HBM-resident object
+    # images and generates the label grids; nothing but the placement records crosses PCIe.
+    try:
+        res["with_data_layer"] = bench_train_data_layer(cp, rank, world, local, comm, n, max(steps // 2, 5))
+    except Exception as e:  # the headline numbers above must survive a failure here
+        res["with_data_layer"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if comm is not None:
         comm.close()
     return res
+
+
+def bench_train_data_layer(cp, rank, world, local, comm, n, steps):
+    import tempfile
+    from fcn_object_detector_amd import lib as L, models
+    from fcn_object_detector_amd.solver import Solver
+    pydir = os.path.join(ROOT, "fcn_object_detector_amd", "python")
+    if pydir not in sys.path:
+        sys.path.insert(0, pydir)
+    os.environ["FCN_DATA_SEED"] = str(100 + rank)
+    with tempfile.TemporaryDirectory() as tmp:
+        net = os.path.join(tmp, "train_val.prototxt")
+        with open(net, "w") as f:
+            f.write(models.googlenet_detectnet_train("data_argumentation_layer", "DataArgumentationLayer",
+                                                     "448,448,16,1,%d,synthetic:1,detectnet" % n, num_classes=1))
+        sol = os.path.join(tmp, "solver.prototxt")
+        with open(sol, "w") as f:
+            f.write('net: "%s"\nbase_lr: 1e-4\nmomentum: 0.9\nweight_decay: 1e-7\nlr_policy: "fixed"\ndisplay: 0\nmax_iter: 1000000\n'
+                    'snapshot: 0\nsnapshot_prefix: "%s"\n' % (net, os.path.join(tmp, "snap")))
+        solver = Solver(sol, device=local, comm=comm, rank=rank, log=None)
+        solver.step(3)
+        L.call("fcn_device_sync")
+        cp.barrier()
+        t0 = time.perf_counter()
+        out = solver.step(steps)
+        L.call("fcn_device_sync")
+        t_local = time.perf_counter() - t0
+        cp.barrier()
+        t_max = cp.max(t_local)
+        solver.close()
+    return {"imgs_per_s": round(steps * n * world / t_max, 2), "ms_per_step": round(t_max * 1e3 / steps, 3), "steps": steps,
+            "loss_last": round(out["total_loss"], 5),
+            "workload": "caffe-train loop: DataArgumentationLayer (synthetic objects, scenes planned on the host, composed on the device) "
+                        "+ device target generation + fwd + bwd + SGD, batch %d/GPU" % n}
 
 
 def bench_vgg(steps: int = 5):

@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__
             hi[c] = max(hi[c], v);
         }
     }
+    // wave reduce, then one partial per wave through LDS, then SIX atomics per workgroup: thousands of same-address
+    // atomics (one set per wave of a frame-sized grid) serialise at ~50 ns each and used to dominate this pre-processing
+    __shared__ int part[6][4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -42,9 +45,15 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__
             hi[c] = max(hi[c], __shfl_xor(hi[c], off));
         }
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&mm[c], lo[c]);
-            atomicMax(&mm[3 + c], hi[c]);
+            part[c][threadIdx.x >> 6] = lo[c];
+            part[3 + c][threadIdx.x >> 6] = hi[c];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        atomicMin(&mm[c], min(min(part[c][0], part[c][1]), min(part[c][2], part[c][3])));
+        atomicMax(&mm[3 + c], max(max(part[3 + c][0], part[3 + c][1]), max(part[3 + c][2], part[3 + c][3])));
     }
 }
 
@@ -98,7 +107,9 @@ int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, i
     hipStream_t st = as_stream(s);
     int* mm = reinterpret_cast<int*>(d_minmax);
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(64), 0, st, mm);
-    hipLaunchKernelGGL(minmax_kernel, dim3(stream_grid((long long)h * w, 256)), dim3(256), 0, st, frame, (long long)h * w, mm);
+    int mm_blocks = stream_grid((long long)h * w, 256 * 16);      // >= 16 pixels per lane: a few hundred workgroups at most
+    if (mm_blocks > 256) mm_blocks = 256;
+    hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks), dim3(256), 0, st, frame, (long long)h * w, mm);
     hipLaunchKernelGGL(resize_norm_kernel, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, st, frame, h, w, dst, H, W, dst_cstride,
                        shift, mm);
     FCN_LAUNCH_CHECK("preprocess_bgr8");
