@@ -155,11 +155,11 @@ def bench_train_data_layer(cp, rank, world, local, comm, n, steps):
             f.write('net: "%s"\nbase_lr: 1e-4\nmomentum: 0.9\nweight_decay: 1e-7\nlr_policy: "fixed"\ndisplay: 0\nmax_iter: 1000000\n'
                     'snapshot: 0\nsnapshot_prefix: "%s"\n' % (net, os.path.join(tmp, "snap")))
         solver = Solver(sol, device=local, comm=comm, rank=rank, log=None)
-        solver.step(3)
+        solver.step(3, pipeline=True)
         L.call("fcn_device_sync")
         cp.barrier()
         t0 = time.perf_counter()
-        out = solver.step(steps)
+        out = solver.step(steps, pipeline=True)
         L.call("fcn_device_sync")
         t_local = time.perf_counter() - t0
         cp.barrier()

@@ -117,6 +117,7 @@ class Solver(object):
                                   autotune=autotune)
         self.net = TrainNet(self)
         self._losses: deque = deque(maxlen=max(self.param.average_loss, 1))
+        self._fed = False
         self._device_label_tops = {}
         self.engine.device_fed = set()
         for l, inst, bottoms, tops in self.py_layers:
@@ -150,13 +151,34 @@ class Solver(object):
             if label_tops:
                 eng.set_targets(inst.last_rects, inst.last_labels, inst.stride, tops=label_tops)
 
-    def step(self, iters: int = 1) -> Dict[str, float]:
+    def _all_device_fed(self) -> bool:
+        """True when no top of any Python layer travels through a host array (scenes composed and labels generated in HBM):
+        the next batch can then be planned and enqueued while the device is still busy with the current iteration."""
+        for l, inst, bottoms, tops in self.py_layers:
+            label_tops = self._device_label_tops.get(id(inst), ()) if getattr(inst, "device_targets", False) else ()
+            if any(t.name not in label_tops and t.name not in getattr(inst, "device_tops", ()) for t in tops):
+                return False
+        return bool(self.py_layers)
+
+    def step(self, iters: int = 1, pipeline: bool = False) -> Dict[str, float]:
+        """Solver::Step.  pipeline=True (what solve() / `caffe train` use) plans and enqueues the next batch while the device
+        runs the current iteration; it is off by default because the input blobs then already hold the NEXT batch when
+        step() returns, which a pycaffe caller inspecting net.blobs would not expect."""
         p, out = self.param, {}
         stop = self.iter + int(iters)
+        pipelined = pipeline and self._all_device_fed()
         while self.iter < stop:
             it = self.iter
-            self._feed()
-            out = self.engine.step()
+            if not self._fed:
+                self._feed()
+            self._fed = False
+            self.engine.step_begin()
+            if pipelined and it + 1 < p.max_iter:
+                # the renders of the next batch queue up behind this iteration on the stream; its planning (host RNG and
+                # box bookkeeping) overlaps the device work
+                self._feed()
+                self._fed = True
+            out = self.engine.step_end()
             self._losses.append(out["total_loss"])
             if p.display and it % p.display == 0:
                 self.log("Iteration %d, loss = %g" % (it, sum(self._losses) / len(self._losses)))
@@ -173,7 +195,7 @@ class Solver(object):
         if resume_file:
             self.restore(resume_file)
         self.log("Solving %s" % (self.engine.spec.name or os.path.basename(self.net_file)))
-        self.step(max(self.param.max_iter - self.iter, 0))
+        self.step(max(self.param.max_iter - self.iter, 0), pipeline=True)
         if not (self.param.snapshot and self.iter % self.param.snapshot == 0):
             self.snapshot()
         self.log("Optimization Done.")

@@ -457,6 +457,12 @@ class TrainEngine(Engine):
         blobs staged with set_targets(), which are generated on the device; upload=False reuses what is already in HBM.
         Returns {loss blob: value} plus 'total_loss' = sum of loss_weight * value (what `caffe train` prints; also under
         'loss' when no blob has that name)."""
+        self.step_begin(seed, upload)
+        return self.step_end()
+
+    def step_begin(self, seed: Optional[int] = None, upload: bool = True) -> None:
+        """Enqueue a whole iteration (inputs, targets, forward, backward, all-reduce, update, loss read-back) and return
+        without waiting: the caller may prepare the next batch while the device works (step_end() collects the losses)."""
         lib = L.load()
         with self.lock:
             L.call("fcn_init", self.device)
@@ -488,10 +494,19 @@ class TrainEngine(Engine):
             self.apply_update(1.0 / (world * self.solver.iter_size))
             for name, arr in self.loss_host.items():
                 L.check(lib.fcn_memcpy_d2h_async(arr.ctypes.data, self.blobs[name].buf.ptr, 4, self.stream))
-            L.call("fcn_stream_sync", self.stream)
+            if getattr(self, "_step_done", None) is None:
+                ev = C.c_void_p()
+                L.call("fcn_event_create", C.byref(ev))
+                self._step_done = ev
+            L.check(lib.fcn_event_record(self._step_done, self.stream))
+            self._in_flight = (list(self._tgt["tops"]) if dev_targets else []) + list(fed)
+
+    def step_end(self) -> Dict[str, float]:
+        with self.lock:
+            L.call("fcn_event_sync", self._step_done)
             for b in self.blobs.values():
                 b.host_valid = b.is_input
-            for nm in (list(self._tgt["tops"]) if dev_targets else []) + list(fed):
+            for nm in self._in_flight:
                 self.blobs[nm].host_valid = False          # generated in HBM, never on the host
             out = {k: float(v[0]) for k, v in self.loss_host.items()}
             out["total_loss"] = float(sum(self.loss_blobs[k] * out[k] for k in self.loss_blobs))
