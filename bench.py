@@ -154,7 +154,16 @@ def bench_train_data_layer(cp, rank, world, local, comm, n, steps):
         with open(sol, "w") as f:
             f.write('net: "%s"\nbase_lr: 1e-4\nmomentum: 0.9\nweight_decay: 1e-7\nlr_policy: "fixed"\ndisplay: 0\nmax_iter: 1000000\n'
                     'snapshot: 0\nsnapshot_prefix: "%s"\n' % (net, os.path.join(tmp, "snap")))
-        solver = Solver(sol, device=local, comm=comm, rank=rank, log=None)
+        solver, err = None, ""
+        try:
+            solver = Solver(sol, device=local, comm=comm, rank=rank, log=None)
+        except Exception as e:      # every rank must take the same branch below: no barrier may be left half-entered
+            err = "%s: %s" % (type(e).__name__, e)
+        errs = [e for e in cp.all_gather(err) if e]
+        if errs:
+            if solver is not None:
+                solver.close()
+            raise RuntimeError("; ".join(errs))
         solver.step(3, pipeline=True)
         L.call("fcn_device_sync")
         cp.barrier()
