@@ -180,6 +180,44 @@ def bench_train_data_layer(cp, rank, world, local, comm, n, steps):
                         "+ device target generation + fwd + bwd + SGD, batch %d/GPU" % n}
 
 
+def bench_infer32(local: int, reps: int = 10):
+    """BASELINE configs[4] without its fp16 arithmetic (the f32 path is what exists): 32 uint8 frames resident in HBM ->
+    pre-processing -> one forward -> one fused decode + groupRectangles launch for all (image, class) pairs -> boxes on
+    the host.  End-to-end frames/s of FCNObjectDetector.run_detector_batch minus the frame upload."""
+    from fcn_object_detector_amd import lib as L, models, proto
+    from fcn_object_detector_amd.detector import FCNObjectDetector, HeadMapping
+    from fcn_object_detector_amd.engine import DeviceBuffer, Engine
+    from fcn_object_detector_amd.netspec import NetSpec, fill_params
+    n = 32
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(n, 448, 448, 4))
+    spec = NetSpec(msg, "TEST")
+    spec.infer()
+    eng = Engine(NetSpec(msg, "TEST"), params=fill_params(spec, seed=1234), device=local)
+    det = FCNObjectDetector(eng, 0.5, 3, 0.2, HeadMapping.detectnet_deploy())
+    frames = np.random.default_rng(9).integers(0, 256, (n, 448, 448, 3), dtype=np.uint8)
+    dev = DeviceBuffer(frames.nbytes, zero=False)
+    L.call("fcn_memcpy_h2d_async", dev.ptr, frames.ctypes.data, frames.nbytes, eng.stream)
+    data = eng.blobs["data"]
+
+    def once():
+        for i in range(n):
+            L.call("fcn_preprocess_bgr8", dev.ptr + i * 448 * 448 * 3, 448, 448, data.ptr + 4 * i * 448 * 448 * data.cstride, 448, 448,
+                   data.cstride, data.upload_shift, det._minmax.ptr, eng.stream)
+        eng.forward_resident(1)
+        det.decoder.launch(*det._cvg_args, *det._box_args, eng.stream)
+        return det.decoder.fetch(eng.stream)
+    once()
+    once()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = once()
+    dt = (time.perf_counter() - t0) / reps
+    eng.close()
+    return {"frames_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "dtype": "f32", "batch": n,
+            "detections_last_batch": int(sum(len(r[0]) for r in res)),
+            "note": "pre-processing + forward + fused decode/groupRectangles + read-back of the boxes; the fp16 MFMA arithmetic of configs[4] is not built"}
+
+
 def bench_vgg(steps: int = 5):
     """The reference's secondary net train/fcn_bbox (VGG16 + FCN-8s scores + x4 bilinear bbox branch):
     forward of its inference form at 448x448 and one training step at its native shape (288x288, stride 8, 11 classes,
@@ -369,6 +407,7 @@ def main() -> None:
         out["forward_batch8"] = {"frames_per_s": round(8e3 / ms8, 1), "ms_per_step": round(ms8, 4), "conv_family_tflops": round(conv8, 2),
                                  "conv_family_frac_of_f32_mfma_peak": round(conv8 / F32_MFMA_PEAK_TFLOPS, 4)}
         eng8.close()
+        out["inference_batch32"] = bench_infer32(local)
         out["secondary"] = bench_vgg()
     cp.close()
     if out is not None:

@@ -214,6 +214,38 @@ class FCNObjectDetector:
         self._frame_dev: Optional[DeviceBuffer] = None
         self._minmax = DeviceBuffer(32)
 
+    def run_detector_batch(self, frames: Sequence[np.ndarray]) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """BASELINE configs[4] minus the fp16 arithmetic: `batch` frames through pre-processing, ONE forward and ONE fused
+        decode + groupRectangles launch ((image, class) per workgroup); per frame the result of run_detector."""
+        eng = self.engine
+        if len(frames) != self.batch:
+            raise ValueError("need %d frames (the engine's batch), got %d" % (self.batch, len(frames)))
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        if any(f.ndim != 3 or f.shape[2] != 3 for f in frames):
+            raise ValueError("expected BGR uint8 frames")
+        with eng.lock:
+            L.call("fcn_init", eng.device)
+            need = sum((f.nbytes + 15) // 16 * 16 for f in frames)
+            if self._frame_dev is None or self._frame_dev.nbytes < need:
+                self._frame_dev = DeviceBuffer(need, zero=False)
+            data = eng.blobs["data"]
+            off = 0
+            for i, f in enumerate(frames):
+                L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr + off, f.ctypes.data, f.nbytes, eng.stream)
+                L.call("fcn_preprocess_bgr8", self._frame_dev.ptr + off, f.shape[0], f.shape[1],
+                       data.ptr + 4 * i * self.im_height * self.im_width * data.cstride, self.im_height, self.im_width, data.cstride,
+                       data.upload_shift, self._minmax.ptr, eng.stream)
+                off += (f.nbytes + 15) // 16 * 16
+            eng.forward_resident(1)
+            self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
+            res = self.decoder.fetch(eng.stream)
+            data.host_valid = False
+        out = []
+        for f, (dets, labels) in zip(frames, res):
+            boxes = np.asarray(dets, dtype=np.int64).reshape(-1, 5)
+            out.append((resize_detection(f.shape, boxes, self.im_width, self.im_height) if len(boxes) else boxes, labels))
+        return out
+
     def run_detector(self, frame: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         eng = self.engine
         if self.batch != 1:

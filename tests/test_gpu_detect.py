@@ -138,3 +138,35 @@ def test_node_pipeline_matches_oracle(gpu, h, w):
         rbox = D.resize_detection(frame.shape, rbox, 448, 448)
     assert np.array_equal(boxes, rbox) and np.array_equal(labels, rlab)
     eng.close()
+
+
+def test_batched_node_pipeline_matches_oracle(gpu):
+    """BASELINE configs[4] without the fp16 arithmetic: a batch of frames of different sizes -> pre-processing -> one forward
+    -> ONE fused decode + groupRectangles launch; per frame bit-equal to the oracle on the maps the GPU produced.  The head
+    biases are raised so that the random-weight net really emits detections."""
+    batch = 4
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(batch, 224, 320, 3))
+    spec = NetSpec(msg, "TEST"); spec.infer()
+    params = fill_params(spec, seed=77)
+    rng = np.random.default_rng(5)
+    params["cvg/classifier"][1][...] = 1.5                              # sigmoid > 0.5 on most cells
+    params["bbox/regressor"][0][...] = 0                                # boxes = bias pattern: all cells vote for similar rects
+    params["bbox/regressor"][1][...] = np.tile(np.array([-30, -25, 35, 40], np.float32), 3) + rng.normal(0, 0.5, 12).astype(np.float32)
+    eng = Engine(NetSpec(msg, "TEST"), params=params, device=0, autotune=False)
+    det = FCNObjectDetector(eng, 0.5, 3, 0.2, HeadMapping.detectnet_deploy())
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((224, 320), (480, 640), (100, 517), (300, 200))]
+    res = det.run_detector_batch(frames)
+    cvg, bb = eng.read_blob("coverage"), eng.read_blob("bboxes")
+    total = 0
+    for i, (frame, (boxes, labels)) in enumerate(zip(frames, res)):
+        rdet, rlab = D.detect(cvg[i], bb[i], 320, 224, 16, 0.5, 3, 0.2, fast=True)
+        rbox = np.asarray(rdet, dtype=np.int64).reshape(-1, 5)
+        if len(rbox):
+            rbox = D.resize_detection(frame.shape, rbox, 320, 224)
+        assert np.array_equal(boxes, rbox) and np.array_equal(labels, rlab), i
+        assert np.abs(eng.read_blob("data")[i] - D.preprocess_frame(frame, 320, 224)).max() <= 4e-6
+        total += len(boxes)
+    assert total > 0
+    with pytest.raises(ValueError):
+        det.run_detector_batch(frames[:2])
+    eng.close()
