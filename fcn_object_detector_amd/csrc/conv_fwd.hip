@@ -41,6 +41,8 @@ using namespace fcn;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 
 namespace fcn {
 
@@ -112,9 +114,13 @@ constexpr int kPoolItemsPerThread = 2;
 
 // MAX pooling riding in a convolution launch (Caffe semantics as in pointwise.hip: window clipped to the image, strict
 // '>' so the first maximum in raster order wins).  One work item = 4 channels of one output pixel.
-template <int NT>
+template <typename T, int NT>
 __device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
-    const int cg = q.C >> 2;
+    constexpr int EPS = 16 / (int)sizeof(T);      // channels per 16-byte work item
+    typedef T vec_t __attribute__((ext_vector_type(EPS)));
+    const int cg = q.C / EPS;
+    const T* x = reinterpret_cast<const T*>(q.x);
+    T* y = reinterpret_cast<T*>(q.y);
 #pragma unroll
     for (int it = 0; it < kPoolItemsPerThread; ++it) {
         const int t = (wg * kPoolItemsPerThread + it) * NT + (int)threadIdx.x;
@@ -129,19 +135,28 @@ __device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
         const int he = min(hs + q.k, q.H), we = min(ws + q.k, q.W);
         hs = max(hs, 0);
         ws = max(ws, 0);
-        const float* xb = q.x + (size_t)n * q.H * q.W * q.x_cstride + g * 4;
-        v4f m = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
-        int mi[4] = {-1, -1, -1, -1};
+        const T* xb = x + (size_t)n * q.H * q.W * q.x_cstride + g * EPS;
+        vec_t m;
+        int mi[EPS];
+#pragma unroll
+        for (int e = 0; e < EPS; ++e) {
+            m[e] = sizeof(T) == 2 ? (T)-65504.f : (T)-3.402823466e+38f;      // lowest finite value of the element type
+            mi[e] = -1;
+        }
         for (int iy = hs; iy < he; ++iy)
             for (int ix = ws; ix < we; ++ix) {
-                const v4f v = *(const v4f*)(xb + ((size_t)iy * q.W + ix) * q.x_cstride);
+                const vec_t v = *(const vec_t*)(xb + ((size_t)iy * q.W + ix) * q.x_cstride);
                 const int id = iy * q.W + ix;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < EPS; ++e)
                     if (v[e] > m[e]) { m[e] = v[e]; mi[e] = id; }
             }
-        *(v4f*)(q.y + (size_t)pix * q.y_cstride + q.y_coffset + g * 4) = m;
-        if (q.idx) *(int4*)(q.idx + (size_t)pix * q.C + g * 4) = make_int4(mi[0], mi[1], mi[2], mi[3]);
+        *(vec_t*)(y + (size_t)pix * q.y_cstride + q.y_coffset + g * EPS) = m;
+        if (q.idx) {
+#pragma unroll
+            for (int e = 0; e < EPS; e += 4)
+                *(int4*)(q.idx + (size_t)pix * q.C + g * EPS + e) = make_int4(mi[e], mi[e + 1], mi[e + 2], mi[e + 3]);
+        }
     }
 }
 
@@ -194,11 +209,21 @@ typedef void __attribute__((address_space(3))) * lds_ptr;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
+// T = float: v_mfma_f32_32x32x2_f32, 4 elements per 16-byte segment.  T = _Float16 (inference with f16 activations and
+// weights, f32 accumulation, BASELINE configs[4]): v_mfma_f32_32x32x16_f16, 8 elements per segment - the staging, the LDS
+// image, the swizzle and the pipeline are byte-for-byte the same (BK counts 4-byte words), a chunk just covers twice the
+// k range and one MFMA consumes what four f32 MFMAs do.
+template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem) {
     using C = Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>;
     constexpr int BM = C::BM, SEGS = C::SEGS, RPI = C::RPI, STEP = C::STEP, IA = C::IA, IB = C::IB, INST = C::INST;
     constexpr int D = C::D, KS = C::KS, BUF_FLOATS = C::BUF_FLOATS;
+    constexpr bool F16 = sizeof(T) == 2;
+    constexpr int EPS = 16 / (int)sizeof(T);          // elements per 16-byte segment
+    constexpr int BKE = BK * 4 / (int)sizeof(T);      // k indices one chunk covers
+    constexpr int MPS = F16 ? 1 : 4;                  // MFMAs that consume one ds_read_b128 fragment pair
+    const T* px = reinterpret_cast<const T*>(p.x);
+    const T* pw = reinterpret_cast<const T*>(p.w);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -216,10 +241,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const int lrow = RPI * wid + lane / SEGS;                  // row of instruction 0
     const int lseg = (lane % SEGS) ^ swz<SEGS>(lrow);          // k-segment this lane fetches (same for all its rows)
     // k position of that segment, kept as (tap, channel) and advanced by BK per chunk without branches
-    int kc = lseg * 4;
+    int kc = lseg * EPS;
     int kt = kc / p.Cin;
     kc -= kt * p.Cin;
-    const int bk_taps = BK / p.Cin, bk_rem = BK - bk_taps * p.Cin;
+    const int bk_taps = BKE / p.Cin, bk_rem = BKE - bk_taps * p.Cin;
     int a_iy0[IA], a_ix0[IA], a_off[IA];   // window origin and its element offset (32-bit: validated on the host)
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
@@ -238,9 +263,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
         const int n = n0 + STEP * i + lrow;
-        b_off[i] = n < p.Cout ? n * p.K + lseg * 4 : -1;
+        b_off[i] = n < p.Cout ? n * p.K + lseg * EPS : -1;
     }
-    int kb = lseg * 4;   // this segment's k index (weights are zero past K)
+    int kb = lseg * EPS;   // this segment's k index (weights are zero past K)
     const int taps = p.kh * p.kw;
     // the zero page pointer is laundered into VGPRs so that "in bounds ? source : zero page" stays a plain select
     // (one LDS-DMA instruction per row group) instead of two exec-masked instructions
@@ -263,19 +288,20 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     auto issue_a = [&](const int i) {
         // bitwise & on purpose: && becomes a divergent branch around the address arithmetic
         const bool ok = (int)is_kok & (int)((unsigned)(a_iy0[i] + is_kr) < (unsigned)p.H) & (int)((unsigned)(a_ix0[i] + is_kq) < (unsigned)p.W);
-        unsigned long long src = reinterpret_cast<unsigned long long>(ok ? p.x + (a_off[i] + is_koff) : zero_page);
+        unsigned long long src = ok ? reinterpret_cast<unsigned long long>(px + (a_off[i] + is_koff)) : reinterpret_cast<unsigned long long>(zero_page);
         asm volatile("" : "+v"(src));    // one select, one DMA (keeps hipcc from forking the load into two exec-masked copies)
         __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + STEP * i * BK), 16, 0, 0);
     };
     auto issue_b = [&](const int i) {
-        unsigned long long src = reinterpret_cast<unsigned long long>(((int)is_kbok & (int)(b_off[i] >= 0)) ? p.w + b_off[i] : zero_page);
+        unsigned long long src = ((int)is_kbok & (int)(b_off[i] >= 0)) ? reinterpret_cast<unsigned long long>(pw + b_off[i])
+                                                                       : reinterpret_cast<unsigned long long>(zero_page);
         asm volatile("" : "+v"(src));
         __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + (BM + STEP * i) * BK), 16, 0, 0);
-        b_off[i] += b_off[i] >= 0 ? BK : 0;
+        b_off[i] += b_off[i] >= 0 ? BKE : 0;
     };
     auto issue_post = [&]() {
-        kb += BK;
-        // advance by one chunk: BK = bk_taps * Cin + bk_rem
+        kb += BKE;
+        // advance by one chunk: BKE = bk_taps * Cin + bk_rem
         kc += bk_rem;
         kt += bk_taps;
         const bool wrap = kc >= p.Cin;
@@ -302,7 +328,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (p.K + BK - 1) / BK;
+    const int nchunks = (p.K + BKE - 1) / BKE;
     // Fragment reads are inline asm: hipcc cannot tell an LDS-DMA in flight from the ds_read of a slot that landed
     // long ago and would drain vmcnt to 0 in front of every compiler-generated LDS read of this array.
     // Addressing: row (lane & 31) of a 32-row tile, k-segment 2*step + (lane >> 5), de-swizzled per lane.
@@ -351,14 +377,23 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
         for (int st = 0; st < KS; ++st) read_step(par, st, st, slot_bytes);
     };
+    // one MFMA group = the WTM x WTN instructions that consume element e of a fragment pair (f32: e = 0..3, 2 k each;
+    // f16: the whole 16-byte fragment = 8 halves per lane, 16 k, in one v_mfma_f32_32x32x16_f16)
+    auto mfma_group = [&](const int par, const int fst, const int e) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                if constexpr (F16)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, af[par][fst][i]),
+                                                                       __builtin_bit_cast(v8h, bf[par][fst][j]), acc[i][j], 0, 0, 0);
+                else
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[par][fst][i][e], bf[par][fst][j][e], acc[i][j], 0, 0, 0);
+            }
+    };
     auto mfma_step = [&](const int par, const int fst) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                for (int j = 0; j < WTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[par][fst][i][e], bf[par][fst][j][e], acc[i][j], 0, 0, 0);
+        for (int e = 0; e < MPS; ++e) mfma_group(par, fst, e);
     };
     auto mfma_chunk = [&](const int par, const int buf_cur) {
         if (PF) {
@@ -417,16 +452,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                     // first the fragment reads of chunk c+1, then the DMA of chunk c+D.
                     frags_landed(u & 1, 0, KS);
                     const unsigned nslot = (unsigned)next(buf_cur) * (BUF_FLOATS * 4);
-                    constexpr int NG = KS * 4;                  // MFMA groups of WTM*WTN instructions
+                    constexpr int NG = KS * MPS;                // MFMA groups of WTM*WTN instructions
                     constexpr int NP = KS + 1 + IA + IB + 1;    // pieces: reads, issue_pre, A loads, B loads, issue_post
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-#pragma unroll
-                        for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                            for (int j = 0; j < WTN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[u & 1][g / 4][i][g % 4], bf[u & 1][g / 4][j][g % 4],
-                                                                                 acc[i][j], 0, 0, 0);
+                        mfma_group(u & 1, g / MPS, g % MPS);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int q = g * NP / NG; q < (g + 1) * NP / NG; ++q) {
@@ -485,6 +515,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
     const bool do_sig2 = (p.flags & FCN_CONV_SIGMOID2) != 0 && p.y2 != nullptr;
     const bool do_accum = (p.flags & FCN_CONV_ACCUM) != 0;
+    const bool out_f32 = (p.flags & FCN_CONV_OUT_F32) != 0;      // f16 inputs, f32 output blob (the detection heads)
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
         const int n = n0 + (wn * WTN + j) * 32 + (lane & 31);
@@ -498,10 +529,19 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 const int m = mrow + (r & 3) + 8 * (r >> 2);
                 if (m < p.M) {
                     float v = acc[i][j][r] + bv;
-                    gf_ptr dst = (gf_ptr)(p.y + (size_t)m * p.y_cstride + p.y_coffset + n);
-                    if (do_accum) v += *dst;
-                    if (do_relu) v = fmaxf(v, 0.f);
-                    *dst = v;
+                    const size_t o = (size_t)m * p.y_cstride + p.y_coffset + n;
+                    if (F16 && !out_f32) {      // f16 activations: rounded once, after bias and ReLU
+                        typedef f16_t __attribute__((address_space(1))) * gh_ptr;
+                        gh_ptr dst = (gh_ptr)(reinterpret_cast<f16_t*>(p.y) + o);
+                        if (do_accum) v += (float)*dst;
+                        if (do_relu) v = fmaxf(v, 0.f);
+                        *dst = (f16_t)v;
+                    } else {
+                        gf_ptr dst = (gf_ptr)(p.y + o);
+                        if (do_accum) v += *dst;
+                        if (do_relu) v = fmaxf(v, 0.f);
+                        *dst = v;
+                    }
                     if (do_sig2) *(gf_ptr)(p.y2 + (size_t)m * p.y2_cstride + p.y2_coffset + n) = 1.f / (1.f + expf(-v));
                 }
             }
@@ -509,15 +549,15 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     }
 }
 
-template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
+template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
     const int tile = blockIdx.x;
     const int conv_tiles = a.tile_end[kMaxGroup - 1];      // the host repeats the last prefix in the unused entries
     if (tile >= conv_tiles) {      // workgroups behind the convolution tiles: the poolings fused into this launch
         const int w = tile - conv_tiles;
-        if (w < a.pool[0].wg_end) pool_body<64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[0], w);
-        else pool_body<64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[1], w - a.pool[0].wg_end);
+        if (w < a.pool[0].wg_end) pool_body<T, 64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[0], w);
+        else pool_body<T, 64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[1], w - a.pool[0].wg_end);
         return;
     }
     int pi = 0, begin = 0;
@@ -533,13 +573,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_gro
     const unsigned __attribute__((address_space(4)))* src = (const unsigned __attribute__((address_space(4)))*)&ka->p[pi];
 #pragma unroll
     for (int i = 0; i < (int)(sizeof(ConvP) / 4); ++i) u.w[i] = src[i];
-    conv_body<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(u.p, tile - begin, smem);
+    conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(u.p, tile - begin, smem);
 }
 
-template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
+template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_one(ConvP p) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
-    conv_body<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(p, blockIdx.x, smem);
+    conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(p, blockIdx.x, smem);
 }
 
 // ---- host side -------------------------------------------------------------------------------
@@ -581,8 +621,10 @@ int validate(const fcn_conv_desc& d) {
     FCN_REQUIRE(d.x && d.w && d.y, FCN_E_ARG, "conv: null x/w/y");
     FCN_REQUIRE(d.N > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.kh > 0 && d.kw > 0 && d.stride > 0 && d.pad >= 0,
                 FCN_E_ARG, "conv: non-positive extent");
-    FCN_REQUIRE(d.Cin % 4 == 0 && d.x_cstride % 4 == 0 && d.x_cstride >= d.Cin, FCN_E_ALIGN,
-                "conv: Cin (%d) and x_cstride (%d) must be multiples of 4 (pad the input channels)", d.Cin, d.x_cstride);
+    const int eps = (d.flags & FCN_CONV_F16) ? 8 : 4;      // elements per 16-byte segment
+    FCN_REQUIRE(d.Cin % eps == 0 && d.x_cstride % eps == 0 && d.x_cstride >= d.Cin, FCN_E_ALIGN,
+                "conv: Cin (%d) and x_cstride (%d) must be multiples of %d (pad the input channels)", d.Cin, d.x_cstride, eps);
+    FCN_REQUIRE((d.flags & FCN_CONV_F16) || !(d.flags & FCN_CONV_OUT_F32), FCN_E_ARG, "conv: FCN_CONV_OUT_F32 only qualifies FCN_CONV_F16");
     FCN_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.w & 15) == 0, FCN_E_ALIGN, "conv: x/w must be 16-byte aligned");
     FCN_REQUIRE(d.OH == (d.H + 2 * d.pad - d.kh) / d.stride + 1 && d.OW == (d.W + 2 * d.pad - d.kw) / d.stride + 1,
                 FCN_E_ARG, "conv: OH/OW (%d,%d) do not match floor((H+2p-k)/s)+1", d.OH, d.OW);
@@ -657,22 +699,24 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
     return total;
 }
 
+template <typename T>
 void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
     switch (cfg) {
-#define X(I, A, B, C_, D, E, F, G, H)                                                                                           \
-    case I:                                                                                                                     \
-        hipLaunchKernelGGL((conv_fwd_one<A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, p); \
+#define X(I, A, B, C_, D, E, F, G, H)                                                                                                 \
+    case I:                                                                                                                           \
+        hipLaunchKernelGGL((conv_fwd_one<T, A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, p); \
         break;
         FCN_CONV_CONFIGS(X)
 #undef X
     }
 }
 
+template <typename T>
 void launch_group_cfg(int cfg, const GroupArgs& ga, int total, hipStream_t st) {
     switch (cfg) {
-#define X(I, A, B, C_, D, E, F, G, H)                                                                                                  \
-    case I:                                                                                                                            \
-        hipLaunchKernelGGL((conv_fwd_group<A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, ga); \
+#define X(I, A, B, C_, D, E, F, G, H)                                                                                                     \
+    case I:                                                                                                                               \
+        hipLaunchKernelGGL((conv_fwd_group<T, A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, ga); \
         break;
         FCN_CONV_CONFIGS(X)
 #undef X
@@ -698,7 +742,8 @@ int fcn_conv2d_fwd_f32(const fcn_conv_desc* h_desc, fcn_stream_t s) {
     fill(p, *h_desc, zp);
     const int cfg = choose_cfg(&p, 1);
     const int total = plan_tiles_cfg(cfg, &p, 1);
-    launch_one_cfg(cfg, p, total, as_stream(s));
+    if (h_desc->flags & FCN_CONV_F16) launch_one_cfg<f16_t>(cfg, p, total, as_stream(s));
+    else launch_one_cfg<float>(cfg, p, total, as_stream(s));
     FCN_LAUNCH_CHECK("conv_fwd_one");
     return 0;
 }
@@ -724,8 +769,10 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
     for (int i = 0; i < n; ++i) {
         int rc = validate(h_descs[i]);
         if (rc) return rc;
+        FCN_REQUIRE(((h_descs[i].flags ^ h_descs[0].flags) & FCN_CONV_F16) == 0, FCN_E_ARG, "conv group: f32 and f16 problems cannot share a launch");
         fill(ps[i], h_descs[i], zp);
     }
+    const int group_f16 = (h_descs[0].flags & FCN_CONV_F16) ? 1 : 0;
     PoolP pools[kMaxPool] = {};
     for (int i = 0; i < npools; ++i) {
         const fcn_pool_desc& d = h_pools[i];
@@ -733,15 +780,17 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
                         d.OW > 0, FCN_E_ARG, "fused maxpool: bad args");
         FCN_REQUIRE((d.OH - 1) * d.stride - d.pad < d.H && (d.OW - 1) * d.stride - d.pad < d.W, FCN_E_ARG,
                     "fused maxpool: last window starts outside the image");
-        FCN_REQUIRE(d.C % 4 == 0 && d.x_cstride % 4 == 0 && d.y_cstride % 4 == 0 && d.y_coffset % 4 == 0 && d.x_cstride >= d.C &&
-                        d.y_coffset >= 0 && d.y_cstride >= d.y_coffset + d.C, FCN_E_ALIGN, "fused maxpool: channels / strides must be multiples of 4");
+        const int peps = group_f16 ? 8 : 4;
+        FCN_REQUIRE((d.f16 ? 1 : 0) == group_f16, FCN_E_ARG, "fused maxpool: element type differs from the group's convolutions");
+        FCN_REQUIRE(d.C % peps == 0 && d.x_cstride % peps == 0 && d.y_cstride % peps == 0 && d.y_coffset % peps == 0 && d.x_cstride >= d.C &&
+                        d.y_coffset >= 0 && d.y_cstride >= d.y_coffset + d.C, FCN_E_ALIGN, "fused maxpool: channels / strides must be multiples of %d", peps);
         FCN_REQUIRE((((uintptr_t)d.x | (uintptr_t)d.y | (uintptr_t)d.idx) & 15) == 0, FCN_E_ALIGN, "fused maxpool: pointers must be 16-byte aligned");
-        FCN_REQUIRE((long long)d.N * d.OH * d.OW * (d.C / 4) < (1ll << 30), FCN_E_UNSUPPORTED, "fused maxpool: too large");
+        FCN_REQUIRE((long long)d.N * d.OH * d.OW * (d.C / peps) < (1ll << 30), FCN_E_UNSUPPORTED, "fused maxpool: too large");
         PoolP& q = pools[i];
         q.x = d.x; q.y = d.y; q.idx = d.idx;
         q.N = d.N; q.H = d.H; q.W = d.W; q.C = d.C; q.x_cstride = d.x_cstride; q.k = d.k; q.stride = d.stride; q.pad = d.pad;
         q.OH = d.OH; q.OW = d.OW; q.y_cstride = d.y_cstride; q.y_coffset = d.y_coffset;
-        q.items = d.N * d.OH * d.OW * (d.C / 4);
+        q.items = d.N * d.OH * d.OW * (d.C / peps);
         q.wg_end = 0;      // depends on the workgroup size of the tile configuration: set at launch
     }
     const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
@@ -796,7 +845,8 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
             }
             grid += end;
         }
-        launch_group_cfg(g->cfg, ga, grid, as_stream(s));
+        if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, grid, as_stream(s));
+        else launch_group_cfg<float>(g->cfg, ga, grid, as_stream(s));
         FCN_LAUNCH_CHECK("conv_fwd_group");
     }
     return 0;

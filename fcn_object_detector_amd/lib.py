@@ -45,7 +45,7 @@ class SolverSeg(C.Structure):
 
 class PoolDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("idx", C.c_void_p)] + [(k, C.c_int32) for k in (
-        "N", "H", "W", "C", "x_cstride", "k", "stride", "pad", "OH", "OW", "y_cstride", "y_coffset")]
+        "N", "H", "W", "C", "x_cstride", "k", "stride", "pad", "OH", "OW", "y_cstride", "y_coffset", "f16")]
 
 
 class SceneObj(C.Structure):
@@ -67,7 +67,7 @@ class DetectParams(C.Structure):
     ]
 
 
-CONV_RELU, CONV_SIGMOID2, CONV_ACCUM = 1, 2, 4
+CONV_RELU, CONV_SIGMOID2, CONV_ACCUM, CONV_OUT_F32, CONV_F16 = 1, 2, 4, 8, 16
 ELT_PROD, ELT_SUM, ELT_MAX = 0, 1, 2
 RECT_ROUND_NEAREST_EVEN, RECT_ROUND_TRUNCATE = 0, 1
 

@@ -91,6 +91,10 @@ int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int
 #define FCN_CONV_RELU      1   /* y = max(y, 0)                                  */
 #define FCN_CONV_SIGMOID2  2   /* y2 = sigmoid(y) is written as well (y2 != NULL) */
 #define FCN_CONV_ACCUM     4   /* y += result (gradient fan-in when the kernel runs as a data-gradient pass) */
+#define FCN_CONV_OUT_F32   8   /* with FCN_CONV_F16: y is float32 (the detection heads feed the f32 decode kernel)   */
+#define FCN_CONV_F16      16   /* x, w and y hold IEEE half floats (v_mfma_f32_32x32x16_f16, f32 accumulate, f32 bias):
+                                * BASELINE configs[4].  Cin and x_cstride must then be multiples of 8; the pointers of
+                                * the descriptor are typed float* for both element types */
 typedef struct fcn_conv_desc {
     const float* x;      /* NHWC input, channel stride x_cstride                           */
     const float* w;      /* weights [Cout][kh][kw][Cin]  (OHWI, Cin contiguous)            */
@@ -127,6 +131,7 @@ int  fcn_conv2d_fwd_group_f32(const fcn_conv_group* h_group, fcn_stream_t s);
 typedef struct fcn_pool_desc {
     const float* x; float* y; int32_t* idx;
     int32_t N, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride, y_coffset;
+    int32_t f16;           /* 1: x / y hold half floats (C and the strides then multiples of 8), must match the group's convolutions */
 } fcn_pool_desc;
 int  fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fcn_pool_desc* h_pools, int npools, void* d_workspace,
                                     int cfg_request, fcn_conv_group* h_out);

@@ -1,0 +1,121 @@
+"""f16 activations / weights with f32 accumulation (BASELINE configs[4]: v_mfma_f32_32x32x16_f16 path), kernel level (-m gpu).
+
+Tolerance: the inputs of the oracle are the SAME f16-rounded values, products of halves are exact in f32 and the
+accumulation is f32 on both sides, so with FCN_CONV_OUT_F32 only the summation order differs (1e-5); with an f16 output
+the final rounding adds half an f16 ulp (2^-11 = 4.9e-4 relative): 1e-3."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from fcn_object_detector_amd import lib as L
+from fcn_object_detector_amd.engine import DeviceBuffer
+from gpu_util import conv_desc, dev_from, dev_to
+from oracle import caffe_ref as R
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # cin, cout, k, stride, pad, h, w, n
+    (3, 64, 7, 2, 3, 61, 45, 1),        # conv1: Cin 3 padded to 8
+    (64, 192, 3, 1, 1, 23, 19, 2),
+    (16, 32, 5, 1, 2, 17, 28, 1),
+    (24, 64, 5, 1, 2, 14, 14, 2),       # taps straddle chunk boundaries
+    (192, 48, 1, 1, 0, 9, 11, 1),
+    (112, 33, 3, 1, 1, 12, 7, 1),
+    (832, 384, 1, 1, 0, 7, 7, 1),
+    (1024, 4, 1, 1, 0, 28, 28, 1),
+]
+
+
+def r8(c):
+    return (c + 7) // 8 * 8
+
+
+def f16_conv(x, wt, b, pad, stride, flags, out_f32, y_cstride=None, y_coffset=0):
+    n, cin, h, w = x.shape
+    cout, _, k, _ = wt.shape
+    ci8 = r8(cin)
+    oh, ow = R.conv_out(h, k, pad, stride), R.conv_out(w, k, pad, stride)
+    xh = np.zeros((n, h, w, ci8), np.float16)
+    xh[..., :cin] = x.transpose(0, 2, 3, 1)
+    wh = np.zeros((cout, k, k, ci8), np.float16)
+    wh[..., :cin] = wt.transpose(0, 2, 3, 1)
+    ycs = y_cstride or r8(cout)
+    yd = dev_from(np.full((n, oh, ow, ycs), -7.0, np.float32 if out_f32 else np.float16))
+    xd, wd, bd = dev_from(xh), dev_from(wh), dev_from(b)
+    d = conv_desc(xd, wd, bd, yd, n, h, w, ci8, ci8, cout, k, pad, stride, oh, ow, ycs, y_coffset,
+                  flags | L.CONV_F16 | (L.CONV_OUT_F32 if out_f32 else 0))
+    L.call("fcn_conv2d_fwd_f32", C.byref(d), None)
+    y = dev_to(yd, (n, oh, ow, ycs), np.float32 if out_f32 else np.float16)
+    return y
+
+
+@pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15"])
+@pytest.mark.parametrize("case", CASES)
+def test_f16_conv_matches_oracle_on_the_same_rounded_inputs(gpu, monkeypatch, case, cfg):
+    if cfg is None:
+        monkeypatch.delenv("FCN_CONV_CFG", raising=False)
+    else:
+        monkeypatch.setenv("FCN_CONV_CFG", cfg)
+    cin, cout, k, s, p, h, w, n = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float16).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = np.maximum(R.conv2d(x, wt, b, p, s), 0)
+    y32 = f16_conv(x, wt, b, p, s, L.CONV_RELU, True)
+    assert rel_err(y32[..., :cout].transpose(0, 3, 1, 2), ref) < 1e-5
+    assert np.all(y32[..., cout:] == -7.0)
+    y16 = f16_conv(x, wt, b, p, s, L.CONV_RELU, False, r8(cout) + 8, 8)
+    got = y16[..., 8:8 + cout].astype(np.float32).transpose(0, 3, 1, 2)
+    assert rel_err(got, ref) < 1e-3
+    assert np.array_equal(got, ref.astype(np.float16).astype(np.float32)) or np.abs(got - ref).max() <= np.abs(ref).max() * 2.0 ** -10
+    assert np.all(y16[..., :8] == np.float16(-7.0)) and np.all(y16[..., 8 + cout:] == np.float16(-7.0))
+
+
+def test_f16_group_with_fused_pool_and_sigmoid_head(gpu):
+    """An f16 group launch: two convolutions + a fused MAX pooling (8 channels per 16-byte item) + the f32 sigmoid output."""
+    rng = np.random.default_rng(4)
+    n, h, w, cin = 2, 12, 9, 32
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float16).astype(np.float32)
+    xh = np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16)
+    xd = dev_from(xh)
+    descs, keep, refs = [], [], []
+    for cout, k, pad, sig in ((40, 1, 0, False), (6, 3, 1, True)):
+        wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float16).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        wd, bd = dev_from(np.ascontiguousarray(wt.transpose(0, 2, 3, 1)).astype(np.float16)), dev_from(b)
+        lin = R.conv2d(x, wt, b, pad, 1)
+        if sig:
+            yd = dev_from(np.zeros((n, h, w, 8), np.float32))
+            y2d = dev_from(np.zeros((n, h, w, 8), np.float32))
+            d = conv_desc(xd, wd, bd, yd, n, h, w, cin, cin, cout, k, pad, 1, h, w, 8, 0, L.CONV_F16 | L.CONV_OUT_F32 | L.CONV_SIGMOID2, 0.0,
+                          y2d, 8, 0)
+            refs.append((y2d, 8, cout, np.float32, R.sigmoid(lin), 1e-5))
+        else:
+            yd = dev_from(np.zeros((n, h, w, 40), np.float16))
+            d = conv_desc(xd, wd, bd, yd, n, h, w, cin, cin, cout, k, pad, 1, h, w, 40, 0, L.CONV_F16 | L.CONV_RELU)
+            refs.append((yd, 40, cout, np.float16, np.maximum(lin, 0), 1e-3))
+        keep += [wd, bd, yd]
+        descs.append(d)
+    pool_ref = R.max_pool(x, 3, 1, 1)
+    pd_ = dev_from(np.zeros((n, h, w, cin), np.float16))
+    pdsc = L.PoolDesc()
+    pdsc.x, pdsc.y, pdsc.idx = xd.ptr, pd_.ptr, None
+    pdsc.N, pdsc.H, pdsc.W, pdsc.C, pdsc.x_cstride, pdsc.k, pdsc.stride, pdsc.pad = n, h, w, cin, cin, 3, 1, 1
+    pdsc.OH, pdsc.OW, pdsc.y_cstride, pdsc.y_coffset, pdsc.f16 = h, w, cin, 0, 1
+    arr, parr = (L.ConvDesc * 2)(*descs), (L.PoolDesc * 1)(pdsc)
+    ws = DeviceBuffer(int(L.load().fcn_conv2d_group_workspace_bytes(2)), zero=False)
+    grp = L.ConvGroup()
+    L.call("fcn_conv2d_group_prepare_fused", arr, 2, parr, 1, ws.ptr, 5, C.byref(grp))
+    L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+    for yd, cs, cout, dt, ref, tol in refs:
+        got = dev_to(yd, (n, h, w, cs), dt)[..., :cout].astype(np.float32).transpose(0, 3, 1, 2)
+        assert rel_err(got, ref) < tol
+    assert np.array_equal(dev_to(pd_, (n, h, w, cin), np.float16).astype(np.float32).transpose(0, 3, 1, 2), pool_ref)
+    # an f32 pooling cannot ride in an f16 group, nor an f16 problem beside an f32 one
+    pdsc.f16 = 0
+    assert L.load().fcn_conv2d_group_prepare_fused(arr, 2, (L.PoolDesc * 1)(pdsc), 1, ws.ptr, 5, C.byref(grp)) == 1
+    descs[1].flags = L.CONV_RELU
+    assert L.load().fcn_conv2d_group_prepare_fused((L.ConvDesc * 2)(*descs), 2, None, 0, ws.ptr, 5, C.byref(grp)) != 0
