@@ -180,10 +180,11 @@ def bench_train_data_layer(cp, rank, world, local, comm, n, steps):
                         "+ device target generation + fwd + bwd + SGD, batch %d/GPU" % n}
 
 
-def bench_infer32(local: int, reps: int = 10):
-    """BASELINE configs[4] without its fp16 arithmetic (the f32 path is what exists): 32 uint8 frames resident in HBM ->
-    pre-processing -> one forward -> one fused decode + groupRectangles launch for all (image, class) pairs -> boxes on
-    the host.  End-to-end frames/s of FCNObjectDetector.run_detector_batch minus the frame upload."""
+def bench_infer32(local: int, dtype: str, reps: int = 10):
+    """BASELINE configs[4]: 32 uint8 frames resident in HBM -> pre-processing -> one forward -> one fused decode +
+    groupRectangles launch for all (image, class) pairs -> boxes on the host (FCNObjectDetector.run_detector_batch minus
+    the frame upload).  dtype "f16": activations and weights stored as halves, v_mfma_f32_32x32x16_f16 with f32
+    accumulation (the image and conv1's weights stay f32: the net shifts a [0,1] image by -127); "f32" beside it."""
     from fcn_object_detector_amd import lib as L, models, proto
     from fcn_object_detector_amd.detector import FCNObjectDetector, HeadMapping
     from fcn_object_detector_amd.engine import DeviceBuffer, Engine
@@ -192,7 +193,7 @@ def bench_infer32(local: int, reps: int = 10):
     msg = proto.parse_text(models.googlenet_detectnet_deploy(n, 448, 448, 4))
     spec = NetSpec(msg, "TEST")
     spec.infer()
-    eng = Engine(NetSpec(msg, "TEST"), params=fill_params(spec, seed=1234), device=local)
+    eng = Engine(NetSpec(msg, "TEST"), params=fill_params(spec, seed=1234), device=local, dtype=dtype)
     det = FCNObjectDetector(eng, 0.5, 3, 0.2, HeadMapping.detectnet_deploy())
     frames = np.random.default_rng(9).integers(0, 256, (n, 448, 448, 3), dtype=np.uint8)
     dev = DeviceBuffer(frames.nbytes, zero=False)
@@ -201,8 +202,8 @@ def bench_infer32(local: int, reps: int = 10):
 
     def once():
         for i in range(n):
-            L.call("fcn_preprocess_bgr8", dev.ptr + i * 448 * 448 * 3, 448, 448, data.ptr + 4 * i * 448 * 448 * data.cstride, 448, 448,
-                   data.cstride, data.upload_shift, det._minmax.ptr, eng.stream)
+            L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", dev.ptr + i * 448 * 448 * 3, 448, 448,
+                   data.ptr + data.esize * i * 448 * 448 * data.cstride, 448, 448, data.cstride, data.upload_shift, det._minmax.ptr, eng.stream)
         eng.forward_resident(1)
         det.decoder.launch(*det._cvg_args, *det._box_args, eng.stream)
         return det.decoder.fetch(eng.stream)
@@ -212,10 +213,12 @@ def bench_infer32(local: int, reps: int = 10):
     for _ in range(reps):
         res = once()
     dt = (time.perf_counter() - t0) / reps
+    fwd_ms = eng.forward_resident(5) / 5
+    heads = {k: eng.read_blob(k).copy() for k in ("coverage", "bboxes")}
     eng.close()
-    return {"frames_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "dtype": "f32", "batch": n,
-            "detections_last_batch": int(sum(len(r[0]) for r in res)),
-            "note": "pre-processing + forward + fused decode/groupRectangles + read-back of the boxes; the fp16 MFMA arithmetic of configs[4] is not built"}
+    return {"frames_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "forward_ms": round(fwd_ms, 3),
+            "forward_tflops": round(FWD_GFLOP * n / fwd_ms, 1), "dtype": dtype, "batch": n,
+            "detections_last_batch": int(sum(len(r[0]) for r in res))}, heads
 
 
 def bench_vgg(steps: int = 5):
@@ -407,7 +410,11 @@ def main() -> None:
         out["forward_batch8"] = {"frames_per_s": round(8e3 / ms8, 1), "ms_per_step": round(ms8, 4), "conv_family_tflops": round(conv8, 2),
                                  "conv_family_frac_of_f32_mfma_peak": round(conv8 / F32_MFMA_PEAK_TFLOPS, 4)}
         eng8.close()
-        out["inference_batch32"] = bench_infer32(local)
+        r32, h32 = bench_infer32(local, "f32")
+        r16, h16 = bench_infer32(local, "f16")
+        r16["rel_err_vs_f32"] = {k: float("%.3e" % (np.abs(h16[k] - h32[k]).max() / max(np.abs(h32[k]).max(), 1e-30))) for k in h32}
+        out["inference_batch32"] = {"workload": "configs[4]: batch 32, 448x448, pre-processing + forward + fused decode/groupRectangles + read-back",
+                                    "f16": r16, "f32": r32}
         out["secondary"] = bench_vgg()
     cp.close()
     if out is not None:

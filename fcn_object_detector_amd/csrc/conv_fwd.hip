@@ -516,6 +516,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const bool do_sig2 = (p.flags & FCN_CONV_SIGMOID2) != 0 && p.y2 != nullptr;
     const bool do_accum = (p.flags & FCN_CONV_ACCUM) != 0;
     const bool out_f32 = (p.flags & FCN_CONV_OUT_F32) != 0;      // f16 inputs, f32 output blob (the detection heads)
+    const bool out_f16 = (p.flags & FCN_CONV_OUT_F16) != 0;      // f32 inputs, f16 output blob (the first layer of an f16 net)
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
         const int n = n0 + (wn * WTN + j) * 32 + (lane & 31);
@@ -530,7 +531,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 if (m < p.M) {
                     float v = acc[i][j][r] + bv;
                     const size_t o = (size_t)m * p.y_cstride + p.y_coffset + n;
-                    if (F16 && !out_f32) {      // f16 activations: rounded once, after bias and ReLU
+                    if ((F16 && !out_f32) || (!F16 && out_f16)) {      // f16 activations: rounded once, after bias and ReLU
                         typedef f16_t __attribute__((address_space(1))) * gh_ptr;
                         gh_ptr dst = (gh_ptr)(reinterpret_cast<f16_t*>(p.y) + o);
                         if (do_accum) v += (float)*dst;
@@ -625,6 +626,7 @@ int validate(const fcn_conv_desc& d) {
     FCN_REQUIRE(d.Cin % eps == 0 && d.x_cstride % eps == 0 && d.x_cstride >= d.Cin, FCN_E_ALIGN,
                 "conv: Cin (%d) and x_cstride (%d) must be multiples of %d (pad the input channels)", d.Cin, d.x_cstride, eps);
     FCN_REQUIRE((d.flags & FCN_CONV_F16) || !(d.flags & FCN_CONV_OUT_F32), FCN_E_ARG, "conv: FCN_CONV_OUT_F32 only qualifies FCN_CONV_F16");
+    FCN_REQUIRE(!(d.flags & FCN_CONV_F16) || !(d.flags & FCN_CONV_OUT_F16), FCN_E_ARG, "conv: FCN_CONV_OUT_F16 only qualifies float32 inputs");
     FCN_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.w & 15) == 0, FCN_E_ALIGN, "conv: x/w must be 16-byte aligned");
     FCN_REQUIRE(d.OH == (d.H + 2 * d.pad - d.kh) / d.stride + 1 && d.OW == (d.W + 2 * d.pad - d.kw) / d.stride + 1,
                 FCN_E_ARG, "conv: OH/OW (%d,%d) do not match floor((H+2p-k)/s)+1", d.OH, d.OW);

@@ -22,14 +22,15 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 // ---------------------------------------------------------------------------------------------
 // NCHW <-> NHWC (pycaffe boundary).  32x32 LDS tile transpose over (C, H*W) per image.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+template <typename D>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, D* __restrict__ dst,
                                                            int C, int HW, int dst_cstride, int dst_coffset, float shift) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     const float* s = src + (size_t)n * C * HW;
-    float* d = dst + (size_t)n * HW * dst_cstride;
+    D* d = dst + (size_t)n * HW * dst_cstride;
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, p = p0 + tx;
         tile[i][tx] = (c < C && p < HW) ? s[(size_t)c * HW + p] : 0.f;
@@ -37,21 +38,22 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int p = p0 + i, c = c0 + tx;
-        if (p < HW && c < C) d[(size_t)p * dst_cstride + dst_coffset + c] = tile[tx][i] + shift;
+        if (p < HW && c < C) d[(size_t)p * dst_cstride + dst_coffset + c] = (D)(tile[tx][i] + shift);
     }
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+template <typename S>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const S* __restrict__ src, float* __restrict__ dst,
                                                            int C, int HW, int src_cstride, int src_coffset) {
     __shared__ float tile[32][33];
     const int n = blockIdx.z;
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const float* s = src + (size_t)n * HW * src_cstride;
+    const S* s = src + (size_t)n * HW * src_cstride;
     float* d = dst + (size_t)n * C * HW;
     for (int i = ty; i < 32; i += 8) {
         const int p = p0 + i, c = c0 + tx;
-        tile[i][tx] = (p < HW && c < C) ? s[(size_t)p * src_cstride + src_coffset + c] : 0.f;
+        tile[i][tx] = (p < HW && c < C) ? (float)s[(size_t)p * src_cstride + src_coffset + c] : 0.f;
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
@@ -321,6 +323,74 @@ int launch_unary(int op, const float* x, float* y, size_t count, float a, float 
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// half-float variants for the f16 inference path (BASELINE configs[4]): 8 channels per lane (one 16-byte access),
+// arithmetic in f32.  MAX pooling needs no argmax here (inference only).
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void maxpool_f16_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int N, int H, int W, int C,
+                                                          int x_cstride, int k, int stride, int pad, int OH, int OW, int y_cstride,
+                                                          int y_coffset) {
+    const int cg = C / 8;
+    const long long total = (long long)N * OH * OW * cg;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(t % cg);
+        long long pix = t / cg;
+        const int ox = (int)(pix % OW);
+        pix /= OW;
+        const int oy = (int)(pix % OH);
+        const int n = (int)(pix / OH);
+        int hs = oy * stride - pad, ws = ox * stride - pad;
+        const int he = min(hs + k, H), we = min(ws + k, W);
+        hs = max(hs, 0);
+        ws = max(ws, 0);
+        const _Float16* xb = x + (size_t)n * H * W * x_cstride + g * 8;
+        h8_t m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (_Float16)-65504.f;
+        for (int iy = hs; iy < he; ++iy)
+            for (int ix = ws; ix < we; ++ix) {
+                const h8_t v = *(const h8_t*)(xb + ((size_t)iy * W + ix) * x_cstride);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        *(h8_t*)(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + y_coffset + g * 8) = m;
+    }
+}
+
+// LRN across channels, local_size 5: the window of 8 channels lives in the 24 halves c-8..c+15 of the pixel
+__global__ __launch_bounds__(256) void lrn5_f16_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, long long pixels, int C,
+                                                       int x_cstride, int y_cstride, float alpha_over_n, float beta, float kk) {
+    const int cg = C / 8;
+    const long long total = pixels * cg;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int g = (int)(t % cg);
+        const long long pix = t / cg;
+        const _Float16* xp = x + (size_t)pix * x_cstride + g * 8;
+        const h8_t c = *(const h8_t*)xp;
+        h8_t l, r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) l[e] = r[e] = (_Float16)0.f;
+        if (g > 0) l = *(const h8_t*)(xp - 8);
+        if (g + 1 < cg) r = *(const h8_t*)(xp + 8);
+        float q[12];      // squares of channels c-2 .. c+9
+        q[0] = (float)l[6] * (float)l[6];
+        q[1] = (float)l[7] * (float)l[7];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q[2 + e] = (float)c[e] * (float)c[e];
+        q[10] = (float)r[0] * (float)r[0];
+        q[11] = (float)r[1] * (float)r[1];
+        h8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s = kk + alpha_over_n * (q[e] + q[e + 1] + q[e + 2] + q[e + 3] + q[e + 4]);
+            o[e] = (_Float16)((float)c[e] * pow_neg_beta(s, beta));
+        }
+        *(h8_t*)(y + (size_t)pix * y_cstride + g * 8) = o;
+    }
+}
+
 extern "C" {
 
 int fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int dst_cstride, int dst_coffset, float shift,
@@ -330,8 +400,33 @@ int fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int 
     FCN_REQUIRE(N <= 65535, FCN_E_UNSUPPORTED, "nchw_to_nhwc: batch too large");
     const int HW = H * W;
     dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, dst_cstride, dst_coffset, shift);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, dst_cstride, dst_coffset, shift);
     FCN_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+int fcn_nchw_f32_to_nhwc_f16(const float* src, void* dst, int N, int C, int H, int W, int dst_cstride, int dst_coffset, float shift,
+                             fcn_stream_t s) {
+    FCN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, FCN_E_ARG, "nchw_to_nhwc_f16: bad args");
+    FCN_REQUIRE(dst_coffset >= 0 && dst_cstride >= dst_coffset + C, FCN_E_ARG, "nchw_to_nhwc_f16: slice exceeds dst_cstride");
+    FCN_REQUIRE(N <= 65535, FCN_E_UNSUPPORTED, "nchw_to_nhwc_f16: batch too large");
+    const int HW = H * W;
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<_Float16>, grid, dim3(256), 0, as_stream(s), src, reinterpret_cast<_Float16*>(dst), C, HW, dst_cstride,
+                       dst_coffset, shift);
+    FCN_LAUNCH_CHECK("nchw_to_nhwc_f16");
+    return 0;
+}
+
+int fcn_nhwc_f16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, int W, int src_cstride, int src_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0, FCN_E_ARG, "nhwc_f16_to_nchw: bad args");
+    FCN_REQUIRE(src_coffset >= 0 && src_cstride >= src_coffset + C, FCN_E_ARG, "nhwc_f16_to_nchw: slice exceeds src_cstride");
+    FCN_REQUIRE(N <= 65535, FCN_E_UNSUPPORTED, "nhwc_f16_to_nchw: batch too large");
+    const int HW = H * W;
+    dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<_Float16>, grid, dim3(256), 0, as_stream(s), reinterpret_cast<const _Float16*>(src), dst, C, HW,
+                       src_cstride, src_coffset);
+    FCN_LAUNCH_CHECK("nhwc_f16_to_nchw");
     return 0;
 }
 
@@ -341,7 +436,7 @@ int fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int 
     FCN_REQUIRE(N <= 65535, FCN_E_UNSUPPORTED, "nhwc_to_nchw: batch too large");
     const int HW = H * W;
     dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, src_cstride, src_coffset);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, src_cstride, src_coffset);
     FCN_LAUNCH_CHECK("nhwc_to_nchw");
     return 0;
 }
@@ -451,4 +546,31 @@ int fcn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* bi
     return 0;
 }
 
+
+int fcn_maxpool_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad, int OH, int OW,
+                        int y_cstride, int y_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && pad < k && OH > 0 && OW > 0, FCN_E_ARG,
+                "maxpool_f16: bad args");
+    FCN_REQUIRE((OH - 1) * stride - pad < H && (OW - 1) * stride - pad < W, FCN_E_ARG, "maxpool_f16: last window starts outside the image");
+    FCN_REQUIRE(C % 8 == 0 && x_cstride % 8 == 0 && y_cstride % 8 == 0 && y_coffset % 8 == 0 && x_cstride >= C && y_coffset >= 0 &&
+                    y_cstride >= y_coffset + C && aligned16(x) && aligned16(y), FCN_E_ALIGN, "maxpool_f16: channels / strides must be multiples of 8");
+    hipLaunchKernelGGL(maxpool_f16_kernel, dim3(stream_grid((long long)N * OH * OW * (C / 8), 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const _Float16*>(x), reinterpret_cast<_Float16*>(y), N, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
+                       y_coffset);
+    FCN_LAUNCH_CHECK("maxpool_f16");
+    return 0;
+}
+
+int fcn_lrn_fwd_f16(const void* x, void* y, int pixels, int C, int x_cstride, int y_cstride, int local_size, float alpha, float beta, float k,
+                    fcn_stream_t s) {
+    FCN_REQUIRE(x && y && pixels > 0 && C > 0, FCN_E_ARG, "lrn_f16: bad args");
+    FCN_REQUIRE(local_size == 5, FCN_E_UNSUPPORTED, "lrn_f16: local_size %d (the reference nets use 5)", local_size);
+    FCN_REQUIRE(C % 8 == 0 && x_cstride % 8 == 0 && y_cstride % 8 == 0 && x_cstride >= C && y_cstride >= C && aligned16(x) && aligned16(y),
+                FCN_E_ALIGN, "lrn_f16: channels / strides must be multiples of 8");
+    hipLaunchKernelGGL(lrn5_f16_kernel, dim3(stream_grid((long long)pixels * (C / 8), 256)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<const _Float16*>(x), reinterpret_cast<_Float16*>(y), (long long)pixels, C, x_cstride, y_cstride,
+                       alpha / (float)local_size, beta, k);
+    FCN_LAUNCH_CHECK("lrn_f16");
+    return 0;
+}
 }  // extern "C"

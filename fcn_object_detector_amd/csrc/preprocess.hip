@@ -57,7 +57,8 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restrict__ frame, int h, int w, float* __restrict__ dst, int H,
+template <typename D>
+__global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restrict__ frame, int h, int w, D* __restrict__ dst, int H,
                                                           int W, int cstride, float shift, const int* __restrict__ mm) {
     double gmin = 1e300, gmax = -1e300;
 #pragma unroll
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
             const double s11 = ((double)frame[((size_t)sy1 * w + sx1) * 3 + c] - m - gmin) / range;
             const double r0 = s00 * a0 + s01 * a1;
             const double r1 = s10 * a0 + s11 * a1;
-            dst[(size_t)t * cstride + c] = (float)(r0 * b0 + r1 * b1) + shift;   // blob value rounded to f32 first, as Caffe's Power layer sees it
+            dst[(size_t)t * cstride + c] = (D)((float)(r0 * b0 + r1 * b1) + shift);   // blob value rounded to f32 first, as Caffe's Power layer sees it
         }
     }
 }
@@ -101,8 +102,8 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
 
 extern "C" {
 
-int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
-                        fcn_stream_t s) {
+static int preprocess_any(const uint8_t* frame, int h, int w, void* dst, bool f16, int H, int W, int dst_cstride, float shift, float* d_minmax,
+                          fcn_stream_t s) {
     FCN_REQUIRE(frame && dst && d_minmax && h > 0 && w > 0 && H > 0 && W > 0 && dst_cstride >= 3, FCN_E_ARG, "preprocess: bad args");
     hipStream_t st = as_stream(s);
     int* mm = reinterpret_cast<int*>(d_minmax);
@@ -110,10 +111,24 @@ int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, i
     int mm_blocks = stream_grid((long long)h * w, 256 * 16);      // >= 16 pixels per lane: a few hundred workgroups at most
     if (mm_blocks > 256) mm_blocks = 256;
     hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks), dim3(256), 0, st, frame, (long long)h * w, mm);
-    hipLaunchKernelGGL(resize_norm_kernel, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, st, frame, h, w, dst, H, W, dst_cstride,
-                       shift, mm);
+    if (f16)
+        hipLaunchKernelGGL(resize_norm_kernel<_Float16>, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, st, frame, h, w,
+                           reinterpret_cast<_Float16*>(dst), H, W, dst_cstride, shift, mm);
+    else
+        hipLaunchKernelGGL(resize_norm_kernel<float>, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, st, frame, h, w,
+                           reinterpret_cast<float*>(dst), H, W, dst_cstride, shift, mm);
     FCN_LAUNCH_CHECK("preprocess_bgr8");
     return 0;
+}
+
+int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
+                        fcn_stream_t s) {
+    return preprocess_any(frame, h, w, dst, false, H, W, dst_cstride, shift, d_minmax, s);
+}
+
+int fcn_preprocess_bgr8_f16(const uint8_t* frame, int h, int w, void* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
+                            fcn_stream_t s) {
+    return preprocess_any(frame, h, w, dst, true, H, W, dst_cstride, shift, d_minmax, s);
 }
 
 }  // extern "C"

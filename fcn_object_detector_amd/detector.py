@@ -232,8 +232,8 @@ class FCNObjectDetector:
             off = 0
             for i, f in enumerate(frames):
                 L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr + off, f.ctypes.data, f.nbytes, eng.stream)
-                L.call("fcn_preprocess_bgr8", self._frame_dev.ptr + off, f.shape[0], f.shape[1],
-                       data.ptr + 4 * i * self.im_height * self.im_width * data.cstride, self.im_height, self.im_width, data.cstride,
+                L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", self._frame_dev.ptr + off, f.shape[0], f.shape[1],
+                       data.ptr + data.esize * i * self.im_height * self.im_width * data.cstride, self.im_height, self.im_width, data.cstride,
                        data.upload_shift, self._minmax.ptr, eng.stream)
                 off += (f.nbytes + 15) // 16 * 16
             eng.forward_resident(1)
@@ -260,8 +260,8 @@ class FCNObjectDetector:
                 self._frame_dev = DeviceBuffer(frame.nbytes, zero=False)
             data = eng.blobs["data"]
             L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, frame.ctypes.data, frame.nbytes, eng.stream)
-            L.call("fcn_preprocess_bgr8", self._frame_dev.ptr, h, w, data.ptr, self.im_height, self.im_width, data.cstride,
-                   data.upload_shift, self._minmax.ptr, eng.stream)
+            L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", self._frame_dev.ptr, h, w, data.ptr, self.im_height,
+                   self.im_width, data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
             eng.forward_resident(1)
             self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
             dets, labels = self.decoder.fetch(eng.stream)[0]

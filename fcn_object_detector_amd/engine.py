@@ -35,6 +35,12 @@ def _r4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+def _ra(c: int, esize: int) -> int:
+    """Channel count rounded up to whole 16-byte segments of `esize`-byte elements (4 floats / 8 halves)."""
+    eps = 16 // esize
+    return (c + eps - 1) // eps * eps
+
+
 class DeviceBuffer:
     """Owns one hipMalloc allocation."""
 
@@ -106,6 +112,7 @@ class Blob:
         self.buf: Optional[DeviceBuffer] = None
         self.coffset = 0
         self.cstride = 0
+        self.esize = 4                 # bytes per element on the device: 4 (float32) or 2 (half, Engine(dtype="f16"))
         self.lazy_shift = 0.0          # value added when the blob is read back (Power layer folded into the upload)
         self.upload_shift = 0.0        # value added while the blob is uploaded (device copy = host + upload_shift)
         self.host: Optional[np.ndarray] = None
@@ -124,7 +131,7 @@ class Blob:
     @property
     def ptr(self) -> int:
         """Device address of channel 0 of pixel 0 of this view."""
-        return self.buf.ptr + 4 * self.coffset
+        return self.buf.ptr + self.esize * self.coffset
 
     @property
     def contiguous(self) -> bool:
@@ -147,7 +154,12 @@ class Engine:
 
     def __init__(self, spec: NetSpec, data_shapes: Optional[Dict[str, Tuple[int, ...]]] = None,
                  params: Optional[Dict[str, List[np.ndarray]]] = None, device: int = 0,
-                 fuse: bool = True, group_convs: bool = True, autotune: bool = True):
+                 fuse: bool = True, group_convs: bool = True, autotune: bool = True, dtype: str = "f32"):
+        if dtype not in ("f32", "f16"):
+            raise ValueError("dtype must be 'f32' or 'f16'")
+        if dtype == "f16" and spec.phase != "TEST":
+            raise NotImplementedError("the half-float path is inference only (BASELINE configs[4])")
+        self.dtype, self.f16 = dtype, dtype == "f16"      # f16: activations / weights stored as halves, f32 accumulation
         self.spec = spec
         self.device = device
         self.fuse = fuse
@@ -190,6 +202,20 @@ class Engine:
                 consumers.setdefault(b, []).append(l)
         self.producers, self.consumers = producers, consumers
         data_tops = set(self.inputs)
+        # f16 mode: everything is stored as halves except what leaves the net towards the f32 decode kernel - the output
+        # blobs and the input / output of a Sigmoid head (written by the convolution epilogue in f32)
+        esize: Dict[str, int] = {}
+        for name, shp in self.shapes.items():
+            wide = (not self.f16 or len(shp) != 4 or name in self.outputs or name in data_tops      # inputs stay float32 (Power(-127) quirk)
+                    or any(q.type == "Power" and q.bottoms[0] in data_tops for q in producers.get(name, []))
+                    or any(q.type == "Sigmoid" for q in consumers.get(name, [])) or any(q.type == "Sigmoid" for q in producers.get(name, [])))
+            esize[name] = 4 if wide else 2
+        if self.f16:
+            for name in self.shapes:
+                if esize[name] == 4 and len(self.shapes[name]) == 4 and name not in data_tops:
+                    bad = [q.type for q in producers.get(name, []) if q.type not in ("Convolution", "Sigmoid", "Power")]
+                    if bad:
+                        raise NotImplementedError("f16 engine: float32 blob %s is produced by %s" % (name, bad))
 
         alias: Dict[str, Tuple[str, int]] = {}   # child blob -> (parent blob, channel offset in parent)
         shift: Dict[str, float] = {}
@@ -202,7 +228,8 @@ class Engine:
                 for b in l.bottoms:
                     c = self.shapes[b][1]
                     prods = [p for p in producers.get(b, []) if not (p.type in ("ReLU", "Dropout") and p.bottoms == p.tops)]
-                    good = (self.fuse and b not in data_tops and b not in alias and c % 4 == 0 and len(prods) == 1
+                    good = (self.fuse and b not in data_tops and b not in alias and c % (16 // esize[b]) == 0 and len(prods) == 1
+                            and esize[b] == esize[l.tops[0]]
                             and prods[0].type in ("Convolution", "Pooling")
                             and [q.type for q in consumers.get(b, []) if not (q.type in ("ReLU", "Dropout") and q.bottoms == q.tops)] == ["Concat"])
                     ok = ok and good
@@ -235,12 +262,13 @@ class Engine:
         # allocate roots, then resolve views
         for name, shp in self.shapes.items():
             self.blobs[name] = Blob(name, shp)
+            self.blobs[name].esize = esize[name]
         for name, blob in self.blobs.items():
             if name in alias:
                 continue
             if len(blob.shape) == 4:
-                blob.cstride = _r4(blob.channels)
-                blob.buf = DeviceBuffer(blob.pixels * blob.cstride * 4)
+                blob.cstride = _ra(blob.channels, blob.esize)
+                blob.buf = DeviceBuffer(blob.pixels * blob.cstride * blob.esize)
             else:
                 blob.cstride = 1
                 blob.buf = DeviceBuffer(16)
@@ -256,6 +284,8 @@ class Engine:
                 if seen > 64:
                     raise RuntimeError("alias cycle at blob %s" % name)
             b, r = self.blobs[name], self.blobs[root]
+            if b.esize != r.esize:
+                raise NotImplementedError("f16 engine: blob %s (%d-byte elements) is a view of %s (%d-byte)" % (name, b.esize, root, r.esize))
             b.buf, b.coffset, b.cstride = r.buf, r.coffset + off, r.cstride
             if total_shift:
                 r.upload_shift = total_shift      # device copy of the input = host value + shift
@@ -290,13 +320,14 @@ class Engine:
             for i, arr in enumerate(packed):
                 lm = l.lr_mult[i] if i < len(l.lr_mult) else 1.0
                 dm = l.decay_mult[i] if i < len(l.decay_mult) else 1.0
+                # offsets count 4-byte words (= floats in the f32 engine, where the solver and RCCL index this buffer)
                 self.param_layout.append(dict(layer=l.name, index=i, offset=off, count=int(arr.size), shape=tuple(arr.shape),
-                                              lr_mult=float(lm), decay_mult=float(dm)))
-                off += _r4(int(arr.size))
+                                              lr_mult=float(lm), decay_mult=float(dm), nbytes=int(arr.nbytes)))
+                off += _r4((int(arr.nbytes) + 3) // 4)
         self.param_count = off
         self.param_flat = DeviceBuffer(max(off, 4) * 4, zero=True)
         for e in self.param_layout:
-            self.params_dev.setdefault(e["layer"], []).append(DevView(self.param_flat.ptr + 4 * e["offset"], 4 * e["count"]))
+            self.params_dev.setdefault(e["layer"], []).append(DevView(self.param_flat.ptr + 4 * e["offset"], e["nbytes"]))
         for l in self.spec.param_layers():
             self._upload_params(l)
 
@@ -304,8 +335,8 @@ class Engine:
         w = self.params_host[l.name][0]
         if l.type == "Convolution":
             co, ci, kh, kw = w.shape
-            ci4 = _r4(ci)
-            out = np.zeros((co, kh, kw, ci4), F32)           # OHWI, Cin padded to a multiple of 4
+            xs = self.blobs[l.bottoms[0]].esize              # element type of the layer's input: 16-byte segments of it
+            out = np.zeros((co, kh, kw, _ra(ci, xs)), np.float16 if xs == 2 else F32)   # OHWI, Cin padded to whole segments
             out[..., :ci] = w.transpose(0, 2, 3, 1)
             return out
         if l.type == "Deconvolution":
@@ -339,20 +370,27 @@ class Engine:
         xb, yb = self.blobs[l.bottoms[0]], self.blobs[l.tops[0]]
         n, cin, h, w = xb.shape
         _, cout, oh, ow = yb.shape
-        if xb.coffset % 4 or xb.cstride % 4:
+        eps = 16 // xb.esize
+        if xb.coffset % eps or xb.cstride % eps:
             raise NotImplementedError("conv input view of %s is not 16-byte aligned" % l.name)
         d = L.ConvDesc()
         d.x, d.w = xb.ptr, self.params_dev[l.name][0].ptr
         d.bias = self.params_dev[l.name][1].ptr if len(self.params_dev[l.name]) > 1 else None
         d.y = yb.buf.ptr
-        d.N, d.H, d.W, d.Cin, d.x_cstride = n, h, w, _r4(cin), xb.cstride
+        d.N, d.H, d.W, d.Cin, d.x_cstride = n, h, w, _ra(cin, xb.esize), xb.cstride
         d.Cout, d.kh, d.kw, d.pad, d.stride, d.OH, d.OW = cout, k, k, pad, s, oh, ow
         d.y_cstride, d.y_coffset = yb.cstride, yb.coffset
         flags = 0
+        if xb.esize == 2:
+            flags |= L.CONV_F16 | (L.CONV_OUT_F32 if yb.esize == 4 else 0)
+        elif yb.esize != 4:
+            flags |= L.CONV_OUT_F16      # first layer of an f16 net: float32 image in, halves out
         if fused_relu:
             flags |= L.CONV_RELU
         if sig_top:
             sb = self.blobs[sig_top]
+            if sb.esize != 4:
+                raise NotImplementedError("sigmoid output %s must be float32" % sig_top)
             d.y2, d.y2_cstride, d.y2_coffset = sb.buf.ptr, sb.cstride, sb.coffset
             flags |= L.CONV_SIGMOID2
         d.flags = flags
@@ -489,13 +527,17 @@ class Engine:
         n, c, h, w = xb.shape
         _, _, oh, ow = yb.shape
         k, s, pad = kernel_stride_pad(pp)
-        if c % 4 or xb.cstride % 4 or yb.cstride % 4 or yb.coffset % 4 or xb.coffset % 4 or n * oh * ow * (c // 4) >= 1 << 30:
+        eps = 16 // xb.esize
+        if xb.esize != yb.esize or (xb.esize == 2 and self.spec.phase != "TEST"):
+            return None
+        if c % eps or xb.cstride % eps or yb.cstride % eps or yb.coffset % eps or xb.coffset % eps or n * oh * ow * (c // eps) >= 1 << 30:
             return None
         idx = self.aux_dev.get(l.name)
         d = L.PoolDesc()
         d.x, d.y, d.idx = xb.ptr, yb.buf.ptr, (idx.ptr if idx is not None else None)
         d.N, d.H, d.W, d.C, d.x_cstride, d.k, d.stride, d.pad = n, h, w, c, xb.cstride, k, s, pad
         d.OH, d.OW, d.y_cstride, d.y_coffset = oh, ow, yb.cstride, yb.coffset
+        d.f16 = 1 if xb.esize == 2 else 0
         return d
 
     def _tuned_cfg(self, name: str, arr, n: int, ws: DeviceBuffer, parr=None, npool: int = 0) -> int:
@@ -558,6 +600,9 @@ class Engine:
     def _emit_simple(self, l: Layer) -> List[Op]:
         B, lib, t = self.blobs, L.load(), l.type
         out: List[Op] = []
+        halves = [b for b in list(l.bottoms) + list(l.tops) if b in B and B[b].esize == 2]
+        if halves and t not in ("Pooling", "LRN"):
+            raise NotImplementedError("f16 engine: layer type %s (%s) has no half-float kernel" % (t, l.name))
         if t == "Pooling":
             xb, yb = B[l.bottoms[0]], B[l.tops[0]]
             pp = l.sub("pooling_param")
@@ -567,8 +612,13 @@ class Engine:
                 k, s, pad = h, 1, 0
             else:
                 k, s, pad = kernel_stride_pad(pp)
-            byts = 4.0 * (xb.pixels * c + yb.pixels * c)
-            if str(pp.get("pool", "MAX")) == "MAX":
+            byts = float(xb.esize) * (xb.pixels * c + yb.pixels * c)
+            if halves:
+                if str(pp.get("pool", "MAX")) != "MAX" or xb.esize != 2 or yb.esize != 2:
+                    raise NotImplementedError("f16 engine: pooling %s" % l.name)
+                out.append(Op("maxpool", l.name, lambda st: L.check(lib.fcn_maxpool_fwd_f16(
+                    xb.ptr, yb.buf.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, yb.coffset, st)), 0.0, byts))
+            elif str(pp.get("pool", "MAX")) == "MAX":
                 idx_ptr = None
                 if self.spec.phase == "TRAIN":      # backward routes the gradient to the argmax
                     ib = DeviceBuffer(yb.pixels * c * 4, zero=False)
@@ -592,6 +642,12 @@ class Engine:
                 sb = DeviceBuffer(xb.pixels * xb.channels * 4, zero=False)
                 self.aux_dev[l.name] = sb
                 scale_ptr = sb.ptr
+            if halves:
+                if xb.esize != 2 or yb.esize != 2 or xb.coffset:
+                    raise NotImplementedError("f16 engine: LRN %s" % l.name)
+                out.append(Op("lrn", l.name, lambda st: L.check(lib.fcn_lrn_fwd_f16(
+                    xb.ptr, yb.ptr, xb.pixels, xb.channels, xb.cstride, yb.cstride, ls, al, be, kk, st)), 0.0, 4.0 * xb.pixels * xb.channels))
+                return out
             out.append(Op("lrn", l.name, lambda st: L.check(lib.fcn_lrn_fwd_f32(
                 xb.ptr, yb.ptr, scale_ptr, xb.pixels, xb.channels, xb.cstride, yb.cstride, ls, al, be, kk, st)),
                 0.0, 8.0 * xb.pixels * xb.channels))
@@ -724,7 +780,10 @@ class Engine:
         n, c, h, w = b.shape
         st = self._stage(name)
         L.check(lib.fcn_memcpy_h2d_async(st.ptr, host.ctypes.data, host.nbytes, stream))
-        L.check(lib.fcn_nchw_to_nhwc_f32(st.ptr, b.buf.ptr, n, c, h, w, b.cstride, b.coffset, b.upload_shift, stream))
+        if b.esize == 2:
+            L.check(lib.fcn_nchw_f32_to_nhwc_f16(st.ptr, b.buf.ptr, n, c, h, w, b.cstride, b.coffset, b.upload_shift, stream))
+        else:
+            L.check(lib.fcn_nchw_to_nhwc_f32(st.ptr, b.buf.ptr, n, c, h, w, b.cstride, b.coffset, b.upload_shift, stream))
 
     def _enqueue_download(self, name: str, stream: Optional[int]) -> None:
         b = self.blobs[name]
@@ -735,7 +794,10 @@ class Engine:
             return
         n, c, h, w = b.shape
         st = self._stage(name)
-        L.check(lib.fcn_nhwc_to_nchw_f32(b.buf.ptr, st.ptr, n, c, h, w, b.cstride, b.coffset, stream))
+        if b.esize == 2:
+            L.check(lib.fcn_nhwc_f16_to_nchw_f32(b.buf.ptr, st.ptr, n, c, h, w, b.cstride, b.coffset, stream))
+        else:
+            L.check(lib.fcn_nhwc_to_nchw_f32(b.buf.ptr, st.ptr, n, c, h, w, b.cstride, b.coffset, stream))
         L.check(lib.fcn_memcpy_d2h_async(host.ctypes.data, st.ptr, host.nbytes, stream))
 
     def read_blob(self, name: str) -> np.ndarray:

@@ -67,7 +67,7 @@ class DetectParams(C.Structure):
     ]
 
 
-CONV_RELU, CONV_SIGMOID2, CONV_ACCUM, CONV_OUT_F32, CONV_F16 = 1, 2, 4, 8, 16
+CONV_RELU, CONV_SIGMOID2, CONV_ACCUM, CONV_OUT_F32, CONV_F16, CONV_OUT_F16 = 1, 2, 4, 8, 16, 32
 ELT_PROD, ELT_SUM, ELT_MAX = 0, 1, 2
 RECT_ROUND_NEAREST_EVEN, RECT_ROUND_TRUNCATE = 0, 1
 
@@ -126,6 +126,11 @@ PROTOTYPES = {
     "fcn_conv2d_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc), C.POINTER(_i)]),
     "fcn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "fcn_conv_weights_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_nchw_f32_to_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "fcn_nhwc_f16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_maxpool_fwd_f16": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
+    "fcn_lrn_fwd_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
+    "fcn_preprocess_bgr8_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp]),
     "fcn_compose_scene_bgr8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
     "fcn_mask_to_label_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "fcn_softmax_fwd_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

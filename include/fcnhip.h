@@ -92,6 +92,8 @@ int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int
 #define FCN_CONV_SIGMOID2  2   /* y2 = sigmoid(y) is written as well (y2 != NULL) */
 #define FCN_CONV_ACCUM     4   /* y += result (gradient fan-in when the kernel runs as a data-gradient pass) */
 #define FCN_CONV_OUT_F32   8   /* with FCN_CONV_F16: y is float32 (the detection heads feed the f32 decode kernel)   */
+#define FCN_CONV_OUT_F16  32   /* float32 x and w, y stored as half floats: the first layer of an f16 net keeps its input in
+                                * float32 (models/deploy.prototxt shifts a [0,1] image by -127: 16 half-float levels)   */
 #define FCN_CONV_F16      16   /* x, w and y hold IEEE half floats (v_mfma_f32_32x32x16_f16, f32 accumulate, f32 bias):
                                 * BASELINE configs[4].  Cin and x_cstride must then be multiples of 8; the pointers of
                                 * the descriptor are typed float* for both element types */
@@ -176,6 +178,19 @@ int  fcn_deconv_depthwise_fwd_f32(const float* x, const float* w, const float* b
  * d_minmax is a 32-byte device scratch (per-channel uint8 min and max, as int32). */
 int  fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride,
                          float shift, float* d_minmax, fcn_stream_t s);
+
+/* ---- half-float activation path (BASELINE configs[4]: batched inference with f16 storage, f32 accumulation).
+ *      Convolutions take FCN_CONV_F16 in fcn_conv_desc.flags; these are the layout converters and the other layers
+ *      of models/deploy.prototxt in that element type.  Channel counts / strides are multiples of 8 (16 bytes). ---- */
+int  fcn_nchw_f32_to_nhwc_f16(const float* src, void* dst, int N, int C, int H, int W, int dst_cstride, int dst_coffset, float shift,
+                              fcn_stream_t s);
+int  fcn_nhwc_f16_to_nchw_f32(const void* src, float* dst, int N, int C, int H, int W, int src_cstride, int src_coffset, fcn_stream_t s);
+int  fcn_maxpool_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad, int OH, int OW,
+                         int y_cstride, int y_coffset, fcn_stream_t s);
+int  fcn_lrn_fwd_f16(const void* x, void* y, int pixels, int C, int x_cstride, int y_cstride, int local_size, float alpha, float beta,
+                     float k, fcn_stream_t s);
+int  fcn_preprocess_bgr8_f16(const uint8_t* frame, int h, int w, void* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
+                             fcn_stream_t s);
 
 /* ---- training-scene synthesis on the device: the pixel work of ArgumentationEngineMapping.argument
  *      (scripts/data_argumentation_layer/argumentation_engine.py:651-746) and the whole-image flip of

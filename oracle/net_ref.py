@@ -194,6 +194,11 @@ class RefNet:
                 B[tops[0]] = np.array(self.losses[tops[0]], F32)
             else:
                 raise NotImplementedError("oracle: layer type %r (%s)" % (t, name))
+            hook = getattr(self, "round_activations", None)      # models reduced-precision storage of the activations
+            if hook is not None:
+                for tp in tops:
+                    if tp in B and getattr(B[tp], "ndim", 0) == 4:
+                        B[tp] = hook(tp, B[tp])
         return B
 
     # -- backward -----------------------------------------------------------

@@ -119,3 +119,70 @@ def test_f16_group_with_fused_pool_and_sigmoid_head(gpu):
     assert L.load().fcn_conv2d_group_prepare_fused(arr, 2, (L.PoolDesc * 1)(pdsc), 1, ws.ptr, 5, C.byref(grp)) == 1
     descs[1].flags = L.CONV_RELU
     assert L.load().fcn_conv2d_group_prepare_fused((L.ConvDesc * 2)(*descs), 2, None, 0, ws.ptr, 5, C.byref(grp)) != 0
+
+
+def _round16(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def test_f16_pointwise_kernels(gpu):
+    rng = np.random.default_rng(6)
+    x = _round16(rng.standard_normal((2, 24, 9, 7)) * 3)
+    xh = np.zeros((2, 9, 7, 24), np.float16)
+    xh[...] = x.transpose(0, 2, 3, 1)
+    xd = dev_from(xh)
+    for k, s, p in ((3, 2, 0), (3, 1, 1), (2, 2, 0)):
+        ref = R.max_pool(x, k, s, p)
+        oh, ow = ref.shape[2:]
+        yd = dev_from(np.full((2, oh, ow, 32), -3.0, np.float16))
+        L.call("fcn_maxpool_fwd_f16", xd.ptr, yd.ptr, 2, 9, 7, 24, 24, k, s, p, oh, ow, 32, 8, None)
+        y = dev_to(yd, (2, oh, ow, 32), np.float16)
+        assert np.array_equal(y[..., 8:].astype(np.float32).transpose(0, 3, 1, 2), ref)
+        assert np.all(y[..., :8] == np.float16(-3.0))
+    yd = dev_from(np.zeros((2, 9, 7, 24), np.float16))
+    L.call("fcn_lrn_fwd_f16", xd.ptr, yd.ptr, 2 * 9 * 7, 24, 24, 24, 5, 1e-4, 0.75, 1.0, None)
+    ref = R.lrn_across(x * 20, 5, 1e-4, 0.75, 1.0) / 20 if False else R.lrn_across(x, 5, 1e-4, 0.75, 1.0)
+    assert rel_err(dev_to(yd, (2, 9, 7, 24), np.float16).astype(np.float32).transpose(0, 3, 1, 2), ref) < 1e-3
+    # layout converters
+    src = rng.standard_normal((2, 5, 6, 7)).astype(np.float32)
+    sd, hd = dev_from(src), dev_from(np.zeros((2, 6, 7, 16), np.float16))
+    L.call("fcn_nchw_f32_to_nhwc_f16", sd.ptr, hd.ptr, 2, 5, 6, 7, 16, 8, 0.5, None)
+    h = dev_to(hd, (2, 6, 7, 16), np.float16)
+    assert np.array_equal(h[..., 8:13], (src + np.float32(0.5)).astype(np.float16).transpose(0, 2, 3, 1))
+    back = dev_from(np.zeros((2, 5, 6, 7), np.float32))
+    L.call("fcn_nhwc_f16_to_nchw_f32", hd.ptr, back.ptr, 2, 5, 6, 7, 16, 8, None)
+    assert np.array_equal(dev_to(back, (2, 5, 6, 7)), h[..., 8:13].astype(np.float32).transpose(0, 3, 1, 2))
+
+
+def test_f16_engine_forward_of_the_detectnet_deploy_net(gpu):
+    """Engine(dtype="f16") on models/deploy.prototxt's graph at reduced size against (a) the f32 oracle, at fp16 accuracy,
+    and (b) an oracle run that rounds weights and activations to halves at the same points, tightly."""
+    from fcn_object_detector_amd import models, proto
+    from fcn_object_detector_amd.engine import Engine
+    from fcn_object_detector_amd.netspec import NetSpec, fill_params
+    from oracle.net_ref import RefNet
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(2, 96, 128, 3))
+    spec = NetSpec(msg, "TEST")
+    spec.infer()
+    params = fill_params(spec, seed=21)
+    eng = Engine(NetSpec(msg, "TEST"), params={k: [a.copy() for a in v] for k, v in params.items()}, device=0, autotune=False, dtype="f16")
+    assert eng.blobs["data"].esize == 4 and eng.blobs["conv1/7x7_s2"].esize == 2 and eng.blobs["inception_3a/output"].esize == 2
+    assert eng.blobs["coverage"].esize == 4 and eng.blobs["bboxes"].esize == 4 and eng.blobs["cvg/classifier"].esize == 4
+    x = np.random.default_rng(1).random((2, 3, 96, 128), dtype=np.float32)
+    eng.host_array("data")[...] = x
+    out = eng.forward()
+    ref = RefNet(msg, "TEST", params)
+    ref.blobs["data"] = x
+    rb = ref.forward()
+    for name in ("coverage", "bboxes"):
+        assert rel_err(out[name], rb[name]) < 2e-2, name                      # fp16 storage of 60+ layers vs pure f32
+    # (b) same rounding points: weights of every layer but conv1 are halves, every internal activation is rounded to half
+    p16 = {k: [(_round16(v[0]) if k != "conv1/7x7_s2" else v[0])] + [a.copy() for a in v[1:]] for k, v in params.items()}
+    ref16 = RefNet(msg, "TEST", p16)
+    ref16.blobs["data"] = x
+    ref16.round_activations = lambda name, a: a if name in ("data", "transformed_data", "coverage", "bboxes", "cvg/classifier") else _round16(a)
+    rb16 = ref16.forward()
+    for name in ("coverage", "bboxes"):
+        assert rel_err(out[name], rb16[name]) < 3e-3, name
+    assert rel_err(eng.read_blob("inception_4a/output"), rb16["inception_4a/output"]) < 3e-3
+    eng.close()

@@ -38,6 +38,8 @@ SHAPES = [
 
 
 CFGS = [int(c) for c in os.environ.get("SWEEP_CFGS", "").split(",") if c]
+F16 = bool(os.environ.get("SWEEP_F16"))          # half-float activations / weights (v_mfma_f32_32x32x16_f16)
+BATCH = int(os.environ.get("SWEEP_BATCH", "1"))
 
 
 def main():
@@ -57,13 +59,17 @@ def main():
         keep, descs, flops = [], [], 0.0
         for (cin, cout, k, pad, s, h, w) in probs:
             oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
-            x = dev_from(rng.standard_normal((1, h, w, cin)).astype(np.float32))
-            wt = dev_from(rng.standard_normal((cout, k, k, cin)).astype(np.float32) * 0.05)
+            dt = np.float16 if F16 else np.float32
+            if F16:
+                cin = (cin + 7) // 8 * 8
+            co = (cout + 7) // 8 * 8 if F16 else cout
+            x = dev_from(rng.standard_normal((BATCH, h, w, cin)).astype(dt))
+            wt = dev_from((rng.standard_normal((cout, k, k, cin)) * 0.05).astype(dt))
             b = dev_from(np.zeros(cout, np.float32))
-            y = dev_from(np.zeros((1, oh, ow, cout), np.float32))
+            y = dev_from(np.zeros((BATCH, oh, ow, co), dt))
             keep += [x, wt, b, y]
-            descs.append(conv_desc(x, wt, b, y, 1, h, w, cin, cin, cout, k, pad, s, oh, ow, cout, 0, L.CONV_RELU | int(os.environ.get('FCN_DBG', '0'), 0)))
-            flops += 2.0 * oh * ow * cout * cin * k * k
+            descs.append(conv_desc(x, wt, b, y, BATCH, h, w, cin, cin, cout, k, pad, s, oh, ow, co, 0, L.CONV_RELU | (L.CONV_F16 if F16 else 0)))
+            flops += 2.0 * BATCH * oh * ow * cout * cin * k * k
         arr = (L.ConvDesc * len(descs))(*descs)
         ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(descs))), zero=False)
         line = "%-10s %6.3f GFLOP |" % (name, flops / 1e9)
