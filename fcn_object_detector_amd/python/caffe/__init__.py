@@ -128,6 +128,8 @@ class Net(object):
     def __init__(self, network_file, *args, **kwargs):
         weights = kwargs.pop("weights", None)
         phase = kwargs.pop("phase", None)
+        # extension (not in pycaffe): dtype="f16" / $FCN_DTYPE=f16 runs a TEST net with half-float activations and weights
+        self._dtype = str(kwargs.pop("dtype", os.environ.get("FCN_DTYPE", "f32")))
         for a in args:
             if isinstance(a, (int, np.integer)) and not isinstance(a, bool):
                 phase = int(a)
@@ -170,7 +172,8 @@ class Net(object):
             spec.infer({**spec.input_shapes, **shapes})
             params = _fill_params(spec, seed=0)
         self._spec = spec
-        self._engine = _Engine(spec, data_shapes=shapes, params=params, device=self._device)
+        self._engine = _Engine(spec, data_shapes=shapes, params=params, device=self._device,
+                               dtype=self._dtype if self._phase == "TEST" else "f32")
         self.blobs = OrderedDict((name, _Blob(self, name)) for name in self._engine.shapes)
         self.params = OrderedDict(
             (l.name, [_Param(self, l.name, i) for i in range(len(self._engine.params_host[l.name]))])
