@@ -200,10 +200,11 @@ def bench_infer32(local: int, dtype: str, reps: int = 10):
     L.call("fcn_memcpy_h2d_async", dev.ptr, frames.ctypes.data, frames.nbytes, eng.stream)
     data = eng.blobs["data"]
 
+    mm = DeviceBuffer(32 * n)
+
     def once():
-        for i in range(n):
-            L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", dev.ptr + i * 448 * 448 * 3, 448, 448,
-                   data.ptr + data.esize * i * 448 * 448 * data.cstride, 448, 448, data.cstride, data.upload_shift, det._minmax.ptr, eng.stream)
+        L.call("fcn_preprocess_bgr8_batch", dev.ptr, n, 448, 448, data.ptr, 1 if data.esize == 2 else 0, 448, 448, data.cstride,
+               data.upload_shift, mm.ptr, eng.stream)
         eng.forward_resident(1)
         det.decoder.launch(*det._cvg_args, *det._box_args, eng.stream)
         return det.decoder.fetch(eng.stream)

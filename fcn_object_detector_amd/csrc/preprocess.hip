@@ -18,14 +18,18 @@ namespace {
 
 __constant__ double kMeanBGR[3] = {104.0069879317889, 116.66876761696767, 122.6789143406786};
 
+// blockIdx.y = frame of a batch of equally sized frames (frame_stride bytes apart, 8 ints of min/max scratch each)
 __global__ void minmax_init_kernel(int* mm) {
+    mm += 8 * blockIdx.y;
     if (threadIdx.x < 3) {
         mm[threadIdx.x] = 255;
         mm[3 + threadIdx.x] = 0;
     }
 }
 
-__global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__ frame, long long npix, int* mm) {
+__global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__ frame, long long npix, int* mm, long long frame_stride) {
+    frame += (size_t)blockIdx.y * frame_stride;
+    mm += 8 * blockIdx.y;
     int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
 #pragma unroll
@@ -59,7 +63,11 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__
 
 template <typename D>
 __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restrict__ frame, int h, int w, D* __restrict__ dst, int H,
-                                                          int W, int cstride, float shift, const int* __restrict__ mm) {
+                                                          int W, int cstride, float shift, const int* __restrict__ mm, long long frame_stride,
+                                                          long long dst_stride) {
+    frame += (size_t)blockIdx.y * frame_stride;
+    dst += (size_t)blockIdx.y * dst_stride;
+    mm += 8 * blockIdx.y;
     double gmin = 1e300, gmax = -1e300;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -102,33 +110,42 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
 
 extern "C" {
 
-static int preprocess_any(const uint8_t* frame, int h, int w, void* dst, bool f16, int H, int W, int dst_cstride, float shift, float* d_minmax,
-                          fcn_stream_t s) {
-    FCN_REQUIRE(frame && dst && d_minmax && h > 0 && w > 0 && H > 0 && W > 0 && dst_cstride >= 3, FCN_E_ARG, "preprocess: bad args");
+static int preprocess_any(const uint8_t* frame, int n, int h, int w, void* dst, bool f16, int H, int W, int dst_cstride, float shift,
+                          float* d_minmax, fcn_stream_t s) {
+    FCN_REQUIRE(frame && dst && d_minmax && n > 0 && n <= 65535 && h > 0 && w > 0 && H > 0 && W > 0 && dst_cstride >= 3, FCN_E_ARG,
+                "preprocess: bad args");
     hipStream_t st = as_stream(s);
     int* mm = reinterpret_cast<int*>(d_minmax);
-    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(64), 0, st, mm);
+    const long long fstride = (long long)h * w * 3, dstride = (long long)H * W * dst_cstride;
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1, n), dim3(64), 0, st, mm);
     int mm_blocks = stream_grid((long long)h * w, 256 * 16);      // >= 16 pixels per lane: a few hundred workgroups at most
     if (mm_blocks > 256) mm_blocks = 256;
-    hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks), dim3(256), 0, st, frame, (long long)h * w, mm);
+    hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks, n), dim3(256), 0, st, frame, (long long)h * w, mm, fstride);
+    int rn_blocks = stream_grid((long long)H * W, 256);
+    if (rn_blocks > 8192) rn_blocks = 8192;
     if (f16)
-        hipLaunchKernelGGL(resize_norm_kernel<_Float16>, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, st, frame, h, w,
-                           reinterpret_cast<_Float16*>(dst), H, W, dst_cstride, shift, mm);
+        hipLaunchKernelGGL(resize_norm_kernel<_Float16>, dim3(rn_blocks, n), dim3(256), 0, st, frame, h, w, reinterpret_cast<_Float16*>(dst), H, W,
+                           dst_cstride, shift, mm, fstride, dstride);
     else
-        hipLaunchKernelGGL(resize_norm_kernel<float>, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, st, frame, h, w,
-                           reinterpret_cast<float*>(dst), H, W, dst_cstride, shift, mm);
+        hipLaunchKernelGGL(resize_norm_kernel<float>, dim3(rn_blocks, n), dim3(256), 0, st, frame, h, w, reinterpret_cast<float*>(dst), H, W,
+                           dst_cstride, shift, mm, fstride, dstride);
     FCN_LAUNCH_CHECK("preprocess_bgr8");
     return 0;
 }
 
 int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
                         fcn_stream_t s) {
-    return preprocess_any(frame, h, w, dst, false, H, W, dst_cstride, shift, d_minmax, s);
+    return preprocess_any(frame, 1, h, w, dst, false, H, W, dst_cstride, shift, d_minmax, s);
 }
 
 int fcn_preprocess_bgr8_f16(const uint8_t* frame, int h, int w, void* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
                             fcn_stream_t s) {
-    return preprocess_any(frame, h, w, dst, true, H, W, dst_cstride, shift, d_minmax, s);
+    return preprocess_any(frame, 1, h, w, dst, true, H, W, dst_cstride, shift, d_minmax, s);
+}
+
+int fcn_preprocess_bgr8_batch(const uint8_t* frames, int n, int h, int w, void* dst, int dst_f16, int H, int W, int dst_cstride, float shift,
+                              float* d_minmax, fcn_stream_t s) {
+    return preprocess_any(frames, n, h, w, dst, dst_f16 != 0, H, W, dst_cstride, shift, d_minmax, s);
 }
 
 }  // extern "C"

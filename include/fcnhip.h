@@ -189,6 +189,10 @@ int  fcn_maxpool_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int
                          int y_cstride, int y_coffset, fcn_stream_t s);
 int  fcn_lrn_fwd_f16(const void* x, void* y, int pixels, int C, int x_cstride, int y_cstride, int local_size, float alpha, float beta,
                      float k, fcn_stream_t s);
+/* n equally sized frames (h*w*3 bytes apart) -> the n images of an N x H x W x dst_cstride blob in three launches;
+ * each frame is normalised with its own min / max.  d_minmax: 32 bytes per frame. */
+int  fcn_preprocess_bgr8_batch(const uint8_t* frames, int n, int h, int w, void* dst, int dst_f16, int H, int W, int dst_cstride,
+                               float shift, float* d_minmax, fcn_stream_t s);
 int  fcn_preprocess_bgr8_f16(const uint8_t* frame, int h, int w, void* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
                              fcn_stream_t s);
 

@@ -169,4 +169,9 @@ def test_batched_node_pipeline_matches_oracle(gpu):
     assert total > 0
     with pytest.raises(ValueError):
         det.run_detector_batch(frames[:2])
+    # equally sized frames take the three-launch batched pre-processing: same blob as frame by frame
+    same = [rng.integers(0, 256, (240, 352, 3), dtype=np.uint8) for _ in range(batch)]
+    det.run_detector_batch(same)
+    for i, f in enumerate(same):
+        assert np.abs(eng.read_blob("data")[i] - D.preprocess_frame(f, 320, 224)).max() <= 4e-6
     eng.close()
