@@ -83,8 +83,46 @@ def targets():
     return d
 
 
+def train_batch():
+    """Inputs of the training fixture: a seeded batch for the DetectNet training net at 64x96 (shared with the tests)."""
+    rng = np.random.default_rng(31)
+    rects = [[(10, 8, 40, 30)], [(30, 20, 50, 36), (4, 4, 24, 28)]]
+    lab = [D.bounding_box_parameterized_labels(64, 96, r, [0] * len(r), 16, 1) for r in rects]
+    data = {"data": rng.random((2, 3, 64, 96), dtype=np.float32)}
+    for j, name in enumerate(("coverage-label", "bbox-label", "size-block", "obj-block", "coverage-block")):
+        data[name] = np.stack([o[j] for o in lab]).astype(np.float32)
+    return data
+
+
+def train():
+    """One solver iteration (SGD, momentum 0.9, lr 1e-3, weight decay 1e-6, dropout seed 11) of the DetectNet training net:
+    losses, a few blob / weight gradients and weights after the update."""
+    from oracle.net_ref import RefSolver
+    msg = proto.parse_text(models.googlenet_detectnet_train("m", "L", "unused", num_classes=1))
+    data = train_batch()
+    spec = NetSpec(msg, "TRAIN")
+    spec.infer({k: v.shape for k, v in data.items()})
+    params = fill_params(spec, seed=4321)
+    ref = RefNet(msg, "TRAIN", {k: [a.copy() for a in v] for k, v in params.items()})
+    ref.blobs.update(data)
+    ref.dropout_seed = 11
+    ref.forward()
+    grads = ref.backward()
+    smsg = proto.parse_text('base_lr: 0.001 momentum: 0.9 weight_decay: 1e-6 lr_policy: "fixed"')
+    RefSolver(ref, smsg, {l.name: l.lr_mult for l in spec.param_layers()}, {l.name: l.decay_mult for l in spec.param_layers()}).apply(grads)
+    out = dict(loss_bbox=np.array([ref.losses["loss_bbox"]]), loss_coverage=np.array([ref.losses["loss_coverage"]]),
+               total=np.array([ref.total_loss()]), coverage=ref.blobs["coverage"], bboxes=ref.blobs["bboxes"],
+               d_bboxes=ref.diffs["bboxes"], d_pool5=ref.diffs["pool5/drop_s1"])
+    for name in ("conv1/7x7_s2", "inception_4a/1x1", "bbox/regressor"):
+        key = name.replace("/", "__")
+        out["dw_" + key] = grads[name][0]
+        out["db_" + key] = grads[name][1]
+        out["w_after_" + key] = ref.params[name][0]
+    return out
+
+
 if __name__ == "__main__":
-    for name, fn in (("layers", layers), ("net_64x96", net), ("detect", detect), ("targets", targets)):
+    for name, fn in (("layers", layers), ("net_64x96", net), ("detect", detect), ("targets", targets), ("train_64x96", train)):
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **fn())
         print(name, os.path.getsize(path) // 1024, "KiB")

@@ -109,3 +109,62 @@ def test_hip_matches_net_detect_target_fixtures(gpu):
     out = generate_targets(rects, labels, 448, 448, 16, 3)
     for name, o in zip(("fg", "bbox", "size", "obj", "cvg"), out):
         assert np.array_equal(o, t[name])
+
+
+def _train_setup():
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mg)
+    msg = proto.parse_text(models.googlenet_detectnet_train("m", "L", "unused", num_classes=1))
+    data = mg.train_batch()
+    spec = NetSpec(msg, "TRAIN")
+    spec.infer({k: v.shape for k, v in data.items()})
+    return msg, spec, data, fill_params(spec, seed=4321)
+
+
+TRAIN_LAYERS = ("conv1/7x7_s2", "inception_4a/1x1", "bbox/regressor")
+
+
+def test_oracle_reproduces_training_fixture():
+    """One solver iteration of the DetectNet training net: losses, gradients, updated weights (tests/golden/train_64x96.npz)."""
+    from oracle.net_ref import RefSolver
+    g = load("train_64x96")
+    msg, spec, data, params = _train_setup()
+    ref = RefNet(msg, "TRAIN", {k: [a.copy() for a in v] for k, v in params.items()})
+    ref.blobs.update(data)
+    ref.dropout_seed = 11
+    ref.forward()
+    assert abs(ref.losses["loss_bbox"] - g["loss_bbox"][0]) < 1e-6 * abs(g["loss_bbox"][0])
+    assert abs(ref.total_loss() - g["total"][0]) < 1e-6 * abs(g["total"][0])
+    grads = ref.backward()
+    assert rel_err(ref.diffs["bboxes"], g["d_bboxes"]) < 1e-6 and rel_err(ref.diffs["pool5/drop_s1"], g["d_pool5"]) < 1e-5
+    smsg = proto.parse_text('base_lr: 0.001 momentum: 0.9 weight_decay: 1e-6 lr_policy: "fixed"')
+    RefSolver(ref, smsg, {l.name: l.lr_mult for l in spec.param_layers()}, {l.name: l.decay_mult for l in spec.param_layers()}).apply(grads)
+    for name in TRAIN_LAYERS:
+        key = name.replace("/", "__")
+        assert rel_err(grads[name][0], g["dw_" + key]) < 1e-5 and rel_err(grads[name][1], g["db_" + key]) < 1e-5
+        assert rel_err(ref.params[name][0], g["w_after_" + key]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_hip_matches_training_fixture(gpu):
+    from fcn_object_detector_amd.train import SolverParams, TrainEngine
+    g = load("train_64x96")
+    msg, spec, data, params = _train_setup()
+    eng = TrainEngine(NetSpec(msg, "TRAIN"), {k: v.shape for k, v in data.items()}, params={k: [a.copy() for a in v] for k, v in params.items()},
+                      device=0, solver=SolverParams(base_lr=1e-3, momentum=0.9, weight_decay=1e-6, lr_policy="fixed"), autotune=False)
+    for k, v in data.items():
+        eng.host_array(k)[...] = v
+    out = eng.step(seed=11)
+    assert abs(out["loss_bbox"] - g["loss_bbox"][0]) < 1e-3 * abs(g["loss_bbox"][0])
+    assert abs(out["loss_coverage"] - g["loss_coverage"][0]) < 1e-3 * abs(g["loss_coverage"][0])
+    assert abs(out["total_loss"] - g["total"][0]) < 1e-3 * abs(g["total"][0])
+    assert rel_err(eng.read_blob("coverage"), g["coverage"]) < 1e-3 and rel_err(eng.read_blob("bboxes"), g["bboxes"]) < 1e-3
+    assert rel_err(eng.read_grad("bboxes"), g["d_bboxes"]) < 1e-3
+    got, after = eng.download_grads(), eng.download_params()
+    for name in ("inception_4a/1x1", "bbox/regressor"):          # deep layers: no ReLU-mask / argmax flips between the two forwards
+        key = name.replace("/", "__")
+        assert rel_err(got[name][0], g["dw_" + key]) < 5e-3, name
+        assert rel_err(after[name][0], g["w_after_" + key]) < 1e-3, name
+    eng.close()
