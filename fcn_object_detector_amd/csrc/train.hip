@@ -40,14 +40,15 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 struct WgradP {
     const float* x;      // NHWC input of the layer
     const float* dy;     // NHWC gradient of the layer's output (view: dy_cstride, dy_coffset folded into the pointer)
-    float* dw_part;      // [splits][Cout][K] partial slabs
-    float* db_part;      // [splits][Cout] or nullptr
+    float* dw_part;      // partial slabs: split s holds [Cout][K] weights followed by [Cout] bias sums, slab_floats apart
+    float* db_part;      // dw_part + Cout*K (bias part of slab 0) or nullptr
     const float* zero_page;
     int N, H, W, Cin, x_cstride;
     int Cout, kh, kw, pad, stride, OH, OW;
     int dy_cstride;
     int M, K;
     int tiles_n, tiles_k, splits, chunks_per_split;   // chunk = 32 pixels
+    int slab_floats;                                   // Cout*K + Cout
     unsigned ow_magic, ohw_magic;                      // ceil(2^32 / OW), ceil(2^32 / (OH*OW)) for the pixel decode
     int kw_magic;
 };
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_kernel(Wgra
     wait_vmcnt<0>();
 
     // dW partial slab [split][cout][k]: C/D map col = lane & 31 (k), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
-    float* slab = p.dw_part + (size_t)split * p.Cout * p.K;
+    float* slab = p.dw_part + (size_t)split * p.slab_floats;
 #pragma unroll
     for (int j = 0; j < TK; ++j) {
         const int kcol = k0 + (wkk * TK + j) * 32 + (lane & 31);
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_kernel(Wgra
             }
         }
     }
-    if (do_bias && n0 + tid < p.Cout) p.db_part[(size_t)split * p.Cout + n0 + tid] = bsum;
+    if (do_bias && n0 + tid < p.Cout) p.db_part[(size_t)split * p.slab_floats + n0 + tid] = bsum;
 }
 
 // tile shapes: X(index, TN, TK, WAVES_N, WAVES_K)
@@ -274,7 +275,7 @@ constexpr WgShape kWgShapes[kNumWgCfg] = {{64, 64, 4, 0.55}, {64, 128, 4, 0.50},
 // dependent-latency loads on a handful of workgroups (100+ us for the small layers); this tree keeps the loads in flight.
 constexpr int RED_LANES = 16;
 __global__ __launch_bounds__(64 * RED_LANES) void reduce_partials_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t count,
-                                                                         int splits) {
+                                                                         int splits, size_t stride) {
     __shared__ float part[RED_LANES][64];
     const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
     for (size_t base = (size_t)blockIdx.x * 64; base < count; base += (size_t)gridDim.x * 64) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(64 * RED_LANES) void reduce_partials_kernel(const f
         float s = 0.f;
         if (i < count) {
 #pragma unroll 4
-            for (int k = sl; k < splits; k += RED_LANES) s += parts[(size_t)k * count + i];
+            for (int k = sl; k < splits; k += RED_LANES) s += parts[(size_t)k * stride + i];
         }
         part[sl][o] = s;
         __syncthreads();
@@ -739,7 +740,8 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     p.ohw_magic = magic32((unsigned)(p.OH * p.OW));
     p.kw_magic = (65536 + p.kw - 1) / p.kw;
     p.dw_part = d_workspace;
-    p.db_part = db ? d_workspace + (size_t)splits * p.Cout * p.K : nullptr;
+    p.slab_floats = p.Cout * p.K + p.Cout;
+    p.db_part = db ? d_workspace + (size_t)p.Cout * p.K : nullptr;
     hipStream_t st = as_stream(s);
     switch (cfg) {
 #define X(I, A, B, C_, D, E)                                                                                                              \
@@ -750,9 +752,14 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
 #undef X
     }
     const size_t cnt = (size_t)p.Cout * p.K;
-    const int red_blocks = (int)((cnt + 63) / 64 < 4096 ? (cnt + 63) / 64 : 4096);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(red_blocks), dim3(64 * RED_LANES), 0, st, p.dw_part, dw, cnt, splits);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.Cout, 64)), dim3(64 * RED_LANES), 0, st, p.db_part, db, (size_t)p.Cout, splits);
+    const size_t stride = (size_t)p.slab_floats;
+    // the solver keeps a layer's bias gradient right behind its weight gradient: one reduction then covers both
+    const bool together = db && db == dw + cnt;
+    const size_t cnt1 = together ? cnt + p.Cout : cnt;
+    const int red_blocks = (int)((cnt1 + 63) / 64 < 4096 ? (cnt1 + 63) / 64 : 4096);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(red_blocks), dim3(64 * RED_LANES), 0, st, p.dw_part, dw, cnt1, splits, stride);
+    if (db && !together)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.Cout, 64)), dim3(64 * RED_LANES), 0, st, p.db_part, db, (size_t)p.Cout, splits, stride);
     FCN_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }

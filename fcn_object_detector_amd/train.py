@@ -163,6 +163,19 @@ class TrainEngine(Engine):
 
         ws_floats = 1
         ops: List[Op] = []
+        # Concat outputs all of whose members are convolutions with a fused in-place ReLU: their ReLU backward is one launch
+        concat_members: Dict[str, List[str]] = {}
+        for child, (parent, _off) in self.alias.items():
+            if any(q.type == "Concat" and parent in q.tops for q in self.producers.get(parent, [])):
+                concat_members.setdefault(parent, []).append(child)
+        concat_relu: Dict[str, str] = {}
+        for parent, members in concat_members.items():
+            prods = [[q for q in self.producers.get(m, []) if q.type == "Convolution"] for m in members]
+            if all(len(pr) == 1 and self._conv_layer_meta.get(pr[0].name, {}).get("relu") for pr in prods) and \
+                    sum(B[m].channels for m in members) == B[parent].channels and B[parent].coffset == 0:
+                for m in members:
+                    concat_relu[m] = parent
+        relu_done: set = set()
         # Flipped / transposed filter banks of the data-gradient passes: slices of ONE flat buffer that a single launch
         # refreshes from the current weights at the start of every backward pass (58 launches otherwise).
         flip_layout: Dict[str, int] = {}
@@ -226,9 +239,18 @@ class TrainEngine(Engine):
                 k, s, pad = kernel_stride_pad(p)
                 n, cin, h, w = xb.shape
                 _, cout, oh, ow = yb.shape
-                if meta.get("relu"):
-                    ops.append(Op("relu_bwd", l.name, lambda st, g=gtop, y=yb: L.check(lib.fcn_relu_bwd_f32(
-                        g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yb.pixels * cout))
+                if meta.get("relu") and l.tops[0] not in relu_done:
+                    whole = concat_relu.get(l.tops[0])
+                    if whole is not None and whole in G and state(G[whole]) == "full":
+                        # every member of this Concat is a convolution with an in-place ReLU and the gradient of the whole
+                        # concatenation is final: ONE contiguous launch masks all members (an inception module: 4 -> 1)
+                        gw, yw = G[whole], B[whole]
+                        ops.append(Op("relu_bwd", whole, lambda st, g=gw, y=yw: L.check(lib.fcn_relu_bwd_f32(
+                            g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yw.pixels * yw.channels))
+                        relu_done.update(concat_members[whole])
+                    else:
+                        ops.append(Op("relu_bwd", l.name, lambda st, g=gtop, y=yb: L.check(lib.fcn_relu_bwd_f32(
+                            g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yb.pixels * cout))
                 d = L.ConvDesc()
                 d.x, d.y = xb.ptr, gtop.buf.ptr
                 d.N, d.H, d.W, d.Cin, d.x_cstride = n, h, w, _r4(cin), xb.cstride
