@@ -176,6 +176,7 @@ class TrainEngine(Engine):
                 for m in members:
                     concat_relu[m] = parent
         relu_done: set = set()
+        dgrad_done: set = set()
         # Flipped / transposed filter banks of the data-gradient passes: slices of ONE flat buffer that a single launch
         # refreshes from the current weights at the start of every backward pass (58 launches otherwise).
         flip_layout: Dict[str, int] = {}
@@ -201,6 +202,38 @@ class TrainEngine(Engine):
             ops.append(Op("flip", "%d filter banks" % len(flip_segs), lambda st, n=len(flip_segs): L.check(lib.fcn_conv_weights_flip_batch_f32(
                 self.param_flat.ptr, self._flip_flat.ptr, self._flip_segs_dev.ptr, n, st))))
         skip_sigmoid_of = {m["sigmoid_top"]: name for name, m in self._conv_layer_meta.items() if m.get("sigmoid_top")}
+
+        def dgrad_desc(l: Layer, gtop: Blob, gbot: Blob, accumulate: bool) -> Tuple[L.ConvDesc, float]:
+            """Data gradient of convolution l = the forward kernel on dY with the flipped / transposed bank."""
+            xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+            k, s, pad = kernel_stride_pad(l.sub("convolution_param"))
+            n, cin, h, w = xb.shape
+            _, cout, oh, ow = yb.shape
+            if s != 1:
+                raise NotImplementedError("data gradient of the strided convolution %s" % l.name)
+            cin_dg = _r4(cout)      # the flipped bank reads Cout4 input channels: the gradient view must expose them contiguously
+            if gtop.cstride - gtop.coffset < cin_dg:
+                raise NotImplementedError("gradient view of %s too narrow for the data-gradient pass" % l.tops[0])
+            wt = DevView(self._flip_flat.ptr + 4 * flip_layout[l.name], cin * k * k * cin_dg * 4)
+            dd = L.ConvDesc()
+            dd.x, dd.w, dd.bias, dd.y = gtop.ptr, wt.ptr, None, gbot.buf.ptr
+            dd.N, dd.H, dd.W, dd.Cin, dd.x_cstride = n, oh, ow, cin_dg, gtop.cstride
+            dd.Cout, dd.kh, dd.kw, dd.pad, dd.stride, dd.OH, dd.OW = cin, k, k, k - 1 - pad, 1, h, w
+            dd.y_cstride, dd.y_coffset = gbot.cstride, gbot.coffset
+            dd.flags = L.CONV_ACCUM if accumulate else 0
+            self._keep.append(dd)
+            return dd, 2.0 * n * cout * oh * ow * cin * k * k
+
+        def emit_dgrads(name: str, items: List[Tuple[L.ConvDesc, float]]) -> None:
+            """One grouped launch (autotuned) for data-gradient passes that write different buffers."""
+            arr = (L.ConvDesc * len(items))(*[it[0] for it in items])
+            gws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(items))), zero=False)
+            grp = L.ConvGroup()
+            cfg = self._tuned_cfg("dgrad:" + name, arr, len(items), gws) if self.autotune else -1
+            L.call("fcn_conv2d_group_prepare", arr, len(items), gws.ptr, cfg, C.byref(grp))
+            self._keep.extend([arr, gws, grp])
+            ops.append(Op("dgrad", "%s [cfg%d %dwg]" % (name, grp.cfg, grp.total_tiles),
+                          lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), sum(it[1] for it in items)))
 
         for l in reversed(spec.layers):
             t = l.type
@@ -248,6 +281,23 @@ class TrainEngine(Engine):
                         ops.append(Op("relu_bwd", whole, lambda st, g=gw, y=yw: L.check(lib.fcn_relu_bwd_f32(
                             g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yw.pixels * yw.channels))
                         relu_done.update(concat_members[whole])
+                        # the members' data gradients only need this masked gradient and write four different buffers (the
+                        # module input and the outputs of the reduce / pool layers): one grouped launch at the top of the
+                        # module's backward instead of four scattered ones
+                        items, names, targets = [], [], []
+                        for m in concat_members[whole]:
+                            lm = [q for q in self.producers.get(m, []) if q.type == "Convolution"][0]
+                            gb = G.get(lm.bottoms[0])
+                            if gb is None or lm.name not in flip_layout or state(gb) != "none" or any(gb.buf.ptr == tb for tb in targets):
+                                continue
+                            items.append(dgrad_desc(lm, G[m], gb, False))
+                            names.append(lm.name)
+                            targets.append(gb.buf.ptr)
+                        if len(items) > 1:
+                            emit_dgrads("+".join(names), items)
+                            for nm in names:
+                                dgrad_done.add(nm)
+                                mark(G[[q for q in spec.layers if q.name == nm][0].bottoms[0]])
                     else:
                         ops.append(Op("relu_bwd", l.name, lambda st, g=gtop, y=yb: L.check(lib.fcn_relu_bwd_f32(
                             g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yb.pixels * cout))
@@ -267,31 +317,8 @@ class TrainEngine(Engine):
                     ops.append(Op("wgrad", l.name, lambda st, d=d, dw=dw, db=db: L.check(lib.fcn_conv2d_wgrad_f32(
                         C.byref(d), dw.ptr, db.ptr if db else None, self._ws.ptr, st)), flops))
                 gbot = G.get(l.bottoms[0])
-                if gbot is not None:
-                    if s != 1:
-                        raise NotImplementedError("data gradient of the strided convolution %s" % l.name)
-                    co4 = gtop.cstride if gtop.coffset == 0 and gtop.cstride == _r4(cout) else None
-                    # the flipped bank reads Cout4 input channels: the gradient view must expose them contiguously
-                    cin_dg = _r4(cout)
-                    if gtop.cstride - gtop.coffset < cin_dg:
-                        raise NotImplementedError("gradient view of %s too narrow for the data-gradient pass" % l.tops[0])
-                    wt = DevView(self._flip_flat.ptr + 4 * flip_layout[l.name], cin * k * k * cin_dg * 4)
-                    dd = L.ConvDesc()
-                    dd.x, dd.w, dd.bias, dd.y = gtop.ptr, wt.ptr, None, gbot.buf.ptr
-                    dd.N, dd.H, dd.W, dd.Cin, dd.x_cstride = n, oh, ow, cin_dg, gtop.cstride
-                    dd.Cout, dd.kh, dd.kw, dd.pad, dd.stride, dd.OH, dd.OW = cin, k, k, k - 1 - pad, 1, h, w
-                    dd.y_cstride, dd.y_coffset = gbot.cstride, gbot.coffset
-                    dd.flags = L.CONV_ACCUM if state(gbot) == "full" else 0
-                    self._keep.append(dd)
-                    # the forward kernel on the flipped bank, as a one-problem group so that its tile shape is autotuned too
-                    arr = (L.ConvDesc * 1)(dd)
-                    gws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(1)), zero=False)
-                    grp = L.ConvGroup()
-                    cfg = self._tuned_cfg("dgrad:" + l.name, arr, 1, gws) if self.autotune else -1
-                    L.call("fcn_conv2d_group_prepare", arr, 1, gws.ptr, cfg, C.byref(grp))
-                    self._keep.extend([arr, gws, grp])
-                    ops.append(Op("dgrad", "%s [cfg%d %dwg]" % (l.name, grp.cfg, grp.total_tiles),
-                                  lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops))
+                if gbot is not None and l.name not in dgrad_done:
+                    emit_dgrads(l.name, [dgrad_desc(l, gtop, gbot, state(gbot) == "full")])
                     mark(gbot)
                 continue
             if t == "Eltwise" and str(l.sub("eltwise_param").get("operation", "SUM")) == "SUM":
