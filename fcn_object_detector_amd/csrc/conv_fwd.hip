@@ -659,7 +659,7 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
 }
 
 // Heuristic used when the caller does not autotune (cfg_request = -1).  Fitted to tools/conv_sweep.py on
-// MI355X: a CU's vector-memory path sustains ~12 B/clk into LDS whatever the source, so a workgroup's chunk
+// MI355X: loads that miss a CU's L1 stream at ~12-16 B/clk into LDS whatever the ring depth, so a workgroup's chunk
 // costs about max(MFMA cycles, staged bytes / 12) plus a barrier; workgroups run in rounds over 256 CUs.
 int choose_cfg(const ConvP* ps, int n) {
     const char* force = getenv("FCN_CONV_CFG");
