@@ -8,9 +8,9 @@
 // in HBM (288 GB: a dataset is uploaded once), a sample costs one 64-byte record per object and one launch.
 //
 // One lane per output pixel, gather form: background first, then the objects in paste order (later objects overwrite
-// earlier ones, as in the reference).  Bilinear resampling reproduces the host renderer's float32 arithmetic bit for
-// bit (fcn_object_detector_amd/data_layer.py::resize_bilinear: half-pixel centres computed in double, weights in
-// float32, round-half-even to uint8), so the device path is checked bit-exactly against the host path.
+// earlier ones, as in the reference).  Bilinear resampling reproduces the oracle renderer's float32 arithmetic bit for
+// bit (oracle/scene_ref.py::resize_bilinear: half-pixel centres computed in double, weights in
+// float32, round-half-even to uint8), so the kernel is checked bit-exactly against the oracle renderer.
 #include "common.h"
 
 using namespace fcn;
@@ -19,7 +19,7 @@ namespace {
 
 struct Tap { int i0, i1; float f; };
 
-// data_layer.py::resize_bilinear coords(): source taps of destination index d for n_in -> n_out
+// oracle/scene_ref.py::resize_bilinear coords(): source taps of destination index d for n_in -> n_out
 __device__ __forceinline__ Tap tap(int d, int n_in, int n_out) {
     Tap t;
     if (n_in == n_out) {

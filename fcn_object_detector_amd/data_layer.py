@@ -66,59 +66,6 @@ def flip_rects(im_hw: Sequence[int], rects: Sequence[Sequence[int]], flip_flag: 
     return out
 
 
-def flip_image(img: np.ndarray, flip_flag: int) -> np.ndarray:
-    """cv.flip: 0 = around the x axis (vertical), 1 = around the y axis (horizontal), -1 = both."""
-    if flip_flag == 0:
-        return img[::-1].copy()
-    if flip_flag == 1:
-        return img[:, ::-1].copy()
-    return img[::-1, ::-1].copy()
-
-
-def demean_rgb_image(im: np.ndarray) -> np.ndarray:
-    """argumentation_engine.py:297-303: float32, subtract the BGR mean, min-max normalise the whole image to [0, 1]."""
-    im = im.astype(np.float32)
-    for c in range(3):
-        im[:, :, c] -= np.float32(MEAN_BGR[c])
-    return (im - im.min()) / (im.max() - im.min())
-
-
-def resize_bilinear(img: np.ndarray, W: int, H: int) -> np.ndarray:
-    """cv.resize(img, (W, H)) with the default INTER_LINEAR (the reference's INTER_CUBIC lands in the dst slot, :120)."""
-    h, w = img.shape[:2]
-    if (h, w) == (H, W):
-        return img.copy()
-
-    def coords(n_out, n_in):
-        f = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / float(n_out)) - 0.5
-        f = f.astype(np.float32)
-        s = np.floor(f).astype(np.int64)
-        fr = (f - s.astype(np.float32)).astype(np.float32)
-        lo = s < 0
-        fr[lo], s[lo] = 0, 0
-        hi = s >= n_in - 1
-        fr[hi], s[hi] = 0, n_in - 1
-        return s, np.minimum(s + 1, n_in - 1), fr
-
-    x0, x1, fx = coords(W, w)
-    y0, y1, fy = coords(H, h)
-    src = img.astype(np.float32) if img.dtype != np.float64 else img
-    fx = fx[None, :, None] if img.ndim == 3 else fx[None, :]
-    fy = fy[:, None, None] if img.ndim == 3 else fy[:, None]
-    top = src[y0][:, x0] * (1 - fx) + src[y0][:, x1] * fx
-    bot = src[y1][:, x0] * (1 - fx) + src[y1][:, x1] * fx
-    out = top * (1 - fy) + bot * fy
-    return np.rint(out).clip(0, 255).astype(np.uint8) if img.dtype == np.uint8 else out.astype(img.dtype)
-
-
-def resize_nearest(img: np.ndarray, W: int, H: int) -> np.ndarray:
-    """cv.resize(..., interpolation=INTER_NEAREST): src index = floor(dst * scale)."""
-    h, w = img.shape[:2]
-    ys = np.minimum((np.arange(H) * (h / float(H))).astype(np.int64), h - 1)
-    xs = np.minimum((np.arange(W) * (w / float(W))).astype(np.int64), w - 1)
-    return img[ys][:, xs].copy()
-
-
 # ----------------------------------------------------------------------------
 # dataset
 # ----------------------------------------------------------------------------
@@ -201,7 +148,7 @@ class DataArgumentationLayer(Layer):
     MAX_PLACEMENT_RETRIES = 100      # ArgumentationEngineMapping.__max_counter
     PLACEMENT_IOU = 0.05             # ArgumentationEngineMapping.__iou_thresh
     supports_device_targets = True   # forward() can stop at the boxes; the solver then builds the label grids in HBM
-    supports_device_scenes = True    # bind_device(): scenes are composed and normalised on the device
+    supports_device_scenes = True    # bind_device(): scenes are composed and normalised on the device (the only renderer)
 
     def setup(self, bottom, top):
         if len(bottom) > 0:
@@ -244,8 +191,8 @@ class DataArgumentationLayer(Layer):
             top[i].reshape(n, ch, gy, gx)
 
     # -- scene synthesis: ArgumentationEngineMapping.argument (argumentation_engine.py:651-746) -------------------------
-    # The random DECISIONS (plan_scene) are separate from the pixel work, which has two renderers that produce the
-    # same bytes: numpy on the host (render_host) and one kernel launch per sample on the device (DeviceRenderer).
+    # The random DECISIONS (plan_scene, host) are separate from the pixel work, which is one kernel launch per sample on
+    # the device (DeviceRenderer); oracle/scene_ref.py renders the same plan with numpy for the parity tests.
     SCENE_H, SCENE_W = 480, 640      # the reference composes at the background's 640x480 and resizes to the net input later
 
     def _source(self, idx: int):
@@ -335,38 +282,6 @@ class DataArgumentationLayer(Layer):
         rects = resize_rects((im_y, im_x), (self.image_size_x, self.image_size_y), rects)
         return dict(bg_crop=(bx, by, ww, hh), objects=objs, final_flip=final_flip, rects=rects, labels=labels)
 
-    def render_host(self, plan: dict):
-        """The decided scene as (image uint8 480x640x3, class mask uint8 480x640), with numpy."""
-        bx, by, ww, hh = plan["bg_crop"]
-        img_out = resize_bilinear(self.background[by:by + hh, bx:bx + ww], self.SCENE_W, self.SCENE_H)
-        mask_out = np.zeros((self.SCENE_H, self.SCENE_W), np.uint8)
-        for o in plan["objects"]:
-            image, mask, _label, _rect = self._source(o["idx"])
-            if -2 < o["flip"] < 2:
-                image, mask = flip_image(image, o["flip"]), flip_image(mask, o["flip"])
-            x, y, w, h = o["roi"]
-            im_roi, im_msk = image[y:y + h, x:x + w], mask[y:y + h, x:x + w]
-            ow, oh = o["out"]
-            if (ow, oh) != (w, h):
-                im_roi, im_msk = resize_bilinear(im_roi, ow, oh), resize_bilinear(im_msk, ow, oh)
-            cx, cy = o["pos"]
-            x0, y0 = max(cx, 0), max(cy, 0)
-            x1, y1 = min(cx + ow, self.SCENE_W), min(cy + oh, self.SCENE_H)
-            sel = im_msk[y0 - cy:y1 - cy, x0 - cx:x1 - cx] > 0
-            img_out[y0:y1, x0:x1][sel] = im_roi[y0 - cy:y1 - cy, x0 - cx:x1 - cx][sel]
-            mask_out[y0:y1, x0:x1][sel] = o["label"] + 1
-        if -2 < plan["final_flip"] < 2:
-            img_out, mask_out = flip_image(img_out, plan["final_flip"]), flip_image(mask_out, plan["final_flip"])
-        return img_out, mask_out
-
-    def make_sample(self):
-        """One training sample on the host: (image float32 HxWx3 in [0,1], class mask HxW uint8, rects at net resolution, labels)."""
-        plan = self.plan_scene()
-        img, mask = self.render_host(plan)
-        img = resize_bilinear(demean_rgb_image(img), self.image_size_x, self.image_size_y)
-        mask = resize_nearest(mask, self.image_size_x, self.image_size_y)
-        return img, mask, plan["rects"], plan["labels"]
-
     def bind_device(self, engine, top_names: Sequence[str]) -> None:
         """Called by the solver: from now on forward() renders `data` (and the class mask of HEAD's mode) straight into the
         engine's input blobs on the device instead of into the host tops."""
@@ -377,18 +292,14 @@ class DataArgumentationLayer(Layer):
         from .detector import generate_targets
         all_rects, all_labels = [], []
         renderer = getattr(self, "_renderer", None)
+        if renderer is None:
+            raise RuntimeError("DataArgumentationLayer: no engine bound (bind_device): the scenes are composed on the MI355X, there is no "
+                               "host renderer in the product")
         for index in range(self.batch_size):
-            if renderer is not None:
-                plan = self.plan_scene()
-                renderer.render(index, plan)
-                rects, labels = plan["rects"], plan["labels"]
-            else:
-                img, mask, rects, labels = self.make_sample()
-                top[0].data[index] = img.transpose((2, 0, 1))
-                if self.mode != "detectnet":
-                    top[1].data[index, 0] = mask
-            all_rects.append(rects)
-            all_labels.append(labels)
+            plan = self.plan_scene()
+            renderer.render(index, plan)
+            all_rects.append(plan["rects"])
+            all_labels.append(plan["labels"])
         self.last_rects, self.last_labels = all_rects, all_labels
         if getattr(self, "device_targets", False):
             return              # the solver hands last_rects to TrainEngine.set_targets: labels are generated in HBM

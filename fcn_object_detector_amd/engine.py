@@ -182,6 +182,7 @@ class Engine:
         self._conv_layer_meta: Dict[str, dict] = {}
         self.aux_dev: Dict[str, DeviceBuffer] = {}      # TRAIN: pooling argmax / LRN scale kept for backward
         self.loss_blobs: Dict[str, float] = {}          # loss top -> loss_weight
+        self.device_fed: set = set()             # input blobs a producer writes straight into HBM (device scene renderer): never uploaded
         self.dropout_seed = 0
         self.dropout_index_offset = 0           # data-parallel rank r: r * (elements of the dropout blob)
         self.inputs = spec.data_tops()
@@ -834,7 +835,8 @@ class Engine:
         try:
             if with_io:
                 for nm in self.inputs:
-                    self._enqueue_upload(nm, self.stream)
+                    if nm not in self.device_fed:
+                        self._enqueue_upload(nm, self.stream)
             self.run_ops(self.stream)
             if with_io:
                 for nm in self.outputs:
@@ -859,7 +861,8 @@ class Engine:
                 L.call("fcn_graph_launch", self.graph_io, self.stream)
             else:
                 for nm in self.inputs:
-                    self._enqueue_upload(nm, self.stream)
+                    if nm not in self.device_fed:
+                        self._enqueue_upload(nm, self.stream)
                 self.run_ops(self.stream)
                 for nm in self.outputs:
                     self._enqueue_download(nm, self.stream)
@@ -874,7 +877,7 @@ class Engine:
                 b.host_valid = True
                 out[nm] = b.host
             for nm in self.inputs:
-                self.blobs[nm].host_valid = True
+                self.blobs[nm].host_valid = nm not in self.device_fed
             return out
 
     def upload_inputs(self) -> None:

@@ -181,6 +181,10 @@ class Net(object):
         self.inputs = list(spec.input_shapes.keys())
         self.outputs = list(self._engine.outputs)
         self._touched_inputs = set(self._engine.inputs)
+        for l, inst, bottoms, tops in self._py_layers:
+            # a layer that renders on the device (the bundled data layer) writes its image tops straight into HBM
+            if getattr(inst, "supports_device_scenes", False):
+                inst.bind_device(self._engine, [t.name for t in tops])
 
     def _shape(self, name: str):
         return self._engine.shapes[name]
@@ -242,7 +246,10 @@ class Net(object):
                 for t in tops:
                     if tuple(t.shape_) != tuple(eng.shapes[t.name]):
                         raise NotImplementedError("Python layer %s changed the shape of %s" % (l.name, t.name))
-                    eng.host_array(t.name)[...] = t.data
+                    if t.name in getattr(inst, "device_tops", ()):
+                        eng.device_fed.add(t.name)
+                    else:
+                        eng.host_array(t.name)[...] = t.data
             out = eng.forward()
             res = {k: out[k] for k in self.outputs}
             if blobs:

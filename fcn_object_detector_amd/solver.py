@@ -119,10 +119,9 @@ class Solver(object):
         self._losses: deque = deque(maxlen=max(self.param.average_loss, 1))
         self._fed = False
         self._device_label_tops = {}
-        self.engine.device_fed = set()
         for l, inst, bottoms, tops in self.py_layers:
             # a data layer that can render its scenes on the device writes `data` (and HEAD's class mask) straight into HBM
-            if getattr(inst, "supports_device_scenes", False) and os.environ.get("FCN_DEVICE_SCENES", "1") != "0":
+            if getattr(inst, "supports_device_scenes", False):
                 inst.bind_device(self.engine, [t.name for t in tops])
                 self.engine.device_fed |= set(inst.device_tops)
             # a data layer that can hand over ground-truth boxes gets its label grids generated in HBM (fcn_gen_targets_nhwc)

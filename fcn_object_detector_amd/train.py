@@ -517,7 +517,7 @@ class TrainEngine(Engine):
             L.call("fcn_init", self.device)
             self.dropout_seed = int(seed if seed is not None else self.iter) & 0xFFFFFFFF
             dev_targets = getattr(self, "_tgt", None) is not None and self._tgt.get("pending")
-            fed = set(getattr(self, "device_fed", ()))      # inputs some producer already wrote in HBM (device scene renderer)
+            fed = set(self.device_fed)      # inputs some producer already wrote in HBM (device scene renderer)
             if upload:
                 skip = (set(self._tgt["tops"]) if dev_targets else set()) | fed
                 for nm in self.inputs:

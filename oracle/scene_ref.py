@@ -1,0 +1,101 @@
+"""CPU restatement of the scene renderer of the reference's data layer - TEST INFRASTRUCTURE ONLY.
+
+The product composes training scenes on the device (fcn_object_detector_amd/csrc/scene.hip, DeviceRenderer in
+fcn_object_detector_amd/data_layer.py); this is the numpy renderer the parity tests hold it to, bit for bit.  It renders a
+scene PLAN (the random decisions of DataArgumentationLayer.plan_scene, which follow ArgumentationEngineMapping.argument,
+reference: scripts/data_argumentation_layer/argumentation_engine.py:651-746) plus the deterministic image helpers of
+ArgumentationEngine (:114-138 resize, :241-267 flip, :297-303 demean).  Parity unpinned: the reference has no fixtures for
+this path and its own renderer (Python 2 + OpenCV) cannot run here; cv.resize is restated as float32 bilinear
+interpolation with half-pixel centres and round-half-even (OpenCV's 8-bit path uses fixed-point coefficients).
+"""
+import numpy as np
+
+MEAN_BGR = (104.0069879317889, 116.66876761696767, 122.6789143406786)
+
+
+def flip_image(img: np.ndarray, flip_flag: int) -> np.ndarray:
+    """cv.flip: 0 = around the x axis (vertical), 1 = around the y axis (horizontal), -1 = both."""
+    if flip_flag == 0:
+        return img[::-1].copy()
+    if flip_flag == 1:
+        return img[:, ::-1].copy()
+    return img[::-1, ::-1].copy()
+
+
+def demean_rgb_image(im: np.ndarray) -> np.ndarray:
+    """argumentation_engine.py:297-303: float32, subtract the BGR mean, min-max normalise the whole image to [0, 1]."""
+    im = im.astype(np.float32)
+    for c in range(3):
+        im[:, :, c] -= np.float32(MEAN_BGR[c])
+    return (im - im.min()) / (im.max() - im.min())
+
+
+def resize_bilinear(img: np.ndarray, W: int, H: int) -> np.ndarray:
+    """cv.resize(img, (W, H)) with the default INTER_LINEAR (the reference's INTER_CUBIC lands in the dst slot, :120)."""
+    h, w = img.shape[:2]
+    if (h, w) == (H, W):
+        return img.copy()
+
+    def coords(n_out, n_in):
+        f = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / float(n_out)) - 0.5
+        f = f.astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        fr = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        fr[lo], s[lo] = 0, 0
+        hi = s >= n_in - 1
+        fr[hi], s[hi] = 0, n_in - 1
+        return s, np.minimum(s + 1, n_in - 1), fr
+
+    x0, x1, fx = coords(W, w)
+    y0, y1, fy = coords(H, h)
+    src = img.astype(np.float32) if img.dtype != np.float64 else img
+    fx = fx[None, :, None] if img.ndim == 3 else fx[None, :]
+    fy = fy[:, None, None] if img.ndim == 3 else fy[:, None]
+    top = src[y0][:, x0] * (1 - fx) + src[y0][:, x1] * fx
+    bot = src[y1][:, x0] * (1 - fx) + src[y1][:, x1] * fx
+    out = top * (1 - fy) + bot * fy
+    return np.rint(out).clip(0, 255).astype(np.uint8) if img.dtype == np.uint8 else out.astype(img.dtype)
+
+
+def resize_nearest(img: np.ndarray, W: int, H: int) -> np.ndarray:
+    """cv.resize(..., interpolation=INTER_NEAREST): src index = floor(dst * scale)."""
+    h, w = img.shape[:2]
+    ys = np.minimum((np.arange(H) * (h / float(H))).astype(np.int64), h - 1)
+    xs = np.minimum((np.arange(W) * (w / float(W))).astype(np.int64), w - 1)
+    return img[ys][:, xs].copy()
+
+
+
+def render_scene(layer, plan: dict):
+    """The decided scene as (image uint8 480x640x3, class mask uint8 480x640), with numpy."""
+    bx, by, ww, hh = plan["bg_crop"]
+    img_out = resize_bilinear(layer.background[by:by + hh, bx:bx + ww], layer.SCENE_W, layer.SCENE_H)
+    mask_out = np.zeros((layer.SCENE_H, layer.SCENE_W), np.uint8)
+    for o in plan["objects"]:
+        image, mask, _label, _rect = layer._source(o["idx"])
+        if -2 < o["flip"] < 2:
+            image, mask = flip_image(image, o["flip"]), flip_image(mask, o["flip"])
+        x, y, w, h = o["roi"]
+        im_roi, im_msk = image[y:y + h, x:x + w], mask[y:y + h, x:x + w]
+        ow, oh = o["out"]
+        if (ow, oh) != (w, h):
+            im_roi, im_msk = resize_bilinear(im_roi, ow, oh), resize_bilinear(im_msk, ow, oh)
+        cx, cy = o["pos"]
+        x0, y0 = max(cx, 0), max(cy, 0)
+        x1, y1 = min(cx + ow, layer.SCENE_W), min(cy + oh, layer.SCENE_H)
+        sel = im_msk[y0 - cy:y1 - cy, x0 - cx:x1 - cx] > 0
+        img_out[y0:y1, x0:x1][sel] = im_roi[y0 - cy:y1 - cy, x0 - cx:x1 - cx][sel]
+        mask_out[y0:y1, x0:x1][sel] = o["label"] + 1
+    if -2 < plan["final_flip"] < 2:
+        img_out, mask_out = flip_image(img_out, plan["final_flip"]), flip_image(mask_out, plan["final_flip"])
+    return img_out, mask_out
+
+def make_sample(layer):
+    """One training sample on the host: (image float32 HxWx3 in [0,1], class mask HxW uint8, rects at net resolution, labels)."""
+    plan = layer.plan_scene()
+    img, mask = render_scene(layer, plan)
+    img = resize_bilinear(demean_rgb_image(img), layer.image_size_x, layer.image_size_y)
+    mask = resize_nearest(mask, layer.image_size_x, layer.image_size_y)
+    return img, mask, plan["rects"], plan["labels"]
+

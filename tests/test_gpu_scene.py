@@ -10,6 +10,7 @@ from fcn_object_detector_amd import proto
 from fcn_object_detector_amd.engine import Engine
 from fcn_object_detector_amd.netspec import NetSpec
 from fcn_object_detector_amd.pylayer import TopProxy
+from oracle import scene_ref as S
 
 pytestmark = pytest.mark.gpu
 
@@ -43,7 +44,7 @@ def test_device_scene_equals_host_scene_bit_for_bit(gpu):
         plan = lay.plan_scene()
         lay._renderer.render(it % 3, plan)
         img_d, msk_d = lay._renderer.read_scene(it % 3)
-        img_h, msk_h = lay.render_host(plan)
+        img_h, msk_h = S.render_scene(lay, plan)
         assert np.array_equal(img_d, img_h), it
         assert np.array_equal(msk_d, msk_h), it
         seen_flip.add(plan["final_flip"])
@@ -59,8 +60,14 @@ def test_device_scene_equals_host_scene_bit_for_bit(gpu):
 @pytest.mark.parametrize("mode", ["mask", "detectnet"])
 def test_device_fed_tops_match_host_tops(gpu, mode):
     """`data` from compose + fcn_preprocess_bgr8 vs the host chain (demean f32, min-max, bilinear resize); the class mask of
-    HEAD's mode vs the nearest-neighbour resize; rects / labels identical (same plan)."""
+    HEAD's mode vs the nearest-neighbour resize; rects / labels identical (same plan).  The layer has no host renderer:
+    without a bound engine forward() fails loudly."""
     lay, eng, tops = make(mode)
+    unbound = D.DataArgumentationLayer()
+    unbound.param_str = lay.param_str
+    unbound.setup([], tops)
+    with pytest.raises(RuntimeError):
+        unbound.forward([], tops)
     random.seed(7)
     state = random.getstate()
     lay.forward([], tops)                       # device path: renders into the engine's blobs
@@ -68,13 +75,19 @@ def test_device_fed_tops_match_host_tops(gpu, mode):
     eng.blobs["data"].host_valid = False          # written in HBM by the renderer, not through the host array
     data_dev = eng.read_blob("data").copy()
     random.setstate(state)
-    renderer, lay._renderer = lay._renderer, None
-    lay.forward([], tops)                       # host path with the same draws
-    assert lay.last_rects == dev_rects and lay.last_labels == dev_labels
-    assert rel_err(data_dev, tops[0].data) < 1e-5
-    assert np.abs(data_dev - tops[0].data).max() < 2e-6
+    host = np.zeros((lay.batch_size, 3, lay.image_size_y, lay.image_size_x), np.float32)
+    host_mask = np.zeros((lay.batch_size, 1, lay.image_size_y, lay.image_size_x), np.float32)
+    host_rects, host_labels = [], []
+    for i in range(lay.batch_size):             # the oracle's renderer with the same draws
+        img, mask, rects, labels = S.make_sample(lay)
+        host[i] = img.transpose(2, 0, 1)
+        host_mask[i, 0] = mask
+        host_rects.append(rects)
+        host_labels.append(labels)
+    assert host_rects == dev_rects and host_labels == dev_labels
+    assert rel_err(data_dev, host) < 1e-5
+    assert np.abs(data_dev - host).max() < 2e-6
     if mode == "mask":
         eng.blobs["label"].host_valid = False
-        assert np.array_equal(eng.read_blob("label"), tops[1].data)
-    lay._renderer = renderer
+        assert np.array_equal(eng.read_blob("label"), host_mask)
     eng.close()

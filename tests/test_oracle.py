@@ -217,3 +217,25 @@ def test_preprocess_identity_resize():
     up = D.preprocess_frame(frame, 96, 64)
     ref = F.interpolate(t(im.transpose(2, 0, 1)[None]), size=(64, 96), mode="bilinear", align_corners=False)[0].numpy()
     assert np.allclose(up, ref, atol=1e-6)
+
+
+def test_scene_image_helpers():
+    from oracle import scene_ref as S
+    rng = np.random.default_rng(0)
+    im = rng.integers(0, 256, (7, 9, 3), dtype=np.uint8)
+    assert np.array_equal(S.flip_image(im, 0), im[::-1]) and np.array_equal(S.flip_image(im, 1), im[:, ::-1])
+    assert np.array_equal(S.flip_image(im, -1), im[::-1, ::-1])
+    d = S.demean_rgb_image(im)
+    assert d.dtype == np.float32 and d.min() == 0.0 and d.max() == 1.0
+    ref = im.astype(np.float32) - np.array(S.MEAN_BGR, np.float32)
+    assert np.allclose(d, (ref - ref.min()) / (ref.max() - ref.min()), atol=1e-6)
+    assert np.array_equal(S.resize_bilinear(im, 9, 7), im)
+    flat = np.full((10, 12, 3), 77, np.uint8)
+    assert np.all(S.resize_bilinear(flat, 30, 5) == 77)
+    # 2x upscale of a ramp: OpenCV half-pixel centres
+    ramp = np.array([[0.0, 10.0]], np.float32)
+    assert np.allclose(S.resize_bilinear(ramp, 4, 1), [[0.0, 2.5, 7.5, 10.0]])
+    m = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    assert np.array_equal(S.resize_nearest(m, 8, 6), m.repeat(2, 0).repeat(2, 1))
+
+
