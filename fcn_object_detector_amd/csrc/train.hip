@@ -74,18 +74,17 @@ struct WgCfg {
 };
 
 template <int TN, int TK, int WAVES_N, int WAVES_K, int NBUF>
-__global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_kernel(WgradP p) {
+__device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* smem) {
     constexpr int WG_NBUF = NBUF;
     using C = WgCfg<TN, TK, WAVES_N, WAVES_K, NBUF>;
     constexpr int BN = C::BN, BK = C::BK, NW = C::NW, RN = C::RN, RK = C::RK, IN_ = C::IN_, IK = C::IK, INST = C::INST;
     constexpr int BUF_FLOATS = C::BUF_FLOATS;
-    __shared__ __attribute__((aligned(16))) float smem[WG_NBUF * BUF_FLOATS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid / WAVES_K, wkk = wid % WAVES_K;
 
-    int b = blockIdx.x;
+    int b = block;
     const int split = b % p.splits;
     b /= p.splits;
     const int tile_k = b % p.tiles_k;
@@ -260,6 +259,42 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_kernel(Wgra
     if (do_bias && n0 + tid < p.Cout) p.db_part[(size_t)split * p.slab_floats + n0 + tid] = bsum;
 }
 
+template <int TN, int TK, int WAVES_N, int WAVES_K, int NBUF>
+__global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_kernel(WgradP p) {
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * WgCfg<TN, TK, WAVES_N, WAVES_K, NBUF>::BUF_FLOATS];
+    wgrad_body<TN, TK, WAVES_N, WAVES_K, NBUF>(p, blockIdx.x, smem);
+}
+
+// Several layers' weight gradients in ONE launch (the four output convolutions of an inception module become ready
+// together, and most of them are small: alone they are launch-latency bound).  The problems travel in the kernel
+// arguments like the forward groups (conv_fwd.hip).
+constexpr int kMaxWgGroup = 4;
+struct WgradGroupArgs {
+    int n;
+    int wg_end[kMaxWgGroup];      // exclusive prefix of workgroups per problem; the unused entries repeat the last one
+    WgradP p[kMaxWgGroup];
+};
+
+template <int TN, int TK, int WAVES_N, int WAVES_K, int NBUF>
+__global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_group_kernel(const WgradGroupArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * WgCfg<TN, TK, WAVES_N, WAVES_K, NBUF>::BUF_FLOATS];
+    const int b = blockIdx.x;
+    int pi = 0, begin = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxWgGroup - 1; ++i) {
+        const bool past = i + 1 < a.n && b >= a.wg_end[i];
+        pi += past ? 1 : 0;
+        begin = past ? a.wg_end[i] : begin;
+    }
+    typedef const WgradGroupArgs __attribute__((address_space(4))) * karg_ptr;
+    karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    union { WgradP p; unsigned w[sizeof(WgradP) / 4]; } u;
+    const unsigned __attribute__((address_space(4)))* src = (const unsigned __attribute__((address_space(4)))*)&ka->p[pi];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(WgradP) / 4); ++i) u.w[i] = src[i];
+    wgrad_body<TN, TK, WAVES_N, WAVES_K, NBUF>(u.p, b - begin, smem);
+}
+
 // tile shapes: X(index, TN, TK, WAVES_N, WAVES_K)
 #define FCN_WGRAD_CONFIGS(X) \
     X(0, 1, 1, 2, 2, 3)      \
@@ -294,6 +329,49 @@ __global__ __launch_bounds__(64 * RED_LANES) void reduce_partials_kernel(const f
             out[i] = t;
         }
         __syncthreads();
+    }
+}
+
+struct ReduceGroupArgs {
+    int n;
+    int blk_end[kMaxWgGroup];
+    const float* parts[kMaxWgGroup];
+    float* out[kMaxWgGroup];
+    unsigned long long count[kMaxWgGroup], stride[kMaxWgGroup];
+    int splits[kMaxWgGroup];
+};
+
+// the same fixed-order tree for up to kMaxWgGroup problems in one launch (one problem per block range)
+__global__ __launch_bounds__(64 * RED_LANES) void reduce_partials_group_kernel(const ReduceGroupArgs a) {
+    __shared__ float part[RED_LANES][64];
+    int pi = 0, begin = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxWgGroup - 1; ++i) {
+        const bool past = i + 1 < a.n && (int)blockIdx.x >= a.blk_end[i];
+        pi += past ? 1 : 0;
+        begin = past ? a.blk_end[i] : begin;
+    }
+    const float* parts = a.parts[0];
+    float* out = a.out[0];
+    size_t count = a.count[0], stride = a.stride[0];
+    int splits = a.splits[0];
+#pragma unroll
+    for (int i = 1; i < kMaxWgGroup; ++i)
+        if (pi == i) { parts = a.parts[i]; out = a.out[i]; count = a.count[i]; stride = a.stride[i]; splits = a.splits[i]; }
+    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t i = (size_t)((int)blockIdx.x - begin) * 64 + o;
+    float s = 0.f;
+    if (i < count) {
+#pragma unroll 4
+        for (int k = sl; k < splits; k += RED_LANES) s += parts[(size_t)k * stride + i];
+    }
+    part[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < count) {
+        float t = part[0][o];
+#pragma unroll
+        for (int l = 1; l < RED_LANES; ++l) t += part[l][o];
+        out[i] = t;
     }
 }
 
@@ -705,10 +783,8 @@ size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* d, int* h_splits) 
     return (size_t)splits * ((size_t)d->Cout * K + d->Cout);
 }
 
-// dW (OHWI, [Cout][kh][kw][Cin]) and db from the layer input x and the output gradient passed in desc->y / y_cstride /
-// y_coffset (desc->w and desc->bias are ignored).  d_workspace: fcn_conv2d_wgrad_workspace_floats() floats.
-int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_workspace, fcn_stream_t s) {
-    FCN_REQUIRE(d && d->x && d->y && dw && d_workspace, FCN_E_ARG, "wgrad: null");
+static int wgrad_validate(const fcn_conv_desc* d) {
+    FCN_REQUIRE(d && d->x && d->y, FCN_E_ARG, "wgrad: null");
     FCN_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 && d->stride > 0, FCN_E_ARG,
                 "wgrad: non-positive extent");
     FCN_REQUIRE(d->Cin % 4 == 0 && d->x_cstride % 4 == 0 && d->y_cstride % 4 == 0 && d->y_coffset % 4 == 0, FCN_E_ALIGN,
@@ -718,12 +794,10 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     FCN_REQUIRE((long long)d->N * d->OH * d->OW < (1ll << 31) && (long long)d->N * d->H * d->W * d->x_cstride < (1ll << 31), FCN_E_UNSUPPORTED,
                 "wgrad: tensor too large");
     FCN_REQUIRE(d->y_cstride >= d->y_coffset + d->Cout, FCN_E_ARG, "wgrad: gradient slice exceeds its channel stride");
-    int rc = 0;
-    const float* zp = zero_page_for_current_device(&rc);
-    if (rc) return rc;
-    int splits = 1, cfg = 0;
-    plan_wgrad(d, &cfg, &splits);
-    WgradP p;
+    return 0;
+}
+
+static void wgrad_fill(WgradP& p, const fcn_conv_desc* d, int cfg, int splits, float* slabs, bool with_bias, const float* zp) {
     p.x = d->x;
     p.dy = d->y + d->y_coffset;
     p.zero_page = zp;
@@ -739,9 +813,23 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     p.ow_magic = magic32((unsigned)p.OW);
     p.ohw_magic = magic32((unsigned)(p.OH * p.OW));
     p.kw_magic = (65536 + p.kw - 1) / p.kw;
-    p.dw_part = d_workspace;
+    p.dw_part = slabs;
     p.slab_floats = p.Cout * p.K + p.Cout;
-    p.db_part = db ? d_workspace + (size_t)p.Cout * p.K : nullptr;
+    p.db_part = with_bias ? slabs + (size_t)p.Cout * p.K : nullptr;
+}
+
+// dW (OHWI, [Cout][kh][kw][Cin]) and db from the layer input x and the output gradient passed in desc->y / y_cstride /
+// y_coffset (desc->w and desc->bias are ignored).  d_workspace: fcn_conv2d_wgrad_workspace_floats() floats.
+int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_workspace, fcn_stream_t s) {
+    FCN_REQUIRE(d && dw && d_workspace, FCN_E_ARG, "wgrad: null");
+    int rc = wgrad_validate(d);
+    if (rc) return rc;
+    const float* zp = zero_page_for_current_device(&rc);
+    if (rc) return rc;
+    int splits = 1, cfg = 0;
+    plan_wgrad(d, &cfg, &splits);
+    WgradP p;
+    wgrad_fill(p, d, cfg, splits, d_workspace, db != nullptr, zp);
     hipStream_t st = as_stream(s);
     switch (cfg) {
 #define X(I, A, B, C_, D, E)                                                                                                              \
@@ -761,6 +849,108 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     if (db && !together)
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.Cout, 64)), dim3(64 * RED_LANES), 0, st, p.db_part, db, (size_t)p.Cout, splits, stride);
     FCN_LAUNCH_CHECK("conv_wgrad");
+    return 0;
+}
+
+// One tile shape for the whole group (the one with the least padded work over all problems), pixel splits so that the
+// launch has ~1024-1536 workgroups in total.
+static void plan_wgrad_group(const fcn_conv_desc* ds, int n, int* cfg_out, int* splits) {
+    int best = 0;
+    const char* force = getenv("FCN_WGRAD_CFG");
+    if (force && force[0] >= '0' && force[0] < '0' + kNumWgCfg) {
+        best = force[0] - '0';
+    } else {
+        double best_cost = 1e300;
+        for (int c = 0; c < kNumWgCfg; ++c) {
+            double cost = 0;
+            for (int i = 0; i < n; ++i) {
+                const long long K = (long long)ds[i].kh * ds[i].kw * ds[i].Cin, M = (long long)ds[i].N * ds[i].OH * ds[i].OW;
+                cost += (double)cdiv(ds[i].Cout, kWgShapes[c].bn) * kWgShapes[c].bn * cdiv(K, kWgShapes[c].bk) * kWgShapes[c].bk * (double)M /
+                        kWgShapes[c].eff;
+            }
+            if (cost < best_cost) { best_cost = cost; best = c; }
+        }
+    }
+    long long tiles = 0;
+    for (int i = 0; i < n; ++i)
+        tiles += (long long)cdiv(ds[i].Cout, kWgShapes[best].bn) * cdiv((long long)ds[i].kh * ds[i].kw * ds[i].Cin, kWgShapes[best].bk);
+    for (int i = 0; i < n; ++i) {
+        const int chunks = cdiv((long long)ds[i].N * ds[i].OH * ds[i].OW, WG_BP);
+        int sp = cdiv(1024, tiles);
+        if (sp > chunks) sp = chunks;
+        if (sp < 1) sp = 1;
+        if (sp > 256) sp = 256;
+        splits[i] = sp;
+    }
+    *cfg_out = best;
+}
+
+size_t fcn_conv2d_wgrad_group_workspace_floats(const fcn_conv_desc* ds, int n) {
+    if (!ds || n <= 0 || n > kMaxWgGroup) return 0;
+    int cfg = 0, splits[kMaxWgGroup];
+    plan_wgrad_group(ds, n, &cfg, splits);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += (size_t)splits[i] * ((size_t)ds[i].Cout * ds[i].kh * ds[i].kw * ds[i].Cin + ds[i].Cout) + 4;
+    return total;
+}
+
+// n <= 4 layers in one launch + one grouped reduction.  dbs[i] may be NULL; when dbs[i] == dws[i] + Cout*K (the solver's
+// layout) weight and bias partials are reduced together.
+int fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* ds, float* const* dws, float* const* dbs, int n, float* d_workspace, fcn_stream_t s) {
+    FCN_REQUIRE(ds && dws && dbs && d_workspace && n > 0 && n <= kMaxWgGroup, FCN_E_ARG, "wgrad group: need 1..%d problems", kMaxWgGroup);
+    int rc = 0;
+    for (int i = 0; i < n; ++i) {
+        rc = wgrad_validate(&ds[i]);
+        if (rc) return rc;
+        FCN_REQUIRE(dws[i], FCN_E_ARG, "wgrad group: null dw");
+    }
+    const float* zp = zero_page_for_current_device(&rc);
+    if (rc) return rc;
+    int cfg = 0, splits[kMaxWgGroup];
+    plan_wgrad_group(ds, n, &cfg, splits);
+    WgradGroupArgs ga;
+    ReduceGroupArgs ra;
+    ga.n = ra.n = n;
+    float* slabs = d_workspace;
+    int wgs = 0, blks = 0, extra = 0;
+    struct Extra { const float* parts; float* out; size_t count, stride; int splits; } extras[kMaxWgGroup];
+    for (int i = 0; i < kMaxWgGroup; ++i) {
+        const int j = i < n ? i : n - 1;
+        if (i < n) {
+            wgrad_fill(ga.p[i], &ds[i], cfg, splits[i], slabs, dbs[i] != nullptr, zp);
+            const WgradP& p = ga.p[i];
+            wgs += p.tiles_n * p.tiles_k * p.splits;
+            const size_t cnt = (size_t)p.Cout * p.K;
+            const bool together = dbs[i] && dbs[i] == dws[i] + cnt;
+            ra.parts[i] = p.dw_part;
+            ra.out[i] = dws[i];
+            ra.count[i] = together ? cnt + p.Cout : cnt;
+            ra.stride[i] = (unsigned long long)p.slab_floats;
+            ra.splits[i] = p.splits;
+            blks += (int)((ra.count[i] + 63) / 64);
+            if (dbs[i] && !together) extras[extra++] = Extra{p.db_part, dbs[i], (size_t)p.Cout, (size_t)p.slab_floats, p.splits};
+            slabs += ((size_t)p.splits * p.slab_floats + 3) / 4 * 4;
+        } else {
+            ga.p[i] = ga.p[j];
+            ra.parts[i] = ra.parts[j]; ra.out[i] = ra.out[j]; ra.count[i] = ra.count[j]; ra.stride[i] = ra.stride[j]; ra.splits[i] = ra.splits[j];
+        }
+        ga.wg_end[i] = wgs;
+        ra.blk_end[i] = blks;
+    }
+    hipStream_t st = as_stream(s);
+    switch (cfg) {
+#define X(I, A, B, C_, D, E)                                                                                          \
+    case I:                                                                                                           \
+        hipLaunchKernelGGL((conv_wgrad_group_kernel<A, B, C_, D, E>), dim3(wgs), dim3(64 * C_ * D), 0, st, ga); \
+        break;
+        FCN_WGRAD_CONFIGS(X)
+#undef X
+    }
+    hipLaunchKernelGGL(reduce_partials_group_kernel, dim3(blks), dim3(64 * RED_LANES), 0, st, ra);
+    for (int e = 0; e < extra; ++e)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((long long)extras[e].count, 64)), dim3(64 * RED_LANES), 0, st, extras[e].parts,
+                           extras[e].out, extras[e].count, extras[e].splits, extras[e].stride);
+    FCN_LAUNCH_CHECK("conv_wgrad_group");
     return 0;
 }
 

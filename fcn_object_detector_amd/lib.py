@@ -125,6 +125,8 @@ PROTOTYPES = {
     "fcn_gen_targets_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "fcn_conv2d_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc), C.POINTER(_i)]),
     "fcn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
+    "fcn_conv2d_wgrad_group_workspace_floats": (_sz, [C.POINTER(ConvDesc), _i]),
+    "fcn_conv2d_wgrad_group_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _vp]),
     "fcn_conv_weights_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fcn_nchw_f32_to_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "fcn_nhwc_f16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -177,6 +177,8 @@ class TrainEngine(Engine):
                     concat_relu[m] = parent
         relu_done: set = set()
         dgrad_done: set = set()
+        wgrad_done: set = set()
+        sibling_reduces: Dict[str, List[Layer]] = {}      # reduce layer -> the reduce layers of its module (ready together)
         # Flipped / transposed filter banks of the data-gradient passes: slices of ONE flat buffer that a single launch
         # refreshes from the current weights at the start of every backward pass (58 launches otherwise).
         flip_layout: Dict[str, int] = {}
@@ -234,6 +236,49 @@ class TrainEngine(Engine):
             self._keep.extend([arr, gws, grp])
             ops.append(Op("dgrad", "%s [cfg%d %dwg]" % (name, grp.cfg, grp.total_tiles),
                           lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), sum(it[1] for it in items)))
+
+        def wgrad_item(l: Layer, gtop: Blob):
+            """(descriptor with y = dY of the layer, dW view, db view or None, flops) of a layer that learns."""
+            xb, yb = B[l.bottoms[0]], B[l.tops[0]]
+            k, s, pad = kernel_stride_pad(l.sub("convolution_param"))
+            n, cin, h, w = xb.shape
+            _, cout, oh, ow = yb.shape
+            if gtop.coffset % 4 or gtop.cstride % 4:
+                raise NotImplementedError("gradient view of %s is not 16-byte aligned" % l.tops[0])
+            d = L.ConvDesc()
+            d.x, d.y = xb.ptr, gtop.buf.ptr
+            d.N, d.H, d.W, d.Cin, d.x_cstride = n, h, w, _r4(cin), xb.cstride
+            d.Cout, d.kh, d.kw, d.pad, d.stride, d.OH, d.OW = cout, k, k, pad, s, oh, ow
+            d.y_cstride, d.y_coffset = gtop.cstride, gtop.coffset
+            self._keep.append(d)
+            dw = self._grad_view(l.name, 0)
+            db = self._grad_view(l.name, 1) if len(self.params_dev[l.name]) > 1 else None
+            return d, dw, db, 2.0 * n * cout * oh * ow * cin * k * k
+
+        def emit_wgrads(layers_: List[Layer], gtops: List[Blob]) -> None:
+            """Weight (and bias) gradients of layers that are ready together: one launch + one reduction for up to four."""
+            nonlocal ws_floats
+            todo = [(l_, g_) for l_, g_ in zip(layers_, gtops) if self._learns(l_) and l_.name not in wgrad_done]
+            for base in range(0, len(todo), 4):
+                chunk = todo[base:base + 4]
+                its = [wgrad_item(l_, g_) for l_, g_ in chunk]
+                names = [l_.name for l_, _ in chunk]
+                if len(its) == 1:
+                    d, dw, db, fl = its[0]
+                    ws_floats = max(ws_floats, int(lib.fcn_conv2d_wgrad_workspace_floats(C.byref(d), None)))
+                    op = Op("wgrad", names[0], lambda st, d=d, dw=dw, db=db: L.check(lib.fcn_conv2d_wgrad_f32(
+                        C.byref(d), dw.ptr, db.ptr if db else None, self._ws.ptr, st)), fl)
+                else:
+                    arr = (L.ConvDesc * len(its))(*[it[0] for it in its])
+                    pdw = (C.c_void_p * len(its))(*[it[1].ptr for it in its])
+                    pdb = (C.c_void_p * len(its))(*[(it[2].ptr if it[2] is not None else None) for it in its])
+                    ws_floats = max(ws_floats, int(lib.fcn_conv2d_wgrad_group_workspace_floats(arr, len(its))))
+                    self._keep.extend([arr, pdw, pdb])
+                    op = Op("wgrad", "+".join(names), lambda st, arr=arr, pdw=pdw, pdb=pdb, m=len(its): L.check(lib.fcn_conv2d_wgrad_group_f32(
+                        arr, pdw, pdb, m, self._ws.ptr, st)), sum(it[3] for it in its))
+                op.layers = names
+                ops.append(op)
+                wgrad_done.update(names)
 
         for l in reversed(spec.layers):
             t = l.type
@@ -298,24 +343,37 @@ class TrainEngine(Engine):
                             for nm in names:
                                 dgrad_done.add(nm)
                                 mark(G[[q for q in spec.layers if q.name == nm][0].bottoms[0]])
+                        # ... and their weight gradients need nothing else either: one grouped launch
+                        mem_layers = [[q for q in self.producers.get(m, []) if q.type == "Convolution"][0] for m in concat_members[whole]]
+                        emit_wgrads(mem_layers, [G[m] for m in concat_members[whole]])
+                        # the layers feeding the members (3x3_reduce, 5x5_reduce) get their whole gradient from that dgrad
+                        # launch: they become ready together too
+                        sibs = []
+                        for lm in mem_layers:
+                            if lm.name not in dgrad_done:
+                                continue
+                            prods = [q for q in self.producers.get(lm.bottoms[0], []) if q.type == "Convolution"]
+                            cons = [q for q in self.consumers.get(lm.bottoms[0], []) if not (q.type in ("ReLU", "Dropout") and q.bottoms == q.tops)]
+                            if len(prods) == 1 and len(cons) == 1 and lm.bottoms[0] not in self.alias and lm.bottoms[0] in G:
+                                sibs.append(prods[0])
+                        if len(sibs) > 1:
+                            for q in sibs:
+                                sibling_reduces[q.name] = sibs
                     else:
                         ops.append(Op("relu_bwd", l.name, lambda st, g=gtop, y=yb: L.check(lib.fcn_relu_bwd_f32(
                             g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yb.pixels * cout))
-                d = L.ConvDesc()
-                d.x, d.y = xb.ptr, gtop.buf.ptr
-                d.N, d.H, d.W, d.Cin, d.x_cstride = n, h, w, _r4(cin), xb.cstride
-                d.Cout, d.kh, d.kw, d.pad, d.stride, d.OH, d.OW = cout, k, k, pad, s, oh, ow
-                d.y_cstride, d.y_coffset = gtop.cstride, gtop.coffset
-                if gtop.coffset % 4 or gtop.cstride % 4:
-                    raise NotImplementedError("gradient view of %s is not 16-byte aligned" % l.tops[0])
-                flops = 2.0 * n * cout * oh * ow * cin * k * k
-                if self._learns(l):
-                    ws_floats = max(ws_floats, int(lib.fcn_conv2d_wgrad_workspace_floats(C.byref(d), None)))
-                    dw = self._grad_view(l.name, 0)
-                    db = self._grad_view(l.name, 1) if len(self.params_dev[l.name]) > 1 else None
-                    self._keep.append(d)
-                    ops.append(Op("wgrad", l.name, lambda st, d=d, dw=dw, db=db: L.check(lib.fcn_conv2d_wgrad_f32(
-                        C.byref(d), dw.ptr, db.ptr if db else None, self._ws.ptr, st)), flops))
+                        relu_done.add(l.tops[0])
+                sibs = sibling_reduces.get(l.name)
+                if sibs and l.name not in wgrad_done and all(state(G[q.tops[0]]) == "full" for q in sibs):
+                    # first of the module's reduce layers to be visited: mask and take the weight gradients of all of them now
+                    for q in sibs:
+                        if q.tops[0] not in relu_done and self._conv_layer_meta[q.name].get("relu"):
+                            gq, yq = G[q.tops[0]], B[q.tops[0]]
+                            ops.append(Op("relu_bwd", q.name, lambda st, g=gq, y=yq: L.check(lib.fcn_relu_bwd_f32(
+                                g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yq.pixels * yq.channels))
+                            relu_done.add(q.tops[0])
+                    emit_wgrads(sibs, [G[q.tops[0]] for q in sibs])
+                emit_wgrads([l], [gtop])
                 gbot = G.get(l.bottoms[0])
                 if gbot is not None and l.name not in dgrad_done:
                     emit_dgrads(l.name, [dgrad_desc(l, gtop, gbot, state(gbot) == "full")])
@@ -419,24 +477,32 @@ class TrainEngine(Engine):
 
     def _plan_buckets(self, bucket_floats: int = 1536 * 1024) -> None:
         """Gradient buckets for the overlapped all-reduce: contiguous ranges of the flat gradient buffer (forward layer
-        order).  Backward fills the buffer from its end, so a bucket is complete once the wgrad of its FIRST layer has been
-        enqueued; its all-reduce then runs on a side stream while the main stream continues with earlier layers."""
+        order).  Backward fills the buffer roughly from its end; a bucket is complete once the LAST of its layers' weight
+        gradient launches (grouped launches reorder them within a module) has been enqueued; its all-reduce then runs on a
+        side stream while the main stream continues with earlier layers."""
         self.buckets: List[dict] = []
         if self.comm is None:
             return
         cur = None
         for e in self.param_layout:
             if cur is None or (e["index"] == 0 and cur["count"] >= bucket_floats):
-                cur = dict(offset=e["offset"], count=0, first_layer=e["layer"])
+                cur = dict(offset=e["offset"], count=0, layers=[])
                 self.buckets.append(cur)
             cur["count"] = e["offset"] + _r4(e["count"]) - cur["offset"]
-        wg_index = {op.name: i for i, op in enumerate(self.bwd_ops) if op.kind == "wgrad"}
+            if e["layer"] not in cur["layers"]:
+                cur["layers"].append(e["layer"])
+        wg_index = {}
+        for i, op in enumerate(self.bwd_ops):
+            if op.kind == "wgrad":
+                for nm in getattr(op, "layers", [op.name]):
+                    wg_index[nm] = i
         lib = L.load()
         sp = C.c_void_p()
         L.call("fcn_stream_create", C.byref(sp))
         self.comm_stream = int(sp.value)
         for b in self.buckets:
-            b["after_op"] = wg_index.get(b["first_layer"], len(self.bwd_ops) - 1)
+            done = [wg_index[nm] for nm in b["layers"] if nm in wg_index]
+            b["after_op"] = max(done) if done else len(self.bwd_ops) - 1
             for key in ("ready", "done"):
                 ev = C.c_void_p()
                 L.call("fcn_event_create", C.byref(ev))

@@ -273,6 +273,11 @@ int  fcn_gen_targets_nhwc(const int32_t* rects, const int32_t* labels, const int
  * db is [Cout] or NULL.  Bit-reproducible (pixel splits are summed in a fixed order).  Workspace size in floats: */
 size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* h_d, int* h_splits);
 int  fcn_conv2d_wgrad_f32(const fcn_conv_desc* h_d, float* dw, float* db, float* d_workspace, fcn_stream_t s);
+/* Up to 4 layers in ONE launch (+ one grouped fixed-order reduction): the output convolutions of an inception module become
+ * ready together and most of them are too small to fill the chip alone.  dbs[i] may be NULL. */
+size_t fcn_conv2d_wgrad_group_workspace_floats(const fcn_conv_desc* h_ds, int n);
+int  fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* h_ds, float* const* h_dws, float* const* h_dbs, int n, float* d_workspace,
+                                fcn_stream_t s);
 /* Filter bank of the data-gradient pass: wt[c][kh-1-r][kw-1-q][k] = w[k][r][q][c] (w: [Cout][kh][kw][Cin4],
  * wt: [Cin][kh][kw][Cout4], zero padded).  dX = fcn_conv2d_fwd_f32(dY, wt) with pad' = k-1-pad for stride-1 layers. */
 int  fcn_conv_weights_flip_f32(const float* w, float* wt, int Cout, int kh, int kw, int Cin, int Cin4, int Cout4, fcn_stream_t s);

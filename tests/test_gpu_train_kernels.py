@@ -226,3 +226,59 @@ def test_weights_flip_batch_equals_per_layer_flip(gpu):
         L.call("fcn_conv_weights_flip_f32", wd.ptr + 4 * sg.w_offset, one.ptr, cout, k, k, cin, sg.Cin4, sg.Cout4, None)
         want = dev_to(one, (cin * k * k * sg.Cout4,))
         assert np.array_equal(got[sg.wt_offset:sg.wt_offset + want.size], want)
+
+
+@pytest.mark.parametrize("wg_cfg", [None, "0", "2"])
+def test_wgrad_group_matches_oracle(gpu, monkeypatch, wg_cfg):
+    """Four layers' weight gradients in one launch + one grouped reduction (fcn_conv2d_wgrad_group_f32): each equals the
+    oracle and the single-layer entry point; bias behind the weights (the solver's layout), elsewhere, or absent."""
+    if wg_cfg is None:
+        monkeypatch.delenv("FCN_WGRAD_CFG", raising=False)
+    else:
+        monkeypatch.setenv("FCN_WGRAD_CFG", wg_cfg)
+    rng = np.random.default_rng(12)
+    n, h, w = 2, 14, 11
+    cases = [(64, 48, 1, 0), (24, 40, 3, 1), (16, 8, 5, 2), (64, 33, 1, 0)]          # cin, cout, k, pad
+    lib = L.load()
+    descs, refs, keep, dws, dbs = [], [], [], [], []
+    for i, (cin, cout, k, pad) in enumerate(cases):
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        dy = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        wt = np.zeros((cout, cin, k, k), np.float32)
+        dw_ref, db_ref, _ = R.conv2d_backward(x, wt, dy, pad, 1, need_dx=False)
+        cin4, co4 = r4(cin), r4(cout)
+        xd, dyd = dev_from(nhwc(x, cin4)), dev_from(nhwc(dy, co4 + 4, 4))
+        d = conv_desc(xd, xd, None, dyd, n, h, w, cin4, cin4, cout, k, pad, 1, h, w, co4 + 4, 4)
+        flat = dev_from(np.full(cout * k * k * cin4 + cout + 8, 3.0, np.float32))
+        dws.append(flat.ptr)
+        if i == 0:
+            dbs.append(flat.ptr + 4 * cout * k * k * cin4)           # right behind the weights: reduced together
+        elif i == 1:
+            dbs.append(flat.ptr + 4 * (cout * k * k * cin4 + 4))     # somewhere else: its own reduction
+        elif i == 2:
+            dbs.append(None)
+        else:
+            dbs.append(flat.ptr + 4 * cout * k * k * cin4)
+        keep += [xd, dyd, flat]
+        descs.append(d)
+        refs.append((flat, cout, k, cin, cin4, dw_ref, db_ref, dbs[-1]))
+    arr = (L.ConvDesc * 4)(*descs)
+    ws = DeviceBuffer(int(lib.fcn_conv2d_wgrad_group_workspace_floats(arr, 4)) * 4, zero=False)
+    pdw = (C.c_void_p * 4)(*dws)
+    pdb = (C.c_void_p * 4)(*dbs)
+    L.call("fcn_conv2d_wgrad_group_f32", arr, pdw, pdb, 4, ws.ptr, None)
+    first = []
+    for flat, cout, k, cin, cin4, dw_ref, db_ref, dbp in refs:
+        nw = cout * k * k * cin4
+        got = dev_to(flat, (nw + cout + 8,))
+        first.append(got.copy())
+        dw = got[:nw].reshape(cout, k, k, cin4)
+        assert rel_err(dw[..., :cin].transpose(0, 3, 1, 2), dw_ref) < TOL
+        if dbp is None:
+            assert np.all(got[nw:] == 3.0)
+        else:
+            off = (dbp - flat.ptr) // 4
+            assert rel_err(got[off:off + cout], db_ref) < TOL
+    L.call("fcn_conv2d_wgrad_group_f32", arr, pdw, pdb, 4, ws.ptr, None)             # bit-reproducible
+    for (flat, cout, k, cin, cin4, *_), f in zip(refs, first):
+        assert np.array_equal(dev_to(flat, f.shape), f)
