@@ -221,6 +221,7 @@ class Engine:
         alias: Dict[str, Tuple[str, int]] = {}   # child blob -> (parent blob, channel offset in parent)
         shift: Dict[str, float] = {}
         self.copy_concats = set()
+        self.copy_slices = set()
         for l in spec.layers:
             if l.type == "Concat":
                 off = 0
@@ -254,10 +255,20 @@ class Engine:
                     shift[l.tops[0]] = float(p.get("shift", 0.0))
             elif l.type == "Slice":
                 n, c, h, w = self.shapes[l.bottoms[0]]
-                off = 0
+                # tops are views of the bottom when every consumer can read a channel slice at a 16-byte aligned offset;
+                # otherwise (models/train_val.prototxt slices a 17-channel label record at 1, 5, 9, 13 for Eltwise layers)
+                # the slices are materialised by copies
+                offs, off = [], 0
                 for t in l.tops:
-                    alias[t] = (l.bottoms[0], off)
+                    offs.append(off)
                     off += self.shapes[t][1]
+                viewable = all(o % (16 // esize[l.bottoms[0]]) == 0 for o in offs) and all(
+                    q.type in ("Convolution", "Pooling", "Concat") for t in l.tops for q in consumers.get(t, []))
+                if viewable:
+                    for t, o in zip(l.tops, offs):
+                        alias[t] = (l.bottoms[0], o)
+                else:
+                    self.copy_slices.add(l.name)
         self.alias, self.shift = alias, shift
 
         # allocate roots, then resolve views
@@ -448,7 +459,7 @@ class Engine:
                 continue
             if t == "Concat" and l.name not in self.copy_concats:
                 continue      # producers already wrote their slices
-            if t == "Slice":
+            if t == "Slice" and l.name not in self.copy_slices:
                 continue      # tops are views of the bottom
             if t == "Dropout" and spec.phase == "TEST" and (l.tops[0] == l.bottoms[0] or l.tops[0] in self.alias):
                 continue
@@ -711,6 +722,16 @@ class Engine:
             out.append(Op("loss", l.name, lambda st: L.check(lib.fcn_softmax_loss_f32(
                 xb.ptr, lab.ptr, da, lb.buf.ptr, xb.shape[0], xb.pixels, xb.channels, xb.cstride, lab.cstride, normalize,
                 0 if ign is None else 1, 0 if ign is None else int(ign), weight, ws.ptr, st)), 0.0, 8.0 * xb.pixels * xb.channels))
+        elif t == "Slice":
+            off = 0
+            xb = B[l.bottoms[0]]
+            for tn in l.tops:
+                yb = B[tn]
+                o = off
+                out.append(Op("copy", l.name + ":" + tn, lambda st, yb=yb, o=o: L.check(lib.fcn_copy_channels_f32(
+                    xb.buf.ptr, yb.buf.ptr, yb.pixels, yb.channels, xb.cstride, xb.coffset + o, yb.cstride, yb.coffset, st)),
+                    0.0, 8.0 * yb.pixels * yb.channels))
+                off += yb.channels
         elif t == "Concat":
             off = 0
             yb = B[l.tops[0]]

@@ -148,6 +148,39 @@ def googlenet_detectnet_train(module: str, layer: str, param_str: str, num_class
     return w.text()
 
 
+def googlenet_detectnet_train_lmdb(features_db: str = "/home/krishneel/Desktop/lmdb/features", labels_db: str = "/home/krishneel/Desktop/lmdb/labels",
+                                   batch: int = 1, num_classes: int = 1, head_classes: Optional[int] = None) -> str:
+    """The reference's models/train_val.prototxt as it stands (models/train_val2.prototxt = head_classes 3 over the SAME
+    1-class slice points: the reference's own inconsistency, reproduced when asked for): two LMDB `Data` layers (image, 17-channel label record), a
+    `Slice` that cuts the record into coverage-label / bbox-label / size-block / obj-block / coverage-block, then the same
+    body and loss tail as googlenet_detectnet_train.  LMDB reading is out of scope: with this engine the two
+    Data tops are input blobs the caller fills (pycaffe `net.blobs['data'].data[...] = ...`)."""
+    w = _Writer()
+    for name, top, src in (("train_data", "data", features_db), ("train_label", "label", labels_db)):
+        body = "  include { phase: TRAIN }\n  data_param {\n    source: \"%s\"\n    batch_size: %d\n    backend: LMDB\n  }" % (src, batch)
+        w.layer(name, "Data", [], [top], body)
+    c = num_classes
+    pts = (c, 5 * c, 9 * c, 13 * c)
+    slice_tops = ["coverage-label", "bbox-label", "size-block", "obj-block", "coverage-block"]
+    slice_body = "  slice_param {\n    slice_dim: 1\n" + "".join("    slice_point: %d\n" % p for p in pts) + "  }"
+    prod = "  eltwise_param { operation: PROD }"
+    feat_w = _Writer()
+    feat = _googlenet_body(feat_w, "data")
+    body_layers = feat_w.lines
+    w.lines.append(body_layers[0])                                   # deploy_transform (Power) sits in front of the Slice
+    w.layer("slice-label", "Slice", ["label"], slice_tops, slice_body)
+    w.layer("bb-label-norm", "Eltwise", ["bbox-label", "size-block"], ["bbox-label-norm"], prod)
+    w.layer("bb-obj-norm", "Eltwise", ["bbox-label-norm", "obj-block"], ["bbox-obj-label-norm"], prod)
+    w.lines.extend(body_layers[1:])
+    _heads(w, feat, head_classes or num_classes)
+    w.layer("bbox_mask", "Eltwise", ["bboxes", "coverage-block"], ["bboxes-masked"], prod)
+    w.layer("bbox-norm", "Eltwise", ["bboxes-masked", "size-block"], ["bboxes-masked-norm"], prod)
+    w.layer("bbox-obj-norm", "Eltwise", ["bboxes-masked-norm", "obj-block"], ["bboxes-obj-masked-norm"], prod)
+    w.layer("bbox_loss", "L1Loss", ["bboxes-obj-masked-norm", "bbox-obj-label-norm"], ["loss_bbox"], extra="  loss_weight: 2.0")
+    w.layer("coverage_loss", "EuclideanLoss", ["coverage", "coverage-label"], ["loss_coverage"])
+    return w.text()
+
+
 # VGG16 conv stack: (block, number of convs, width)
 VGG16 = [(1, 2, 64), (2, 2, 128), (3, 3, 256), (4, 3, 512), (5, 3, 512)]
 

@@ -283,6 +283,8 @@ class TrainEngine(Engine):
         for l in reversed(spec.layers):
             t = l.type
             if t in DATA_TYPES or t in ("Concat", "Slice") or (t == "ReLU" and l.name in self._fused_relu_layers()):
+                if t == "Slice" and l.name in self.copy_slices and any(tp in G for tp in l.tops):
+                    raise NotImplementedError("backward through the copied Slice %s" % l.name)
                 continue
             if t in ("L1Loss", "EuclideanLoss", "SoftmaxWithLoss"):
                 g = G.get(l.bottoms[0])

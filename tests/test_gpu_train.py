@@ -121,3 +121,31 @@ def test_three_solver_steps_match_oracle(gpu, kind):
             if np.linalg.norm(dr) > 0:
                 assert np.linalg.norm(du - dr) < 0.25 * np.linalg.norm(dr), name
     eng.close()
+
+
+def test_reference_lmdb_fronted_net_equals_python_layer_net(gpu):
+    """models/train_val.prototxt as shipped (Data tops `data` / 17-channel `label`, Slice into the five label blobs) gives the
+    same losses and weight gradients as the Python-layer form of the same net when the label record holds the same tensors."""
+    msg, spec, data, eng, ref, rsolver, rng = build(lr=0.0)
+    for k, v in data.items():
+        eng.host_array(k)[...] = v
+    want = eng.step(seed=3)
+    g_want = eng.download_grads()
+    eng.close()
+    lmsg = proto.parse_text(models.googlenet_detectnet_train_lmdb(batch=2, num_classes=1))
+    record = np.concatenate([data[k] for k in ("coverage-label", "bbox-label", "size-block", "obj-block", "coverage-block")], axis=1)
+    assert record.shape[1] == 17
+    shapes = {"data": data["data"].shape, "label": record.shape}
+    lspec = NetSpec(lmsg, "TRAIN")
+    lspec.infer(shapes)
+    sp = SolverParams(base_lr=0.0, momentum=0.9, weight_decay=1e-7, lr_policy="fixed")
+    leng = TrainEngine(NetSpec(lmsg, "TRAIN"), shapes, params=fill_params(lspec, seed=1234), device=0, solver=sp)
+    leng.host_array("data")[...] = data["data"]
+    leng.host_array("label")[...] = record
+    got = leng.step(seed=3)
+    for k in ("loss_bbox", "loss_coverage", "total_loss"):
+        assert abs(got[k] - want[k]) <= 1e-6 * abs(want[k]), k
+    g_got = leng.download_grads()
+    for name in ("conv1/7x7_s2", "inception_4a/1x1", "bbox/regressor"):
+        assert rel_err(g_got[name][0], g_want[name][0]) < 1e-5, name
+    leng.close()

@@ -146,6 +146,17 @@ def test_builder_equals_reference_bounding_box_train():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+def test_builder_equals_reference_models_train_val():
+    """The LMDB-fronted training nets as shipped: models/train_val.prototxt and models/train_val2.prototxt (3-class heads)."""
+    for rel, kw in (("models/train_val.prototxt", {}), ("models/train_val2.prototxt", {"head_classes": 3})):
+        a = _signature(proto.parse_file(os.path.join(REF, rel)), "TRAIN")
+        b = _signature(proto.parse_text(models.googlenet_detectnet_train_lmdb(**kw)), "TRAIN")
+        assert len(a[1]) == len(b[1]) == 152
+        for x, y in zip(a[1], b[1]):
+            assert x == y
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
 def test_all_reference_prototxts_parse():
     for rel in ("models/deploy.prototxt", "models/train_val.prototxt", "models/train_val2.prototxt",
                 "train/fcn_bbox/train_val.prototxt", "train/bounding_box/train_val.prototxt",
