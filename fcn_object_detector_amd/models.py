@@ -64,10 +64,10 @@ def _conv_body(num_output: int, k: int, pad: int = 0, stride: int = 1, bias_valu
     s = ["  param { lr_mult: %g decay_mult: %g }" % (lr[0], decay[0]),
          "  param { lr_mult: %g decay_mult: %g }" % (lr[1], decay[1]),
          "  convolution_param {", "    num_output: %d" % num_output]
-    if pad or explicit:
+    if pad or explicit:                      # explicit: True = write pad and stride even at their defaults, "pad" = pad only
         s.append("    pad: %d" % pad)
     s.append("    kernel_size: %d" % k)
-    if stride != 1 or explicit:
+    if stride != 1 or explicit is True:
         s.append("    stride: %d" % stride)
     s += ['    weight_filler { type: "xavier" }', '    bias_filler { type: "constant" value: %g }' % bias_value, "  }"]
     return "\n".join(s)
@@ -291,4 +291,42 @@ def vgg16_bounding_box_train(module: str, layer: str, param_str: str, num_classe
     w.layer("bbox-obj-norm", "Eltwise", ["bboxes-masked-norm", "obj-block"], ["bboxes-obj-masked-norm"], prod)
     w.layer("bbox_loss", "L1Loss", ["bboxes-obj-masked-norm", "bbox-obj-label-norm"], ["loss_bbox"], extra="  loss_weight: 2.0")
     w.layer("coverage_loss", "EuclideanLoss", ["coverage", "coverage-label"], ["loss_coverage"])
+    return w.text()
+
+
+def vgg16_bounding_box_deploy(batch: int = 10, height: int = 448, width: int = 448, num_classes: int = 20) -> str:
+    """The reference's train/bounding_box/deploy.prototxt: VGG16 to conv5_3 (stride 16), a pyramid-pooling context branch on
+    conv4_3 (AVE pools to 1x1 / 2x2 / 4x4 / 7x7, 1x1 convolutions to 128 channels, frozen bilinear deconvolutions back to
+    28x28), concatenated with conv5_3 and pool4 (1536 channels), dropout, the DetectNet coverage / bbox heads."""
+    w = _Writer()
+    w.layer("data", "Input", [], ["data"], "  input_param { shape { dim: %d dim: 3 dim: %d dim: %d } }" % (batch, height, width))
+    prev = "data"
+    for blk, n, width_ in VGG16[:4]:
+        for i in range(1, n + 1):
+            nm = "conv%d_%d" % (blk, i)
+            w.layer(nm, "Convolution", [prev], [nm], _conv_body(width_, 3, 1, bias_value=0.0))
+            w.layer("relu%d_%d" % (blk, i), "ReLU", [nm], [nm])
+            prev = nm
+        w.layer("pool%d" % blk, "Pooling", [prev], ["pool%d" % blk], "  pooling_param { pool: MAX kernel_size: 2 stride: 2 }")
+        prev = "pool%d" % blk
+    ups = []
+    for tag, pk, dk, ds, dp in (("1x1", 56, 56, 28, 14), ("2x2", 28, 28, 14, 7), ("4x4", 14, 13, 7, 3), ("7x7", 8, 8, 4, 2)):
+        w.layer("pool4/" + tag, "Pooling", ["conv4_3"], ["pool4/" + tag], "  pooling_param { pool: AVE kernel_size: %d stride: %d }" % (pk, pk))
+        cn = "conv4_3/" + tag
+        w.layer(cn, "Convolution", ["pool4/" + tag], [cn], _conv_body(128, 1, 0, bias_value=0.0, lr=(10.0, 2.0), explicit="pad"))
+        w.layer("act_4_3/" + tag, "ReLU", [cn], [cn])
+        _frozen_bilinear_deconv(w, cn + "/upsample", cn, 128, dk, ds, dp)
+        ups.append(cn + "/upsample")
+    prev = "pool4"
+    for i in range(1, 4):
+        nm = "conv5_%d" % i
+        w.layer(nm, "Convolution", [prev], [nm], _conv_body(512, 3, 1, bias_value=0.0))
+        if i < 3:
+            w.layer("relu5_%d" % i, "ReLU", [nm], [nm])
+        prev = nm
+    w.layer("conv4_3/conv5_3/concat", "Concat", ["conv5_3", "pool4"] + ups, ["conv4_3/conv5_3/concat"])
+    w.layer("dropout5", "Dropout", ["conv4_3/conv5_3/concat"], ["dropout5"], "  dropout_param { dropout_ratio: 0.5 }")
+    w.layer("cvg/classifier", "Convolution", ["dropout5"], ["cvg/classifier"], _conv_body(num_classes, 1, bias_value=0.0))
+    w.layer("coverage/sig", "Sigmoid", ["cvg/classifier"], ["coverage"])
+    w.layer("bbox/regressor", "Convolution", ["dropout5"], ["bboxes"], _conv_body(4 * num_classes, 1, bias_value=0.0))
     return w.text()

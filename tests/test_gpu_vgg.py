@@ -205,3 +205,26 @@ def test_bounding_box_train_net_frozen_layers_and_adam(gpu):
         assert np.array_equal(after[name][0], params[name][0]), name
     assert not np.array_equal(after["conv4_1"][0], params["conv4_1"][0])
     eng.close()
+
+
+def test_bounding_box_deploy_pyramid_pooling_forward(gpu):
+    """train/bounding_box/deploy.prototxt at its native 448x448 (the pyramid pools are sized for a 56x56 conv4_3), batch 1:
+    AVE pooling to 1x1..7x7, 1x1 convolutions on 1-49 pixels, bilinear deconvolutions k56/s28 .. k8/s4, a copied Concat
+    (pool4 also feeds conv5_1), dropout as identity, sigmoid head."""
+    msg = proto.parse_text(models.vgg16_bounding_box_deploy(1, 448, 448, 3))
+    spec = NetSpec(msg, "TEST")
+    spec.infer()
+    params = fill_params(spec, seed=3)
+    eng = Engine(NetSpec(msg, "TEST"), params={k: [a.copy() for a in v] for k, v in params.items()}, device=0, autotune=False)
+    x = np.random.default_rng(2).random((1, 3, 448, 448), dtype=np.float32)
+    eng.host_array("data")[...] = x
+    out = eng.forward()
+    ref = RefNet(msg, "TEST", params)
+    ref.blobs["data"] = x
+    rb = ref.forward()
+    assert eng.shapes["conv4_3/conv5_3/concat"] == (1, 1536, 28, 28)
+    for name in ("pool4/1x1", "conv4_3/2x2", "conv4_3/4x4/upsample", "conv4_3/1x1/upsample", "conv5_3", "conv4_3/conv5_3/concat"):
+        assert rel_err(eng.read_blob(name), rb[name]) < 1e-3, name
+    for name in ("coverage", "bboxes"):
+        assert rel_err(out[name], rb[name]) < 1e-3, name
+    eng.close()

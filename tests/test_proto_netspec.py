@@ -157,6 +157,15 @@ def test_builder_equals_reference_models_train_val():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
+def test_builder_equals_reference_bounding_box_deploy():
+    a = _signature(proto.parse_file(os.path.join(REF, "train/bounding_box/deploy.prototxt")), "TEST")
+    b = _signature(proto.parse_text(models.vgg16_bounding_box_deploy()), "TEST")
+    assert a[0] == b[0] == {"data": (10, 3, 448, 448)} and len(a[1]) == len(b[1]) == 51
+    for x, y in zip(a[1], b[1]):
+        assert x == y
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not mounted (GPU box)")
 def test_all_reference_prototxts_parse():
     for rel in ("models/deploy.prototxt", "models/train_val.prototxt", "models/train_val2.prototxt",
                 "train/fcn_bbox/train_val.prototxt", "train/bounding_box/train_val.prototxt",
