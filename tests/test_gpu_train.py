@@ -126,7 +126,14 @@ def test_three_solver_steps_match_oracle(gpu, kind):
 def test_reference_lmdb_fronted_net_equals_python_layer_net(gpu):
     """models/train_val.prototxt as shipped (Data tops `data` / 17-channel `label`, Slice into the five label blobs) gives the
     same losses and weight gradients as the Python-layer form of the same net when the label record holds the same tensors."""
-    msg, spec, data, eng, ref, rsolver, rng = build(lr=0.0)
+    # both engines without autotuning: the same (heuristic) tile shapes, hence the same rounding, ReLU masks and pool argmaxes
+    msg = proto.parse_text(models.googlenet_detectnet_train("m", "L", "unused", num_classes=1))
+    data = make_batch(np.random.default_rng(42), 2, 96, 128)
+    pshapes = {k: v.shape for k, v in data.items()}
+    spec = NetSpec(msg, "TRAIN")
+    spec.infer(pshapes)
+    sp = SolverParams(base_lr=0.0, momentum=0.9, weight_decay=1e-7, lr_policy="fixed")
+    eng = TrainEngine(NetSpec(msg, "TRAIN"), pshapes, params=fill_params(spec, seed=1234), device=0, solver=sp, autotune=False)
     for k, v in data.items():
         eng.host_array(k)[...] = v
     want = eng.step(seed=3)
@@ -138,8 +145,7 @@ def test_reference_lmdb_fronted_net_equals_python_layer_net(gpu):
     shapes = {"data": data["data"].shape, "label": record.shape}
     lspec = NetSpec(lmsg, "TRAIN")
     lspec.infer(shapes)
-    sp = SolverParams(base_lr=0.0, momentum=0.9, weight_decay=1e-7, lr_policy="fixed")
-    leng = TrainEngine(NetSpec(lmsg, "TRAIN"), shapes, params=fill_params(lspec, seed=1234), device=0, solver=sp)
+    leng = TrainEngine(NetSpec(lmsg, "TRAIN"), shapes, params=fill_params(lspec, seed=1234), device=0, solver=sp, autotune=False)
     leng.host_array("data")[...] = data["data"]
     leng.host_array("label")[...] = record
     got = leng.step(seed=3)
