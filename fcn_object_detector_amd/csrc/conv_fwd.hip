@@ -514,6 +514,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
     const bool do_sig2 = (p.flags & FCN_CONV_SIGMOID2) != 0 && p.y2 != nullptr;
+    const bool do_mask = (p.flags & FCN_CONV_MASK) != 0 && p.y2 != nullptr;      // ReLU backward of the layer below (y2 = its activation)
     const bool do_accum = (p.flags & FCN_CONV_ACCUM) != 0;
     const bool out_f32 = (p.flags & FCN_CONV_OUT_F32) != 0;      // f16 inputs, f32 output blob (the detection heads)
     const bool out_f16 = (p.flags & FCN_CONV_OUT_F16) != 0;      // f32 inputs, f16 output blob (the first layer of an f16 net)
@@ -541,6 +542,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                         gf_ptr dst = (gf_ptr)(p.y + o);
                         if (do_accum) v += *dst;
                         if (do_relu) v = fmaxf(v, 0.f);
+                        if (do_mask) v = *(gf_ptr)(p.y2 + (size_t)m * p.y2_cstride + p.y2_coffset + n) > 0.f ? v : 0.f;
                         *dst = v;
                     }
                     if (do_sig2) *(gf_ptr)(p.y2 + (size_t)m * p.y2_cstride + p.y2_coffset + n) = 1.f / (1.f + expf(-v));
@@ -636,8 +638,10 @@ int validate(const fcn_conv_desc& d) {
     FCN_REQUIRE((long long)d.N * d.H * d.W * d.x_cstride < (1ll << 31) && (long long)d.Cout * d.kh * d.kw * d.Cin < (1ll << 31),
                 FCN_E_UNSUPPORTED, "conv: tensor too large for 32-bit element offsets");
     FCN_REQUIRE(d.in_shift == 0.f, FCN_E_UNSUPPORTED, "conv: in_shift is applied by the producer of the input (fcn_nchw_to_nhwc_f32 / fcn_preprocess_bgr8)");
-    if (d.flags & FCN_CONV_SIGMOID2)
-        FCN_REQUIRE(d.y2 && d.y2_cstride >= d.y2_coffset + d.Cout, FCN_E_ARG, "conv: FCN_CONV_SIGMOID2 needs y2");
+    if (d.flags & (FCN_CONV_SIGMOID2 | FCN_CONV_MASK))
+        FCN_REQUIRE(d.y2 && d.y2_cstride >= d.y2_coffset + d.Cout, FCN_E_ARG, "conv: FCN_CONV_SIGMOID2 / FCN_CONV_MASK need y2");
+    FCN_REQUIRE(!((d.flags & FCN_CONV_SIGMOID2) && (d.flags & FCN_CONV_MASK)), FCN_E_ARG, "conv: FCN_CONV_SIGMOID2 and FCN_CONV_MASK both use y2");
+    FCN_REQUIRE(!((d.flags & FCN_CONV_MASK) && (d.flags & FCN_CONV_F16)), FCN_E_UNSUPPORTED, "conv: FCN_CONV_MASK is a float32 (training) feature");
     FCN_REQUIRE((long long)d.N * d.OH * d.OW < (1ll << 31), FCN_E_UNSUPPORTED, "conv: problem too large for int32 indexing");
     return 0;
 }

@@ -158,8 +158,11 @@ class TrainEngine(Engine):
                 return "full"
             raise NotImplementedError("gradient of %s is partially written" % g.name)
 
-        def mark(g: Blob) -> None:
+        writers: Dict[str, List[object]] = {}      # gradient blob -> what wrote it, in order (a dgrad record or None)
+
+        def mark(g: Blob, writer: object = None) -> None:
             written.setdefault(g.buf.ptr, []).append((g.coffset, g.coffset + g.channels))
+            writers.setdefault(g.name, []).append(writer)
 
         ws_floats = 1
         ops: List[Op] = []
@@ -226,16 +229,39 @@ class TrainEngine(Engine):
             self._keep.append(dd)
             return dd, 2.0 * n * cout * oh * ow * cin * k * k
 
-        def emit_dgrads(name: str, items: List[Tuple[L.ConvDesc, float]]) -> None:
-            """One grouped launch (autotuned) for data-gradient passes that write different buffers."""
-            arr = (L.ConvDesc * len(items))(*[it[0] for it in items])
-            gws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(items))), zero=False)
-            grp = L.ConvGroup()
-            cfg = self._tuned_cfg("dgrad:" + name, arr, len(items), gws) if self.autotune else -1
-            L.call("fcn_conv2d_group_prepare", arr, len(items), gws.ptr, cfg, C.byref(grp))
-            self._keep.extend([arr, gws, grp])
-            ops.append(Op("dgrad", "%s [cfg%d %dwg]" % (name, grp.cfg, grp.total_tiles),
-                          lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), sum(it[1] for it in items)))
+        dgrad_records: List[dict] = []
+        relu_ops: Dict[str, Op] = {}       # gradient blob whose ReLU backward is the op (candidates for the fused mask)
+
+        def emit_dgrads(name: str, items: List[Tuple[L.ConvDesc, float]], targets: List[str]) -> dict:
+            """One grouped launch for data-gradient passes that write different buffers.  The group is prepared (and
+            autotuned) after the whole backward plan is known, because the LAST writer of a gradient may still get the ReLU
+            mask of the layer below folded into its epilogue (finish_dgrads)."""
+            rec = dict(name=name, descs=[it[0] for it in items], targets=list(targets), grp=L.ConvGroup())
+            rec["op"] = Op("dgrad", name, lambda st, g=rec["grp"]: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), sum(it[1] for it in items))
+            ops.append(rec["op"])
+            dgrad_records.append(rec)
+            return rec
+
+        def finish_dgrads() -> None:
+            # fold "ReLU backward of blob X" into the last data-gradient pass that writes dX, when that is what wrote it last
+            for x, rop in relu_ops.items():
+                w = writers.get(x, [])
+                rec = w[-1] if w else None
+                if not isinstance(rec, dict) or rop not in ops:
+                    continue
+                d = rec["descs"][rec["targets"].index(x)]
+                act = B[x]
+                d.y2, d.y2_cstride, d.y2_coffset = act.buf.ptr, act.cstride, act.coffset
+                d.flags |= L.CONV_MASK
+                ops.remove(rop)
+            for rec in dgrad_records:
+                n_ = len(rec["descs"])
+                arr = (L.ConvDesc * n_)(*rec["descs"])
+                gws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(n_)), zero=False)
+                cfg = self._tuned_cfg("dgrad:" + rec["name"], arr, n_, gws) if self.autotune else -1
+                L.call("fcn_conv2d_group_prepare", arr, n_, gws.ptr, cfg, C.byref(rec["grp"]))
+                self._keep.extend([arr, gws, rec["grp"]])
+                rec["op"].name = "%s [cfg%d %dwg]" % (rec["name"], rec["grp"].cfg, rec["grp"].total_tiles)
 
         def wgrad_item(l: Layer, gtop: Blob):
             """(descriptor with y = dY of the layer, dW view, db view or None, flops) of a layer that learns."""
@@ -325,13 +351,14 @@ class TrainEngine(Engine):
                         # every member of this Concat is a convolution with an in-place ReLU and the gradient of the whole
                         # concatenation is final: ONE contiguous launch masks all members (an inception module: 4 -> 1)
                         gw, yw = G[whole], B[whole]
-                        ops.append(Op("relu_bwd", whole, lambda st, g=gw, y=yw: L.check(lib.fcn_relu_bwd_f32(
-                            g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yw.pixels * yw.channels))
+                        relu_ops[whole] = Op("relu_bwd", whole, lambda st, g=gw, y=yw: L.check(lib.fcn_relu_bwd_f32(
+                            g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yw.pixels * yw.channels)
+                        ops.append(relu_ops[whole])
                         relu_done.update(concat_members[whole])
                         # the members' data gradients only need this masked gradient and write four different buffers (the
                         # module input and the outputs of the reduce / pool layers): one grouped launch at the top of the
                         # module's backward instead of four scattered ones
-                        items, names, targets = [], [], []
+                        items, names, targets, tnames = [], [], [], []
                         for m in concat_members[whole]:
                             lm = [q for q in self.producers.get(m, []) if q.type == "Convolution"][0]
                             gb = G.get(lm.bottoms[0])
@@ -340,11 +367,12 @@ class TrainEngine(Engine):
                             items.append(dgrad_desc(lm, G[m], gb, False))
                             names.append(lm.name)
                             targets.append(gb.buf.ptr)
+                            tnames.append(lm.bottoms[0])
                         if len(items) > 1:
-                            emit_dgrads("+".join(names), items)
-                            for nm in names:
+                            rec = emit_dgrads("+".join(names), items, tnames)
+                            for nm, tn in zip(names, tnames):
                                 dgrad_done.add(nm)
-                                mark(G[[q for q in spec.layers if q.name == nm][0].bottoms[0]])
+                                mark(G[tn], rec)
                         # ... and their weight gradients need nothing else either: one grouped launch
                         mem_layers = [[q for q in self.producers.get(m, []) if q.type == "Convolution"][0] for m in concat_members[whole]]
                         emit_wgrads(mem_layers, [G[m] for m in concat_members[whole]])
@@ -362,8 +390,11 @@ class TrainEngine(Engine):
                             for q in sibs:
                                 sibling_reduces[q.name] = sibs
                     else:
-                        ops.append(Op("relu_bwd", l.name, lambda st, g=gtop, y=yb: L.check(lib.fcn_relu_bwd_f32(
-                            g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yb.pixels * cout))
+                        rop = Op("relu_bwd", l.name, lambda st, g=gtop, y=yb: L.check(lib.fcn_relu_bwd_f32(
+                            g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yb.pixels * cout)
+                        ops.append(rop)
+                        if l.tops[0] not in self.alias:
+                            relu_ops[l.tops[0]] = rop
                         relu_done.add(l.tops[0])
                 sibs = sibling_reduces.get(l.name)
                 if sibs and l.name not in wgrad_done and all(state(G[q.tops[0]]) == "full" for q in sibs):
@@ -371,15 +402,16 @@ class TrainEngine(Engine):
                     for q in sibs:
                         if q.tops[0] not in relu_done and self._conv_layer_meta[q.name].get("relu"):
                             gq, yq = G[q.tops[0]], B[q.tops[0]]
-                            ops.append(Op("relu_bwd", q.name, lambda st, g=gq, y=yq: L.check(lib.fcn_relu_bwd_f32(
-                                g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yq.pixels * yq.channels))
+                            relu_ops[q.tops[0]] = Op("relu_bwd", q.name, lambda st, g=gq, y=yq: L.check(lib.fcn_relu_bwd_f32(
+                                g.ptr, y.ptr, g.ptr, y.pixels, y.channels, y.cstride, st)), 0.0, 12.0 * yq.pixels * yq.channels)
+                            ops.append(relu_ops[q.tops[0]])
                             relu_done.add(q.tops[0])
                     emit_wgrads(sibs, [G[q.tops[0]] for q in sibs])
                 emit_wgrads([l], [gtop])
                 gbot = G.get(l.bottoms[0])
                 if gbot is not None and l.name not in dgrad_done:
-                    emit_dgrads(l.name, [dgrad_desc(l, gtop, gbot, state(gbot) == "full")])
-                    mark(gbot)
+                    rec = emit_dgrads(l.name, [dgrad_desc(l, gtop, gbot, state(gbot) == "full")], [l.bottoms[0]])
+                    mark(gbot, rec)
                 continue
             if t == "Eltwise" and str(l.sub("eltwise_param").get("operation", "SUM")) == "SUM":
                 p = l.sub("eltwise_param")
@@ -473,6 +505,7 @@ class TrainEngine(Engine):
             else:
                 raise NotImplementedError("backward of layer type %s (%s)" % (t, l.name))
             mark(gbot)
+        finish_dgrads()
         self._ws = DeviceBuffer(ws_floats * 4, zero=False)
         self.bwd_ops = ops
         self._plan_buckets()

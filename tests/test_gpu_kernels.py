@@ -103,6 +103,36 @@ def test_conv_sigmoid_second_output(gpu):
     assert rel_err(y, ref) < TOL and np.abs(y2 - R.sigmoid(ref)).max() < 1e-5
 
 
+@pytest.mark.parametrize("cfg", ["0", "5", "14", None])
+def test_conv_epilogue_relu_mask(gpu, monkeypatch, cfg):
+    """FCN_CONV_MASK: the result is zeroed where a second tensor (the activation of the layer below, a channel slice of a
+    wider buffer) is not positive -- the ReLU backward folded into the data-gradient pass that writes the gradient last."""
+    if cfg is None:
+        monkeypatch.delenv("FCN_CONV_CFG", raising=False)
+    else:
+        monkeypatch.setenv("FCN_CONV_CFG", cfg)
+    rng = np.random.default_rng(12)
+    n, cin, cout, h, w = 2, 48, 40, 13, 9
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * 0.05).astype(np.float32)
+    act = np.maximum(rng.standard_normal((n, cout, h, w)), 0).astype(np.float32)       # about half exactly zero
+    act_wide = np.full((n, h, w, 72), 5.0, np.float32)
+    act_wide[..., 16:16 + cout] = act.transpose(0, 2, 3, 1)
+    xd, wd, ad = dev_from(nhwc(x)), dev_from(pack_ohwi(wt)), dev_from(act_wide)
+    yd = dev_from(np.full((n, h, w, cout), -7.0, np.float32))
+    d = conv_desc(xd, wd, None, yd, n, h, w, cin, cin, cout, 3, 1, 1, h, w, cout, 0, L.CONV_MASK, 0.0, ad, 72, 16)
+    L.call("fcn_conv2d_fwd_f32", C.byref(d), None)
+    y = nchw(dev_to(yd, (n, h, w, cout)), cout)
+    ref = R.conv2d(x, wt, None, 1, 1) * (act > 0)
+    assert rel_err(y, ref) < TOL
+    assert np.all(y[act <= 0] == 0.0)
+    # mask and the second sigmoid output share the y2 slot: asking for both is refused
+    d.flags = L.CONV_MASK | L.CONV_SIGMOID2
+    assert L.load().fcn_conv2d_fwd_f32(C.byref(d), None) != 0
+    d.flags, d.y2 = L.CONV_MASK, None
+    assert L.load().fcn_conv2d_fwd_f32(C.byref(d), None) != 0
+
+
 def test_conv_group_launch(gpu):
     """Four independent problems (an inception module's branch entries) in one launch."""
     rng = np.random.default_rng(8)
