@@ -59,10 +59,13 @@ __device__ __forceinline__ void unflip(int flip, int H, int W, int& x, int& y) {
 __global__ __launch_bounds__(256) void compose_scene_kernel(const unsigned char* __restrict__ bg, int bg_h, int bg_w, int crop_x, int crop_y,
                                                             int crop_w, int crop_h, const fcn_scene_obj* __restrict__ objs, int nobj,
                                                             int final_flip, unsigned char* __restrict__ out_img,
-                                                            unsigned char* __restrict__ out_mask, int H, int W) {
-    const int total = H * W;
+                                                            unsigned char* __restrict__ out_mask, int H, int W, int vx, int vy,
+                                                            int VH, int VW) {
+    // the output is the VH x VW window at (vx, vy) of the (flipped) H x W scene: the zoom crop of random_argumentation is a
+    // change of origin for a gather kernel, not a copy
+    const int total = VH * VW;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int Y = t / W, X = t - Y * W;
+        const int Y = t / VW + vy, X = t - (t / VW) * VW + vx;
         int x = X, y = Y;                       // position in the scene BEFORE the whole-image flip
         if (final_flip >= -1 && final_flip <= 1) unflip(final_flip, H, W, x, y);
         // background: bilinear resize of the crop to H x W
@@ -97,9 +100,11 @@ __global__ __launch_bounds__(256) void compose_scene_kernel(const unsigned char*
                                     (float)q.img[off[1][1] * 3 + c], ox.f, oy.f));
             lab = (unsigned char)q.label1;
         }
-        out_img[(size_t)t * 3 + 0] = px[0];
-        out_img[(size_t)t * 3 + 1] = px[1];
-        out_img[(size_t)t * 3 + 2] = px[2];
+        if (out_img) {
+            out_img[(size_t)t * 3 + 0] = px[0];
+            out_img[(size_t)t * 3 + 1] = px[1];
+            out_img[(size_t)t * 3 + 2] = px[2];
+        }
         if (out_mask) out_mask[t] = lab;
     }
 }
@@ -121,16 +126,27 @@ __global__ __launch_bounds__(256) void mask_to_label_kernel(const unsigned char*
 
 extern "C" {
 
-int fcn_compose_scene_bgr8(const uint8_t* bg, int bg_h, int bg_w, int crop_x, int crop_y, int crop_w, int crop_h, const fcn_scene_obj* d_objs,
-                           int nobj, int final_flip, uint8_t* out_img, uint8_t* out_mask, int H, int W, fcn_stream_t s) {
-    FCN_REQUIRE(bg && out_img && bg_h > 0 && bg_w > 0 && H > 0 && W > 0 && nobj >= 0 && (nobj == 0 || d_objs), FCN_E_ARG, "compose_scene: bad args");
+int fcn_compose_scene_view_bgr8(const uint8_t* bg, int bg_h, int bg_w, int crop_x, int crop_y, int crop_w, int crop_h, const fcn_scene_obj* d_objs,
+                                int nobj, int final_flip, uint8_t* out_img, uint8_t* out_mask, int H, int W, int view_x, int view_y, int view_w,
+                                int view_h, fcn_stream_t s) {
+    FCN_REQUIRE(bg && (out_img || out_mask) && bg_h > 0 && bg_w > 0 && H > 0 && W > 0 && nobj >= 0 && (nobj == 0 || d_objs), FCN_E_ARG,
+                "compose_scene: bad args");
+    FCN_REQUIRE(view_x >= 0 && view_y >= 0 && view_w > 0 && view_h > 0 && view_x + view_w <= W && view_y + view_h <= H, FCN_E_ARG,
+                "compose_scene: view (%d,%d,%d,%d) outside the %dx%d scene", view_x, view_y, view_w, view_h, W, H);
     FCN_REQUIRE(crop_x >= 0 && crop_y >= 0 && crop_w > 0 && crop_h > 0 && crop_x + crop_w <= bg_w && crop_y + crop_h <= bg_h, FCN_E_ARG,
                 "compose_scene: background crop (%d,%d,%d,%d) outside the %dx%d image", crop_x, crop_y, crop_w, crop_h, bg_w, bg_h);
     FCN_REQUIRE((long long)H * W < (1ll << 30), FCN_E_UNSUPPORTED, "compose_scene: scene too large");
-    hipLaunchKernelGGL(compose_scene_kernel, dim3(stream_grid((long long)H * W, 256)), dim3(256), 0, as_stream(s), bg, bg_h, bg_w, crop_x, crop_y,
-                       crop_w, crop_h, d_objs, nobj, final_flip, out_img, out_mask, H, W);
+    hipLaunchKernelGGL(compose_scene_kernel, dim3(stream_grid((long long)view_h * view_w, 256)), dim3(256), 0, as_stream(s), bg, bg_h, bg_w,
+                       crop_x, crop_y, crop_w, crop_h, d_objs, nobj, final_flip, out_img, out_mask, H, W, view_x, view_y, view_h, view_w);
     FCN_LAUNCH_CHECK("compose_scene");
     return 0;
+}
+
+int fcn_compose_scene_bgr8(const uint8_t* bg, int bg_h, int bg_w, int crop_x, int crop_y, int crop_w, int crop_h, const fcn_scene_obj* d_objs,
+                           int nobj, int final_flip, uint8_t* out_img, uint8_t* out_mask, int H, int W, fcn_stream_t s) {
+    FCN_REQUIRE(out_img, FCN_E_ARG, "compose_scene: bad args");
+    return fcn_compose_scene_view_bgr8(bg, bg_h, bg_w, crop_x, crop_y, crop_w, crop_h, d_objs, nobj, final_flip, out_img, out_mask, H, W, 0, 0, W,
+                                       H, s);
 }
 
 int fcn_mask_to_label_f32(const uint8_t* mask, int h, int w, float* dst, int H, int W, int dst_cstride, fcn_stream_t s) {

@@ -7,7 +7,9 @@ same ``param_str`` (``W,H,stride,num_classes,batch,train.txt``), same dataset-fi
 label tensors come from ``fcn_gen_targets`` (HIP), not from interpreted loops.
 
 Differences that are deliberate and documented:
-  * ``imgaug`` colour augmentation (argumentation_engine.py:308-322) is not available offline and is skipped;
+  * ``imgaug`` (argumentation_engine.py:308-322; an un-pinned, un-vendored submodule) is not available offline: its colour
+    sequence is restated from the library's documented operators (plan_color below; pixel work in csrc/augment.hip) with
+    this layer's own numpy generator for the parameter draws, so the images are statistically, not bitwise, those of imgaug;
   * the reference reads a hard-coded background JPEG (data_argumentation_layer.py:86); here the background is the
     ``FCN_BACKGROUND`` image if set, else seeded noise;
   * ``train.txt`` may be the keyword ``synthetic[:N]`` — N procedurally textured objects instead of image files
@@ -64,6 +66,84 @@ def flip_rects(im_hw: Sequence[int], rects: Sequence[Sequence[int]], flip_flag: 
         x, y = min(p1[0], p2[0]), min(p1[1], p2[1])
         out.append([max(int(x), 0), max(int(y), 0), int(abs(p2[0] - p1[0])), int(abs(p2[1] - p1[1]))])
     return out
+
+
+def plan_zoom(im_hw: Sequence[int], rect: Sequence[int], rect_flip: Sequence[int]):
+    """The "zoom in" of random_argumentation (argumentation_engine.py:156-172) and crop_image_dimension (:190-236) for a
+    scene that holds ONE box: the random draws (``random`` module, reference order) and the integer crop window.
+
+    Returns (window (x, y, w, h) inside the image, new rect) or None when the reference's arithmetic leaves no pixels
+    (the reference would fail inside cv.resize; here the sample keeps the uncropped scene).  Python-2 ``/`` on ints is
+    floor division (`rect[2]/2`), kept as `//`."""
+    H, W = int(im_hw[0]), int(im_hw[1])
+    if rect[2] <= 0 or rect[3] <= 0:
+        return None
+    scale_x = int(math.floor(np.float32(W) / np.float32(rect[2])))
+    scale_y = int(math.floor(np.float32(H) / np.float32(rect[3])))
+    e1 = random.uniform(1.0, float(np.float32(scale_x / 1.0)))
+    e2 = random.uniform(1.0, float(np.float32(scale_y / 1.0)))
+    rx, ry, rw, rh = (int(v) for v in rect_flip)
+    widths = (int(rw * e1), rw * e2)
+    heights = (int(rh * e1), rh * e2)                     # sic: the first factor again (:167)
+    x = (rx + rw // 2) - widths[0]
+    y = (ry + rh // 2) - heights[0]
+    w = widths[1] + widths[0]
+    h = heights[1] + heights[0]
+    cx, cy = rx + rw / 2.0, ry + rh / 2.0
+    shift_x, shift_y = random.randint(0, int(w / 2)), random.randint(0, int(h / 2))
+    cx = (cx + shift_x) if random.randint(0, 1) else (cx - shift_x)
+    cy = (cy + shift_y) if random.randint(0, 1) else (cy - shift_y)
+    nx, ny, nw, nh = int(cx - (w / 2)), int(cy - (h / 2)), int(w), int(h)
+    if nx > x:
+        nx = x                                            # (the width correction that follows in the reference subtracts |nx - x| = 0)
+    if ny > y:
+        ny = y
+    if nx + nw < x + w:
+        nx += (x + w) - (nx + nw)
+    if ny + nh < y + h:
+        ny += (y + h) - (ny + nh)
+    x, y, w, h = nx, ny, nw, nh
+    x = 0 if x < 0 else x
+    y = 0 if y < 0 else y
+    if x > W or y > H:
+        return None                                       # the reference's negative-extent branch: an empty crop
+    x0, y0 = int(x), int(y)
+    x1, y1 = min(int(x + w), W), min(int(y + h), H)       # numpy slicing clips to the image
+    if x1 <= x0 or y1 <= y0 or int(x + w) < 0 or int(y + h) < 0:
+        return None
+    return (x0, y0, x1 - x0, y1 - y0), [int(rx - x), int(ry - y), rw, rh]
+
+
+def plan_color(rng: np.random.Generator) -> dict:
+    """Parameter draws of color_space_argumentation (argumentation_engine.py:308-322): OneOf(GaussianBlur sigma (0, 3),
+    AverageBlur k (2, 7), MedianBlur k (3, 7)) -> Sharpen(alpha (0, 1), lightness (0.75, 1.5)) -> Add((-2, 21), per_channel
+    0.5) -> Multiply((0.75, 1.25), per_channel 0.5) -> Grayscale(alpha (0, 0.5)), in this order."""
+    kind = ("gauss", "box", "median")[int(rng.integers(0, 3))]
+    blur = dict(kind=kind)
+    if kind == "gauss":
+        blur["sigma"] = float(rng.uniform(0.0, 3.0))
+    elif kind == "box":
+        blur["k"] = int(rng.integers(2, 8))
+    else:
+        k = int(rng.integers(3, 8))
+        blur["k"] = k - 1 if k % 2 == 0 else k            # imgaug: even median kernels are made odd by subtracting one
+    sharpen = (float(rng.uniform(0.0, 1.0)), float(rng.uniform(0.75, 1.5)))
+    add = [int(v) for v in rng.integers(-2, 22, 3)] if rng.random() < 0.5 else [int(rng.integers(-2, 22))] * 3
+    mul = [float(v) for v in rng.uniform(0.75, 1.25, 3)] if rng.random() < 0.5 else [float(rng.uniform(0.75, 1.25))] * 3
+    return dict(blur=blur, sharpen=sharpen, add=add, mul=mul, gray=float(rng.uniform(0.0, 0.5)))
+
+
+def gauss_taps(sigma: float) -> np.ndarray:
+    """Half of the symmetric Gaussian kernel (centre first), float32, normalised in float64; radius ceil(3.3 sigma)
+    (3.3 sigma is where imgaug's cv2 path cuts the kernel for sigma below 3)."""
+    r = max(int(math.ceil(3.3 * sigma)), 1)
+    x = np.arange(0, r + 1, dtype=np.float64)
+    w = np.exp(-0.5 * x * x / (sigma * sigma))
+    w /= w[0] + 2.0 * w[1:].sum()
+    return w.astype(np.float32)
+
+
+GAUSS_MIN_SIGMA = 0.001       # imgaug skips the blur below this
 
 
 # ----------------------------------------------------------------------------
@@ -175,6 +255,9 @@ class DataArgumentationLayer(Layer):
             bg = np.random.default_rng(1234).integers(0, 256, (960, 1280, 3), dtype=np.uint8)
         self.background = bg
         self._sources = {}
+        self.zoom_augmentation = os.environ.get("FCN_DATA_ZOOM", "1") != "0"     # random_argumentation's is_crop (:156)
+        self.color_augmentation = os.environ.get("FCN_DATA_COLOR", "1") != "0"
+        self._color_rng = np.random.default_rng(int(os.environ["FCN_DATA_SEED"]) + 1 if "FCN_DATA_SEED" in os.environ else None)
         if self.randomize:
             random.seed(int(os.environ["FCN_DATA_SEED"])) if "FCN_DATA_SEED" in os.environ else random.seed()
 
@@ -275,12 +358,20 @@ class DataArgumentationLayer(Layer):
             labels.append(label)
         rects = [tuple(int(v) for v in r) for r in placed]
         final_flip = random.randint(-1, 2)                        # random_argumentation (argumentation_engine.py:143-188)
+        unflipped = rects
         if -2 < final_flip < 2 and rects:
             rects = [tuple(r) for r in flip_rects((im_y, im_x), rects, final_flip)]
         else:
             final_flip = 2
-        rects = resize_rects((im_y, im_x), (self.image_size_x, self.image_size_y), rects)
-        return dict(bg_crop=(bx, by, ww, hh), objects=objs, final_flip=final_flip, rects=rects, labels=labels)
+        view = None                                               # the zoom crops the IMAGE; the class mask stays whole (:148-172)
+        if self.zoom_augmentation and len(rects) == 1:
+            z = plan_zoom((im_y, im_x), unflipped[0], rects[0])
+            if z is not None:
+                view, rects = z[0], [tuple(z[1])]
+        color = plan_color(self._color_rng) if self.color_augmentation else None
+        src_hw = (view[3], view[2]) if view else (im_y, im_x)
+        rects = resize_rects(src_hw, (self.image_size_x, self.image_size_y), rects)
+        return dict(bg_crop=(bx, by, ww, hh), objects=objs, final_flip=final_flip, view=view, color=color, rects=rects, labels=labels)
 
     def bind_device(self, engine, top_names: Sequence[str]) -> None:
         """Called by the solver: from now on forward() renders `data` (and the class mask of HEAD's mode) straight into the
@@ -337,6 +428,10 @@ class DeviceRenderer(object):
         self.recs_host = [(L.SceneObj * 4)() for _ in range(n)]
         self.recs_dev = [DeviceBuffer(C.sizeof(L.SceneObj) * 4, zero=True) for _ in range(n)]
         self.minmax = DeviceBuffer(64, zero=True)
+        self.aug_a = [DeviceBuffer(h * w * 3, zero=False) for _ in range(n)]       # colour augmentation ping-pong buffers
+        self.aug_b = [DeviceBuffer(h * w * 3, zero=False) for _ in range(n)]
+        self.aug_f32 = DeviceBuffer(h * w * 3 * 4, zero=False)                    # Gaussian blur: row pass result (stream ordered)
+        self.final = [None] * n
 
     def _upload(self, arr: np.ndarray):
         a = np.ascontiguousarray(arr)
@@ -365,23 +460,60 @@ class DeviceRenderer(object):
             L.call("fcn_memcpy_h2d_async", self.recs_dev[index].ptr, C.addressof(recs), C.sizeof(L.SceneObj) * len(objs), st)
         bx, by, ww, hh = plan["bg_crop"]
         bgh, bgw = lay.background.shape[:2]
-        L.call("fcn_compose_scene_bgr8", self.bg.ptr, bgh, bgw, bx, by, ww, hh, self.recs_dev[index].ptr, len(objs), plan["final_flip"],
-               self.scene[index].ptr, self.mask[index].ptr, lay.SCENE_H, lay.SCENE_W, st)
+        SH, SW = lay.SCENE_H, lay.SCENE_W
+        view = plan.get("view")
+        vx, vy, vw, vh = view if view else (0, 0, SW, SH)
+        compose = [self.bg.ptr, bgh, bgw, bx, by, ww, hh, self.recs_dev[index].ptr, len(objs), plan["final_flip"]]
+        if view:            # the zoom crops the image only: the class mask is rendered whole by a second, mask-only launch
+            L.call("fcn_compose_scene_view_bgr8", *compose, self.scene[index].ptr, None, SH, SW, vx, vy, vw, vh, st)
+            if self.label is not None:
+                L.call("fcn_compose_scene_view_bgr8", *compose, None, self.mask[index].ptr, SH, SW, 0, 0, SW, SH, st)
+        else:
+            L.call("fcn_compose_scene_view_bgr8", *compose, self.scene[index].ptr, self.mask[index].ptr if self.label is not None else None,
+                   SH, SW, 0, 0, SW, SH, st)
+        img = self.scene[index]
+        if plan.get("color"):
+            img = self._color(index, img, vh, vw, plan["color"], st)
+        self.final[index] = (img, vh, vw)
         d = self.data
         n, c, H, W = d.shape
-        L.call("fcn_preprocess_bgr8", self.scene[index].ptr, lay.SCENE_H, lay.SCENE_W, d.ptr + 4 * index * H * W * d.cstride, H, W, d.cstride,
+        L.call("fcn_preprocess_bgr8", img.ptr, vh, vw, d.ptr + 4 * index * H * W * d.cstride, H, W, d.cstride,
                float(getattr(d, "upload_shift", 0.0) or 0.0), self.minmax.ptr, st)
         if self.label is not None:
             lb = self.label
-            L.call("fcn_mask_to_label_f32", self.mask[index].ptr, lay.SCENE_H, lay.SCENE_W, lb.ptr + 4 * index * H * W * lb.cstride, H, W,
-                   lb.cstride, st)
+            L.call("fcn_mask_to_label_f32", self.mask[index].ptr, SH, SW, lb.ptr + 4 * index * H * W * lb.cstride, H, W, lb.cstride, st)
+
+    def _color(self, index: int, img, h: int, w: int, color: dict, st):
+        """color_space_argumentation on the device: blur (one of three) then the fused Sharpen/Add/Multiply/Grayscale pass;
+        the image ping-pongs between the slot's two scratch buffers.  Returns the buffer holding the result."""
+        L, C = self.L, self.C
+        a, b2 = self.aug_a[index], self.aug_b[index]
+        blur = color["blur"]
+        if blur["kind"] == "gauss":
+            if blur["sigma"] >= GAUSS_MIN_SIGMA:
+                taps = gauss_taps(blur["sigma"])
+                L.call("fcn_blur_gauss_bgr8", img.ptr, a.ptr, self.aug_f32.ptr, h, w, taps.ctypes.data, len(taps) - 1, st)
+                img = a
+        elif blur["kind"] == "box":
+            L.call("fcn_blur_box_bgr8", img.ptr, a.ptr, h, w, blur["k"], st)
+            img = a
+        else:
+            L.call("fcn_blur_median_bgr8", img.ptr, a.ptr, h, w, blur["k"], st)
+            img = a
+        al, light = color["sharpen"]
+        ga = np.float32(color["gray"])
+        q = L.ColorParams(float(np.float32((1.0 - al) + al * (8.0 + light))), float(np.float32(-al)), (C.c_int32 * 3)(*color["add"]),
+                          (C.c_float * 3)(*[float(np.float32(m)) for m in color["mul"]]), float(ga), float(np.float32(1.0) - ga))
+        L.call("fcn_color_augment_bgr8", img.ptr, b2.ptr, h, w, C.byref(q), st)
+        return b2
 
     def read_scene(self, index: int):
-        """Host copies of the composed uint8 scene and class mask of batch slot `index` (tests)."""
+        """Host copies of the final uint8 image (zoom window, colour augmented) and the class mask of batch slot `index` (tests)."""
         lay = self.layer
-        img = np.empty((lay.SCENE_H, lay.SCENE_W, 3), np.uint8)
+        buf, h, w = self.final[index]
+        img = np.empty((h, w, 3), np.uint8)
         msk = np.empty((lay.SCENE_H, lay.SCENE_W), np.uint8)
-        self.L.call("fcn_memcpy_d2h_async", img.ctypes.data, self.scene[index].ptr, img.nbytes, self.engine.stream)
+        self.L.call("fcn_memcpy_d2h_async", img.ctypes.data, buf.ptr, img.nbytes, self.engine.stream)
         self.L.call("fcn_memcpy_d2h_async", msk.ctypes.data, self.mask[index].ptr, msk.nbytes, self.engine.stream)
         self.L.call("fcn_stream_sync", self.engine.stream)
         return img, msk

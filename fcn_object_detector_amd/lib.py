@@ -53,6 +53,14 @@ class SceneObj(C.Structure):
         "src_h", "src_w", "flip", "roi_x", "roi_y", "roi_w", "roi_h", "out_w", "out_h", "cx", "cy", "label1")]
 
 
+class ColorParams(C.Structure):
+    _fields_ = [("sharpen_centre", C.c_float), ("sharpen_off", C.c_float), ("add", C.c_int32 * 3), ("mul", C.c_float * 3),
+                ("gray_alpha", C.c_float), ("gray_keep", C.c_float)]
+
+
+GAUSS_MAX_RADIUS = 15
+
+
 class FlipSeg(C.Structure):
     _fields_ = [("w_offset", C.c_uint64), ("wt_offset", C.c_uint64), ("Cout", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("Cin", C.c_int32), ("Cin4", C.c_int32), ("Cout4", C.c_int32)]
@@ -136,6 +144,11 @@ PROTOTYPES = {
     "fcn_preprocess_bgr8_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp]),
     "fcn_compose_scene_bgr8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
     "fcn_mask_to_label_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "fcn_compose_scene_view_bgr8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_blur_gauss_bgr8": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
+    "fcn_blur_box_bgr8": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "fcn_blur_median_bgr8": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "fcn_color_augment_bgr8": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "fcn_softmax_fwd_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "fcn_softmax_loss_workspace_bytes": (_sz, []),
     "fcn_softmax_loss_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _vp]),

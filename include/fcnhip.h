@@ -217,6 +217,37 @@ typedef struct fcn_scene_obj {
 int  fcn_compose_scene_bgr8(const uint8_t* bg, int bg_h, int bg_w, int crop_x, int crop_y, int crop_w, int crop_h,
                             const fcn_scene_obj* d_objs, int nobj, int final_flip, uint8_t* out_img, uint8_t* out_mask,
                             int H, int W, fcn_stream_t s);
+/* The same scene seen through the window (view_x, view_y, view_w, view_h) of the flipped H x W scene: out_img is
+ * view_h x view_w x 3, out_mask view_h x view_w; either may be NULL.  This is the "zoom in" crop of random_argumentation
+ * (argumentation_engine.py:156-172, crop_image_dimension :190-236), which crops the image but not the class mask. */
+int  fcn_compose_scene_view_bgr8(const uint8_t* bg, int bg_h, int bg_w, int crop_x, int crop_y, int crop_w, int crop_h,
+                                 const fcn_scene_obj* d_objs, int nobj, int final_flip, uint8_t* out_img, uint8_t* out_mask,
+                                 int H, int W, int view_x, int view_y, int view_w, int view_h, fcn_stream_t s);
+
+/* ---- colour augmentation of a composed scene: color_space_argumentation (argumentation_engine.py:308-322), an
+ *      imgaug Sequential restated from the operators' documented definitions (imgaug itself is an un-vendored submodule).
+ *      All images are h x w x 3 uint8, every stage rounds half-to-even and saturates to uint8 like the library's
+ *      uint8 pipeline.  src and dst must not alias. ---- */
+#define FCN_GAUSS_MAX_RADIUS 15
+/* GaussianBlur: separable, half-kernel taps[0..radius] (centre first, float32, normalised by the caller), reflect-101
+ * border; tmp: h*w*3 floats of scratch */
+int  fcn_blur_gauss_bgr8(const uint8_t* src, uint8_t* dst, float* tmp, int h, int w, const float* h_taps, int radius, fcn_stream_t s);
+/* AverageBlur (cv2.blur): k x k box, anchor k/2, reflect-101 border, round(sum * (1.0 / k^2)) in double; 1 <= k <= 15 */
+int  fcn_blur_box_bgr8(const uint8_t* src, uint8_t* dst, int h, int w, int k, fcn_stream_t s);
+/* MedianBlur (cv2.medianBlur): per-channel median of the k x k window, replicated border; k in {3, 5, 7} */
+int  fcn_blur_median_bgr8(const uint8_t* src, uint8_t* dst, int h, int w, int k, fcn_stream_t s);
+typedef struct fcn_color_params {
+    float sharpen_centre;  /* (1 - a) + a * (8 + lightness): centre of the 3x3 Sharpen matrix            */
+    float sharpen_off;     /* -a: its eight other entries (reflect-101 border)                           */
+    int32_t add[3];        /* Add: per-channel integer offsets                                           */
+    float mul[3];          /* Multiply: per-channel factors                                              */
+    float gray_alpha;      /* Grayscale: out = gray_keep * v + gray_alpha * grey                         */
+    float gray_keep;       /* 1 - gray_alpha, rounded to float32 by the caller                           */
+} fcn_color_params;
+/* Sharpen -> Add -> Multiply -> Grayscale in one pass.  grey = (4899 c0 + 9617 c1 + 1868 c2 + 8192) >> 14: OpenCV's
+ * RGB2GRAY fixed point applied to the channels in storage order, as imgaug does to the reference's BGR image. */
+int  fcn_color_augment_bgr8(const uint8_t* src, uint8_t* dst, int h, int w, const fcn_color_params* h_params, fcn_stream_t s);
+
 /* class mask (h x w uint8) -> H x W label blob, one float per pixel at stride dst_cstride (nearest neighbour: top[1] of
  * the data layer in HEAD's mask mode, data_argumentation_layer.py:113-121) */
 int  fcn_mask_to_label_f32(const uint8_t* mask, int h, int w, float* dst, int H, int W, int dst_cstride, fcn_stream_t s);

@@ -39,22 +39,69 @@ def make(mode, n=3, W=160, H=96, classes=4, objects=3):
 def test_device_scene_equals_host_scene_bit_for_bit(gpu):
     lay, eng, _ = make("mask")
     random.seed(2024)
-    seen_flip, seen_scale, seen_clip = set(), 0, 0
-    for it in range(40):
+    lay._color_rng = np.random.default_rng(2024)
+    seen_flip, seen_scale, seen_clip, seen_zoom, seen_blur = set(), 0, 0, 0, set()
+    for it in range(60):
         plan = lay.plan_scene()
         lay._renderer.render(it % 3, plan)
         img_d, msk_d = lay._renderer.read_scene(it % 3)
         img_h, msk_h = S.render_scene(lay, plan)
-        assert np.array_equal(img_d, img_h), it
+        assert img_d.shape == img_h.shape
+        assert np.array_equal(img_d, img_h), (it, plan["view"], plan["color"])
         assert np.array_equal(msk_d, msk_h), it
         seen_flip.add(plan["final_flip"])
+        seen_zoom += plan["view"] is not None
+        seen_blur.add(plan["color"]["blur"]["kind"])
         for o in plan["objects"]:
             seen_flip.add(("obj", o["flip"]))
             seen_scale += o["out"] != o["roi"][2:]
             seen_clip += o["pos"][0] < 0 or o["pos"][1] < 0 or o["pos"][0] + o["out"][0] > 640 or o["pos"][1] + o["out"][1] > 480
         assert set(np.unique(msk_h)) <= {0, 1, 2, 3}
     assert {("obj", -1), ("obj", 0), ("obj", 1), ("obj", 2)} <= seen_flip and seen_scale > 5      # the cases were really exercised
+    assert seen_zoom >= 5 and seen_blur == {"gauss", "box", "median"}
     eng.close()
+
+
+def _dev_image_op(name, img, *args):
+    import ctypes as C
+    from fcn_object_detector_amd import lib as L
+    from gpu_util import dev_from, dev_to
+    src, dst = dev_from(img), dev_from(np.zeros_like(img))
+    L.call(name, src.ptr, dst.ptr, *args, None)
+    return dev_to(dst, img.shape, np.uint8)
+
+
+@pytest.mark.parametrize("hw", [(1, 1), (2, 9), (7, 5), (33, 41), (96, 130)])
+def test_colour_kernels_match_oracle(gpu, hw):
+    """Each operator of the restated imgaug sequence on its own, bit for bit, down to images smaller than the kernels
+    (the reflect-101 border then folds more than once)."""
+    import ctypes as C
+    from fcn_object_detector_amd import lib as L
+    from gpu_util import dev_from
+    h, w = hw
+    rng = np.random.default_rng(h * 100 + w)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    tmp = dev_from(np.zeros((h, w, 3), np.float32))
+    for sigma in (0.05, 0.7, 1.9, 3.0):
+        taps = D.gauss_taps(sigma)
+        got = _dev_image_op("fcn_blur_gauss_bgr8", img, tmp.ptr, h, w, taps.ctypes.data, len(taps) - 1)
+        assert np.array_equal(got, S.blur_gauss(img, taps)), sigma
+    for k in range(1, 9):
+        assert np.array_equal(_dev_image_op("fcn_blur_box_bgr8", img, h, w, k), S.blur_box(img, k)), k
+    for k in (3, 5, 7):
+        assert np.array_equal(_dev_image_op("fcn_blur_median_bgr8", img, h, w, k), S.blur_median(img, k)), k
+    for _ in range(6):
+        c = D.plan_color(rng)
+        al, light = c["sharpen"]
+        ga = np.float32(c["gray"])
+        q = L.ColorParams(float(np.float32((1.0 - al) + al * (8.0 + light))), float(np.float32(-al)), (C.c_int32 * 3)(*c["add"]),
+                          (C.c_float * 3)(*c["mul"]), float(ga), float(np.float32(1.0) - ga))
+        got = _dev_image_op("fcn_color_augment_bgr8", img, h, w, C.byref(q))
+        assert np.array_equal(got, S.color_point_ops(img, c["sharpen"], c["add"], c["mul"], c["gray"]))
+    lib = L.load()
+    src = dev_from(img)
+    assert lib.fcn_blur_median_bgr8(src.ptr, tmp.ptr, h, w, 4, None) != 0 and lib.fcn_blur_box_bgr8(src.ptr, tmp.ptr, h, w, 16, None) != 0
+    assert lib.fcn_blur_box_bgr8(src.ptr, src.ptr, h, w, 3, None) != 0                 # in place is refused
 
 
 @pytest.mark.parametrize("mode", ["mask", "detectnet"])
@@ -69,12 +116,14 @@ def test_device_fed_tops_match_host_tops(gpu, mode):
     with pytest.raises(RuntimeError):
         unbound.forward([], tops)
     random.seed(7)
-    state = random.getstate()
+    lay._color_rng = np.random.default_rng(7)
+    state, cstate = random.getstate(), lay._color_rng.bit_generator.state
     lay.forward([], tops)                       # device path: renders into the engine's blobs
     dev_rects, dev_labels = lay.last_rects, lay.last_labels
     eng.blobs["data"].host_valid = False          # written in HBM by the renderer, not through the host array
     data_dev = eng.read_blob("data").copy()
     random.setstate(state)
+    lay._color_rng.bit_generator.state = cstate
     host = np.zeros((lay.batch_size, 3, lay.image_size_y, lay.image_size_x), np.float32)
     host_mask = np.zeros((lay.batch_size, 1, lay.image_size_y, lay.image_size_x), np.float32)
     host_rects, host_labels = [], []

@@ -85,7 +85,7 @@ def test_host_and_device_label_paths_agree(gpu, tmp_path):
         lay = s.py_layers[0][1]
         lay.device_targets = dev
         random.seed(5)
-        lay._noise = np.random.default_rng(1234)
+        lay._color_rng = np.random.default_rng(1234)
         losses.append([s.step(1)["loss"] for _ in range(2)])
         s.close()
     assert losses[0] == losses[1]
@@ -112,7 +112,7 @@ def test_snapshot_restore_is_exact(gpu, tmp_path, kind):
     out = []
     for s in (a, b):
         random.seed(99)
-        s.py_layers[0][1]._noise = np.random.default_rng(77)
+        s.py_layers[0][1]._color_rng = np.random.default_rng(77)
         out.append(s.step(1)["loss"])
     assert out[0] == out[1]
     a.close()

@@ -45,3 +45,20 @@ with tempfile.TemporaryDirectory() as tmp:
     L.call("fcn_stream_sync", s.engine.stream)
     t2 = time.perf_counter()
     print("render enqueue %.3f ms/sample, device drain of 200 renders %.3f ms (%.3f ms each)" % ((t1 - t0) / 200 * 1e3, (t2 - t0) * 1e3, (t2 - t0) / 200 * 1e3))
+    for blur in (dict(kind="gauss", sigma=3.0), dict(kind="gauss", sigma=0.8), dict(kind="box", k=7), dict(kind="median", k=3),
+                 dict(kind="median", k=5), dict(kind="median", k=7), None):
+        p = dict(plan)
+        p["view"] = None
+        p["color"] = dict(plan["color"], blur=blur) if blur else None
+        lay._renderer.render(0, p)
+        L.call("fcn_stream_sync", s.engine.stream)
+        t0 = time.perf_counter()
+        for _ in range(100):
+            lay._renderer.render(0, p)
+        L.call("fcn_stream_sync", s.engine.stream)
+        print("render with %-40s %.3f ms/sample (enqueue + drain)" % (blur, (time.perf_counter() - t0) / 100 * 1e3))
+    s.step(20, pipeline=True) if "pipeline" in s.step.__code__.co_varnames else None
+    t0 = time.perf_counter()
+    s.step(50, pipeline=True)
+    L.call("fcn_stream_sync", s.engine.stream)
+    print("pipelined solver iteration %.3f ms" % ((time.perf_counter() - t0) / 50 * 1e3))
