@@ -627,20 +627,48 @@ class TrainEngine(Engine):
             if dev_targets:
                 self._enqueue_targets()
             world = self.comm.world if self.comm is not None else 1
+            side = self._wgrad_stream()
+            side_used = False
             for kind, item in self._step_plan():
                 if kind == "graph":
                     L.check(lib.fcn_graph_launch(item, self.stream))
                 elif kind == "op":
                     item.run(self.stream)
+                elif kind == "fork":
+                    op, ev0, ev1 = item
+                    L.check(lib.fcn_event_record(ev0, self.stream))
+                    L.check(lib.fcn_stream_wait_event(side, ev0))
+                    op.run(side)
+                    L.check(lib.fcn_event_record(ev1, side))
+                elif kind == "join":
+                    L.check(lib.fcn_stream_wait_event(self.stream, item))
+                elif kind == "side":
+                    # a weight gradient: nothing later in this step reads it except the update, and its inputs (dY, X) are
+                    # final here -> it runs on the second stream beside the data-gradient chain
+                    op, ev = item
+                    L.check(lib.fcn_event_record(ev, self.stream))
+                    L.check(lib.fcn_stream_wait_event(side, ev))
+                    op.run(side)
+                    side_used = True
                 else:
                     for b in item:
                         # this bucket's gradients are final: sum them across ranks on the side stream
-                        L.check(lib.fcn_event_record(b["ready"], self.stream))
+                        if side_used:       # final = everything queued so far on BOTH streams
+                            if "ready_main" not in b:
+                                ev = C.c_void_p()
+                                L.call("fcn_event_create", C.byref(ev))
+                                b["ready_main"] = ev
+                            L.check(lib.fcn_event_record(b["ready_main"], self.stream))
+                            L.check(lib.fcn_stream_wait_event(side, b["ready_main"]))
+                        L.check(lib.fcn_event_record(b["ready"], side if side_used else self.stream))
                         L.check(lib.fcn_stream_wait_event(self.comm_stream, b["ready"]))
                         self.comm.all_reduce_sum(self.grad_flat.ptr + 4 * b["offset"], b["count"], self.comm_stream)
                         L.check(lib.fcn_event_record(b["done"], self.comm_stream))
             for b in self.buckets:
                 L.check(lib.fcn_stream_wait_event(self.stream, b["done"]))
+            if side_used:
+                L.check(lib.fcn_event_record(self._side_done, side))
+                L.check(lib.fcn_stream_wait_event(self.stream, self._side_done))
             self.apply_update(1.0 / (world * self.solver.iter_size))
             for name, arr in self.loss_host.items():
                 L.check(lib.fcn_memcpy_d2h_async(arr.ctypes.data, self.blobs[name].buf.ptr, 4, self.stream))
@@ -666,6 +694,18 @@ class TrainEngine(Engine):
 
     # kinds whose launch arguments change from step to step (the dropout seed): they stay ordinary launches
     DYNAMIC_KINDS = ("dropout", "dropout_bwd")
+
+    def _wgrad_stream(self) -> Optional[int]:
+        """Second stream for the weight-gradient launches (FCN_WGRAD_STREAM=0 keeps everything on one stream)."""
+        import os
+        if os.environ.get("FCN_WGRAD_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_side_stream", None) is None:
+            sp, ev = C.c_void_p(), C.c_void_p()
+            L.call("fcn_stream_create", C.byref(sp))
+            L.call("fcn_event_create", C.byref(ev))
+            self._side_stream, self._side_done = int(sp.value), ev
+        return self._side_stream
 
     def _step_plan(self) -> List[Tuple[str, object]]:
         """Forward + backward of one step as [("graph", hipGraphExec) | ("op", Op) | ("reduce", [buckets])].
@@ -709,7 +749,24 @@ class TrainEngine(Engine):
             run.clear()
 
         self._step_graphs: List[int] = getattr(self, "_step_graphs", [])
+        side = self._wgrad_stream() is not None
+
+        def new_event():
+            ev = C.c_void_p()
+            L.call("fcn_event_create", C.byref(ev))
+            self._keep.append(ev)
+            return ev
+        if side and self.bwd_ops and self.bwd_ops[0].kind == "flip":
+            # the flipped filter banks depend on the weights only: refreshed beside the forward pass, joined before backward
+            at = len(self.ops)
+            flip_evs = (new_event(), new_event())
+            seq[at] = ("join", flip_evs[1])
+            seq.insert(0, ("fork", (self.bwd_ops[0], flip_evs[0], flip_evs[1])))
         for kind, item in seq:
+            if kind == "op" and side and item.kind == "wgrad":
+                flush()
+                plan.append(("side", (item, new_event())))
+                continue
             if kind == "op" and item.kind not in self.DYNAMIC_KINDS:
                 run.append(item)
                 continue
@@ -726,6 +783,10 @@ class TrainEngine(Engine):
             lib.fcn_graph_destroy(g)
         self._step_graphs = []
         self._plan = None
+        if getattr(self, "_side_stream", None):
+            lib.fcn_stream_sync(self._side_stream)
+            lib.fcn_stream_destroy(self._side_stream)
+            self._side_stream = None
         super().close()
 
     def apply_update(self, grad_scale: float) -> None:

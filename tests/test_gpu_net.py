@@ -81,6 +81,43 @@ def test_batch_and_odd_sizes(gpu):
     eng.close()
 
 
+def test_forward_pipeline_equals_lone_engine(gpu):
+    """ForwardPipeline: three replicas (own stream and activations), frames handed out round-robin: every frame's result is
+    the lone engine's, bit for bit and in submission order; the replicas take over the first one's tile plan."""
+    from fcn_object_detector_amd.engine import ForwardPipeline
+    msg, params, lone = build(1, 96, 128, 3, autotune=False)
+    pipe = ForwardPipeline(lambda: NetSpec(msg, "TEST"), params=params, device=0, depth=3, autotune=False)
+    rng = np.random.default_rng(9)
+    frames = [rng.random((1, 3, 96, 128), dtype=np.float32) for _ in range(8)]
+    want = []
+    for f in frames:
+        lone.host_array("data")[...] = f
+        want.append({k: v.copy() for k, v in lone.forward().items()})
+    got = pipe.map([{"data": f} for f in frames])
+    assert len(got) == 8
+    for g, w in zip(got, want):
+        for k in ("coverage", "bboxes"):
+            assert np.array_equal(g[k], w[k])
+    rb = oracle_forward(msg, params, frames[5])
+    assert rel_err(got[5]["coverage"], rb["coverage"]) < TOL and rel_err(got[5]["bboxes"], rb["bboxes"]) < TOL
+    # flow control: no more than `depth` frames outstanding, nothing to collect when idle
+    for f in frames[:3]:
+        pipe.submit({"data": f})
+    with pytest.raises(RuntimeError):
+        pipe.submit({"data": frames[3]})
+    assert np.array_equal(pipe.collect()["coverage"], want[0]["coverage"])
+    pipe.collect(), pipe.collect()
+    with pytest.raises(RuntimeError):
+        pipe.collect()
+    assert pipe.run_resident(7) > 0
+    # a tuned first replica hands its plan to the others
+    tuned = ForwardPipeline(lambda: NetSpec(msg, "TEST"), params=params, device=0, depth=2)
+    assert tuned.engines[0]._chosen_cfgs and tuned.engines[1]._chosen_cfgs == tuned.engines[0]._chosen_cfgs
+    tuned.close()
+    pipe.close()
+    lone.close()
+
+
 def test_pycaffe_front_end(gpu, tmp_path):
     """The reference's calling sequence (fcn_object_detector.py:68-69,82,87,317-328) against our `caffe` package."""
     if PYCAFFE not in sys.path:
