@@ -222,6 +222,32 @@ def bench_infer32(local: int, dtype: str, reps: int = 10):
             "detections_last_batch": int(sum(len(r[0]) for r in res))}, heads
 
 
+def bench_detector_stream(local: int, msg, params, n_frames: int = 300):
+    """The whole node per camera frame at batch 1, PCIe included: 640x480 uint8 frame from host memory -> upload ->
+    pre-processing -> forward -> decode + groupRectangles -> detections on the host; one frame at a time vs three in flight."""
+    from fcn_object_detector_amd.detector import DetectorPipeline, FCNObjectDetector, HeadMapping
+    from fcn_object_detector_amd.engine import Engine
+    from fcn_object_detector_amd.netspec import NetSpec
+    frames = [np.random.default_rng(i).integers(0, 256, (480, 640, 3), dtype=np.uint8) for i in range(8)]
+    pipe = DetectorPipeline(lambda first: Engine(NetSpec(msg, "TEST"), params=params, device=local, tune_from=first), depth=3,
+                            mapping=HeadMapping.detectnet_deploy())
+    lone = pipe.detectors[0]
+    for f in frames:
+        lone.run_detector(f)
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        lone.run_detector(frames[i % 8])
+    serial = n_frames / (time.perf_counter() - t0)
+    pipe.run_detector_stream(frames)
+    t0 = time.perf_counter()
+    pipe.run_detector_stream(frames[i % 8] for i in range(n_frames))
+    piped = n_frames / (time.perf_counter() - t0)
+    pipe.close()
+    return {"workload": "per camera frame (640x480 uint8 from host memory): upload + pre-processing + forward + decode/groupRectangles + "
+                        "read-back, f32, batch 1", "frames_per_s_one_at_a_time": round(serial, 1),
+            "frames_per_s_3_in_flight": round(piped, 1)}
+
+
 def bench_vgg(steps: int = 5):
     """The reference's secondary net train/fcn_bbox (VGG16 + FCN-8s scores + x4 bilinear bbox branch):
     forward of its inference form at 448x448 and one training step at its native shape (288x288, stride 8, 11 classes,
@@ -432,6 +458,7 @@ def main() -> None:
         r32, h32 = bench_infer32(local, "f32")
         r16, h16 = bench_infer32(local, "f16")
         r16["rel_err_vs_f32"] = {k: float("%.3e" % (np.abs(h16[k] - h32[k]).max() / max(np.abs(h32[k]).max(), 1e-30))) for k in h32}
+        out["detector_batch1"] = bench_detector_stream(local, msg, params)
         out["inference_batch32"] = {"workload": "configs[4]: batch 32, 448x448, pre-processing + forward + fused decode/groupRectangles + read-back",
                                     "f16": r16, "f32": r32}
         out["secondary"] = bench_vgg()

@@ -23,7 +23,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import lib as L
-from .engine import DeviceBuffer, Engine
+from .engine import DeviceBuffer, Engine, PinnedArray
 
 F32 = np.float32
 
@@ -73,9 +73,10 @@ class GridDecoder:
         self.d_rects = DeviceBuffer(slots * p.max_out * 16, zero=True)
         self.d_weights = DeviceBuffer(slots * p.max_out * 4, zero=True)
         self.d_count = DeviceBuffer(slots * 4, zero=True)
-        self.h_rects = np.zeros((slots, p.max_out, 4), np.int32)
-        self.h_weights = np.zeros((slots, p.max_out), np.int32)
-        self.h_count = np.zeros((slots,), np.int32)
+        # results land in pinned host memory: the read-back is then truly asynchronous (a pageable destination would hold the
+        # host thread until the stream drains, which serialises the frames of a DetectorPipeline)
+        self._pinned = [PinnedArray((slots, p.max_out, 4)), PinnedArray((slots, p.max_out)), PinnedArray((slots,))]
+        self.h_rects, self.h_weights, self.h_count = (a.array.view(np.int32) for a in self._pinned)
 
     def launch(self, cvg_ptr: int, cvg_cstride: int, cvg_coffset: int, cvg_image_stride: int,
                box_ptr: int, box_cstride: int, box_coffset: int, box_image_stride: int, stream: Optional[int]) -> None:
@@ -84,11 +85,16 @@ class GridDecoder:
         L.call("fcn_detect_decode_group", cvg_ptr, box_ptr, self.batch, cvg_image_stride, box_image_stride, C.byref(p),
                self.ws.ptr, self.d_rects.ptr, self.d_weights.ptr, self.d_count.ptr, stream)
 
-    def fetch(self, stream: Optional[int]) -> List[Tuple[np.ndarray, np.ndarray]]:
-        """Per image: (detections (D,5) float64 [x1,y1,x2,y2,log n] in reference order, labels (D,) int)."""
+    def fetch_begin(self, stream: Optional[int]) -> None:
+        """Enqueue the read-back of the detections behind the decode launch (returns at once)."""
         L.call("fcn_memcpy_d2h_async", self.h_count.ctypes.data, self.d_count.ptr, self.h_count.nbytes, stream)
         L.call("fcn_memcpy_d2h_async", self.h_rects.ctypes.data, self.d_rects.ptr, self.h_rects.nbytes, stream)
         L.call("fcn_memcpy_d2h_async", self.h_weights.ctypes.data, self.d_weights.ptr, self.h_weights.nbytes, stream)
+
+    def fetch(self, stream: Optional[int], begun: bool = False) -> List[Tuple[np.ndarray, np.ndarray]]:
+        """Per image: (detections (D,5) float64 [x1,y1,x2,y2,log n] in reference order, labels (D,) int)."""
+        if not begun:
+            self.fetch_begin(stream)
         L.call("fcn_stream_sync", stream)
         out = []
         for img in range(self.batch):
@@ -255,27 +261,89 @@ class FCNObjectDetector:
             out.append((resize_detection(f.shape, boxes, self.im_width, self.im_height) if len(boxes) else boxes, labels))
         return out
 
-    def run_detector(self, frame: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    def submit(self, frame: np.ndarray) -> None:
+        """Enqueue one frame end to end - upload, pre-processing, forward, decode + grouping, read-back - on the engine's stream
+        and return without waiting; collect() delivers the detections.  One frame may be outstanding per detector."""
         eng = self.engine
         if self.batch != 1:
             raise ValueError("run_detector handles one frame; build the engine with batch 1")
+        if getattr(self, "_outstanding", None) is not None:
+            raise RuntimeError("a frame is already in flight: collect() it first")
         frame = np.ascontiguousarray(frame, np.uint8)
-        h, w, c = frame.shape
-        if c != 3:
+        if frame.ndim != 3 or frame.shape[2] != 3:
             raise ValueError("expected a BGR uint8 frame")
+        h, w, _c = frame.shape
         with eng.lock:
             L.call("fcn_init", eng.device)
             if self._frame_dev is None or self._frame_dev.nbytes < frame.nbytes:
                 self._frame_dev = DeviceBuffer(frame.nbytes, zero=False)
+                self._frame_pinned = PinnedArray(((frame.nbytes + 3) // 4,))      # staging: an async copy needs pinned memory
+            stage = self._frame_pinned.array.view(np.uint8)[:frame.nbytes]
+            stage[...] = frame.reshape(-1)
             data = eng.blobs["data"]
-            L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, frame.ctypes.data, frame.nbytes, eng.stream)
+            L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, stage.ctypes.data, frame.nbytes, eng.stream)
             L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", self._frame_dev.ptr, h, w, data.ptr, self.im_height,
                    self.im_width, data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
-            eng.forward_resident(1)
+            eng.forward_enqueue()
             self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
-            dets, labels = self.decoder.fetch(eng.stream)[0]
+            self.decoder.fetch_begin(eng.stream)
             data.host_valid = False
+            self._outstanding = frame.shape
+
+    def collect(self) -> Tuple[np.ndarray, np.ndarray]:
+        if getattr(self, "_outstanding", None) is None:
+            raise RuntimeError("no frame in flight")
+        shape, self._outstanding = self._outstanding, None
+        with self.engine.lock:
+            dets, labels = self.decoder.fetch(self.engine.stream, begun=True)[0]
         boxes = np.asarray(dets, dtype=np.int64).reshape(-1, 5)        # :123 np.asarray(..., dtype=np.int) truncates
         if not len(boxes):
             return boxes, labels
-        return resize_detection(frame.shape, boxes, self.im_width, self.im_height), labels
+        return resize_detection(shape, boxes, self.im_width, self.im_height), labels
+
+    def run_detector(self, frame: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        self.submit(frame)
+        return self.collect()
+
+
+class DetectorPipeline:
+    """`depth` detectors on replica engines (engine.ForwardPipeline's idea for the whole node: upload, pre-processing,
+    forward, decode + grouping and read-back of consecutive camera frames overlap on the device).  Results are those of
+    run_detector, in frame order."""
+
+    def __init__(self, make_engine, depth: int = 3, **detector_kw):
+        self.detectors: List[FCNObjectDetector] = []
+        first = None
+        for _ in range(max(int(depth), 1)):
+            eng = make_engine(first)            # make_engine(tune_from) -> Engine (batch 1)
+            first = first or eng
+            self.detectors.append(FCNObjectDetector(eng, **detector_kw))
+        self._queue: List[FCNObjectDetector] = []
+        self._next = 0
+
+    def submit(self, frame: np.ndarray) -> None:
+        if len(self._queue) >= len(self.detectors):
+            raise RuntimeError("DetectorPipeline: %d frames already in flight" % len(self._queue))
+        d = self.detectors[self._next]
+        self._next = (self._next + 1) % len(self.detectors)
+        d.submit(frame)
+        self._queue.append(d)
+
+    def collect(self) -> Tuple[np.ndarray, np.ndarray]:
+        if not self._queue:
+            raise RuntimeError("DetectorPipeline: nothing in flight")
+        return self._queue.pop(0).collect()
+
+    def run_detector_stream(self, frames) -> List[Tuple[np.ndarray, np.ndarray]]:
+        out = []
+        for f in frames:
+            if len(self._queue) == len(self.detectors):
+                out.append(self.collect())
+            self.submit(f)
+        while self._queue:
+            out.append(self.collect())
+        return out
+
+    def close(self) -> None:
+        for d in self.detectors:
+            d.engine.close()

@@ -949,6 +949,19 @@ class Engine:
                 self._enqueue_upload(nm, self.stream)
             L.call("fcn_stream_sync", self.stream)
 
+    def forward_enqueue(self) -> None:
+        """The layer stack once on inputs already in HBM, enqueued on the engine's stream without waiting."""
+        with self.lock:
+            if os.environ.get("FCN_NO_GRAPH", "0") in ("", "0"):
+                if self.graph_core is None:
+                    self.graph_core = self._capture(with_io=False)
+                L.call("fcn_graph_launch", self.graph_core, self.stream)
+            else:
+                self.run_ops(self.stream)
+            for b in self.blobs.values():
+                if not b.is_input:
+                    b.host_valid = False
+
     def forward_resident(self, iters: int = 1, use_graph: bool = True) -> float:
         """Run the layer stack ``iters`` times on inputs already in HBM; returns HIP-event ms for all iterations."""
         use_graph = use_graph and os.environ.get("FCN_NO_GRAPH", "0") in ("", "0")      # plain launches (e.g. under a profiler)

@@ -175,3 +175,35 @@ def test_batched_node_pipeline_matches_oracle(gpu):
     for i, f in enumerate(same):
         assert np.abs(eng.read_blob("data")[i] - D.preprocess_frame(f, 320, 224)).max() <= 4e-6
     eng.close()
+
+
+def test_detector_pipeline_equals_frame_by_frame(gpu):
+    """DetectorPipeline (three replica engines, frames of different sizes in flight together): per frame exactly what
+    run_detector returns, in frame order; the head biases are raised so that there are detections to compare."""
+    from fcn_object_detector_amd.detector import DetectorPipeline
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(1, 224, 320, 3))
+    spec = NetSpec(msg, "TEST"); spec.infer()
+    params = fill_params(spec, seed=77)
+    rng = np.random.default_rng(6)
+    params["cvg/classifier"][1][...] = 1.5
+    params["bbox/regressor"][0][...] = 0
+    params["bbox/regressor"][1][...] = np.tile(np.array([-30, -25, 35, 40], np.float32), 3) + rng.normal(0, 0.5, 12).astype(np.float32)
+    mapping = HeadMapping.detectnet_deploy()
+    lone = FCNObjectDetector(Engine(NetSpec(msg, "TEST"), params=params, device=0, autotune=False), 0.5, 3, 0.2, mapping)
+    pipe = DetectorPipeline(lambda first: Engine(NetSpec(msg, "TEST"), params=params, device=0, autotune=False, tune_from=first), depth=3,
+                            detection_threshold=0.5, min_boxes=3, nms_eps=0.2, mapping=mapping)
+    sizes = [(224, 320), (480, 640), (100, 517), (300, 200), (480, 640), (224, 320), (97, 131)]
+    frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+    want = [lone.run_detector(f) for f in frames]
+    got = pipe.run_detector_stream(frames)
+    assert len(got) == len(frames) and sum(len(b) for b, _ in want) > 0
+    for (gb, gl), (wb, wl) in zip(got, want):
+        assert np.array_equal(gb, wb) and np.array_equal(gl, wl)
+    pipe.submit(frames[0])
+    with pytest.raises(RuntimeError):
+        pipe._queue[0].submit(frames[1])                # one frame per replica
+    assert np.array_equal(pipe.collect()[0], want[0][0])
+    with pytest.raises(RuntimeError):
+        pipe.collect()
+    pipe.close()
+    lone.engine.close()
