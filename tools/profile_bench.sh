@@ -10,6 +10,9 @@ export FCN_TUNE_CACHE=$OUT/${TAG}_tune.json
 ARGS="--steps 50 --warmup 5 --no-cpu-baseline --no-secondary $*"
 cd "$ROOT"
 python3 bench.py $ARGS > "$OUT/${TAG}_bench_plain.json"            # fills the tune cache: profiled runs replay the plan
+# the profiled runs keep ONE frame in flight: per-kernel durations (what `roofline` is computed from) are only meaningful
+# when launches do not overlap
+ARGS="$ARGS --in-flight 1"
 export TMPDIR=/tmp
 # rocprofv3 (ROCm 7.2) segfaults inside hipGraphLaunch when the plan is replayed from the tune cache; the profiled runs
 # therefore issue the same kernels as ordinary launches (identical kernels, arguments and order)
