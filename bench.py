@@ -184,40 +184,58 @@ def bench_infer32(local: int, dtype: str, reps: int = 10):
     """BASELINE configs[4]: 32 uint8 frames resident in HBM -> pre-processing -> one forward -> one fused decode +
     groupRectangles launch for all (image, class) pairs -> boxes on the host (FCNObjectDetector.run_detector_batch minus
     the frame upload).  dtype "f16": activations and weights stored as halves, v_mfma_f32_32x32x16_f16 with f32
-    accumulation (the image and conv1's weights stay f32: the net shifts a [0,1] image by -127); "f32" beside it."""
+    accumulation (the image and conv1's weights stay f32: the net shifts a [0,1] image by -127); "f32" beside it.
+    Measured one batch at a time and with two batches in flight on replica engines (the read-back and the host-side
+    unpacking of one batch overlap the forward of the next)."""
     from fcn_object_detector_amd import lib as L, models, proto
-    from fcn_object_detector_amd.detector import FCNObjectDetector, HeadMapping
+    from fcn_object_detector_amd.detector import DetectorPipeline, HeadMapping
     from fcn_object_detector_amd.engine import DeviceBuffer, Engine
     from fcn_object_detector_amd.netspec import NetSpec, fill_params
     n = 32
     msg = proto.parse_text(models.googlenet_detectnet_deploy(n, 448, 448, 4))
     spec = NetSpec(msg, "TEST")
     spec.infer()
-    eng = Engine(NetSpec(msg, "TEST"), params=fill_params(spec, seed=1234), device=local, dtype=dtype)
-    det = FCNObjectDetector(eng, 0.5, 3, 0.2, HeadMapping.detectnet_deploy())
+    params = fill_params(spec, seed=1234)
+    pipe = DetectorPipeline(lambda first: Engine(NetSpec(msg, "TEST"), params=params, device=local, dtype=dtype, tune_from=first), depth=2,
+                            mapping=HeadMapping.detectnet_deploy())
+    det = pipe.detectors[0]
+    eng = det.engine
     frames = np.random.default_rng(9).integers(0, 256, (n, 448, 448, 3), dtype=np.uint8)
     dev = DeviceBuffer(frames.nbytes, zero=False)
     L.call("fcn_memcpy_h2d_async", dev.ptr, frames.ctypes.data, frames.nbytes, eng.stream)
-    data = eng.blobs["data"]
+    L.call("fcn_device_sync")
+    layout = [(i * 448 * 448 * 3, 448, 448) for i in range(n)]
+    for d in pipe.detectors:
+        d._minmax_batch_holder[:] = [DeviceBuffer(32 * n)]
 
-    mm = DeviceBuffer(32 * n)
+    def submit(d):
+        with d.engine.lock:
+            d._enqueue_batch(dev.ptr, layout, True)
+            d._outstanding = [(448, 448, 3)] * n
 
-    def once():
-        L.call("fcn_preprocess_bgr8_batch", dev.ptr, n, 448, 448, data.ptr, 1 if data.esize == 2 else 0, 448, 448, data.cstride,
-               data.upload_shift, mm.ptr, eng.stream)
-        eng.forward_resident(1)
-        det.decoder.launch(*det._cvg_args, *det._box_args, eng.stream)
-        return det.decoder.fetch(eng.stream)
-    once()
-    once()
+    for d in pipe.detectors:
+        submit(d)
+        d.collect_batch()
     t0 = time.perf_counter()
     for _ in range(reps):
-        res = once()
+        submit(det)
+        res = det.collect_batch()
     dt = (time.perf_counter() - t0) / reps
+    # two batches in flight
+    a, b = pipe.detectors
+    t0 = time.perf_counter()
+    submit(a)
+    for i in range(2 * reps - 1):
+        nxt, cur = (b, a) if i % 2 == 0 else (a, b)
+        submit(nxt)
+        cur.collect_batch()
+    (b if (2 * reps - 1) % 2 else a).collect_batch()
+    dt2 = (time.perf_counter() - t0) / (2 * reps)
     fwd_ms = eng.forward_resident(5) / 5
     heads = {k: eng.read_blob(k).copy() for k in ("coverage", "bboxes")}
-    eng.close()
-    return {"frames_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3), "forward_ms": round(fwd_ms, 3),
+    pipe.close()
+    return {"frames_per_s": round(n / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 3), "batches_in_flight": 2,
+            "one_batch_at_a_time": {"frames_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3)}, "forward_ms": round(fwd_ms, 3),
             "forward_tflops": round(FWD_GFLOP * n / fwd_ms, 1), "dtype": dtype, "batch": n,
             "detections_last_batch": int(sum(len(r[0]) for r in res))}, heads
 

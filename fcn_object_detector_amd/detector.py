@@ -224,9 +224,16 @@ class FCNObjectDetector:
     def run_detector_batch(self, frames: Sequence[np.ndarray]) -> List[Tuple[np.ndarray, np.ndarray]]:
         """BASELINE configs[4] minus the fp16 arithmetic: `batch` frames through pre-processing, ONE forward and ONE fused
         decode + groupRectangles launch ((image, class) per workgroup); per frame the result of run_detector."""
+        self.submit_batch(frames)
+        return self.collect_batch()
+
+    def submit_batch(self, frames: Sequence[np.ndarray]) -> None:
+        """Enqueue a whole batch (upload, pre-processing, forward, decode + grouping, read-back) without waiting."""
         eng = self.engine
         if len(frames) != self.batch:
             raise ValueError("need %d frames (the engine's batch), got %d" % (self.batch, len(frames)))
+        if getattr(self, "_outstanding", None) is not None:
+            raise RuntimeError("a batch is already in flight: collect_batch() it first")
         frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
         if any(f.ndim != 3 or f.shape[2] != 3 for f in frames):
             raise ValueError("expected BGR uint8 frames")
@@ -235,30 +242,48 @@ class FCNObjectDetector:
             need = sum((f.nbytes + 15) // 16 * 16 for f in frames)
             if self._frame_dev is None or self._frame_dev.nbytes < need:
                 self._frame_dev = DeviceBuffer(need, zero=False)
+                self._frame_pinned = PinnedArray(((need + 3) // 4,))      # staging: an async copy needs pinned memory
+            stage = self._frame_pinned.array.view(np.uint8)
             data = eng.blobs["data"]
             if len(self._minmax_batch_holder) == 0 or self._minmax_batch_holder[0].nbytes < 32 * len(frames):
                 self._minmax_batch_holder[:] = [DeviceBuffer(32 * len(frames))]
             same = all(f.shape == frames[0].shape for f in frames)
-            off = 0
-            for i, f in enumerate(frames):
-                L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr + off, f.ctypes.data, f.nbytes, eng.stream)
-                if not same:
-                    L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", self._frame_dev.ptr + off, f.shape[0],
-                           f.shape[1], data.ptr + data.esize * i * self.im_height * self.im_width * data.cstride, self.im_height, self.im_width,
-                           data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
+            off, offs = 0, []
+            for f in frames:
+                stage[off:off + f.nbytes] = f.reshape(-1)
+                offs.append(off)
                 off += f.nbytes if same else (f.nbytes + 15) // 16 * 16
-            if same:      # one camera: the whole batch in three launches
-                L.call("fcn_preprocess_bgr8_batch", self._frame_dev.ptr, len(frames), frames[0].shape[0], frames[0].shape[1], data.ptr,
-                       1 if data.esize == 2 else 0, self.im_height, self.im_width, data.cstride, data.upload_shift,
-                       self._minmax_batch_holder[0].ptr, eng.stream)
-            eng.forward_resident(1)
-            self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
-            res = self.decoder.fetch(eng.stream)
-            data.host_valid = False
+            L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, stage.ctypes.data, off, eng.stream)
+            self._enqueue_batch(self._frame_dev.ptr, [(o, f.shape[0], f.shape[1]) for o, f in zip(offs, frames)], same)
+            self._outstanding = [f.shape for f in frames]
+
+    def _enqueue_batch(self, dev_ptr: int, layout: Sequence[Tuple[int, int, int]], same: bool) -> None:
+        """Pre-processing of frames already in HBM (byte offset, h, w each), forward, decode launch, read-back: all enqueued."""
+        eng = self.engine
+        data = eng.blobs["data"]
+        if same:      # one camera: the whole batch in three launches
+            L.call("fcn_preprocess_bgr8_batch", dev_ptr, len(layout), layout[0][1], layout[0][2], data.ptr, 1 if data.esize == 2 else 0,
+                   self.im_height, self.im_width, data.cstride, data.upload_shift, self._minmax_batch_holder[0].ptr, eng.stream)
+        else:
+            for i, (off, h, w) in enumerate(layout):
+                L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", dev_ptr + off, h, w,
+                       data.ptr + data.esize * i * self.im_height * self.im_width * data.cstride, self.im_height, self.im_width,
+                       data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
+        eng.forward_enqueue()
+        self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
+        self.decoder.fetch_begin(eng.stream)
+        data.host_valid = False
+
+    def collect_batch(self) -> List[Tuple[np.ndarray, np.ndarray]]:
+        if getattr(self, "_outstanding", None) is None:
+            raise RuntimeError("no batch in flight")
+        shapes, self._outstanding = self._outstanding, None
+        with self.engine.lock:
+            res = self.decoder.fetch(self.engine.stream, begun=True)
         out = []
-        for f, (dets, labels) in zip(frames, res):
+        for shape, (dets, labels) in zip(shapes, res):
             boxes = np.asarray(dets, dtype=np.int64).reshape(-1, 5)
-            out.append((resize_detection(f.shape, boxes, self.im_width, self.im_height) if len(boxes) else boxes, labels))
+            out.append((resize_detection(shape, boxes, self.im_width, self.im_height) if len(boxes) else boxes, labels))
         return out
 
     def submit(self, frame: np.ndarray) -> None:
@@ -333,6 +358,20 @@ class DetectorPipeline:
         if not self._queue:
             raise RuntimeError("DetectorPipeline: nothing in flight")
         return self._queue.pop(0).collect()
+
+    def run_detector_batches(self, batches) -> List[List[Tuple[np.ndarray, np.ndarray]]]:
+        """Batched engines: consecutive batches overlap (the read-back and host-side unpacking of one with the forward of the next)."""
+        out, queue, nxt = [], [], 0
+        for frames in batches:
+            if len(queue) == len(self.detectors):
+                out.append(queue.pop(0).collect_batch())
+            d = self.detectors[nxt]
+            nxt = (nxt + 1) % len(self.detectors)
+            d.submit_batch(frames)
+            queue.append(d)
+        while queue:
+            out.append(queue.pop(0).collect_batch())
+        return out
 
     def run_detector_stream(self, frames) -> List[Tuple[np.ndarray, np.ndarray]]:
         out = []

@@ -207,3 +207,31 @@ def test_detector_pipeline_equals_frame_by_frame(gpu):
         pipe.collect()
     pipe.close()
     lone.engine.close()
+
+
+def test_batched_detector_pipeline(gpu):
+    """Two batch-4 replicas, three batches in a row: each batch's result equals run_detector_batch on a lone detector."""
+    from fcn_object_detector_amd.detector import DetectorPipeline
+    batch = 4
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(batch, 224, 320, 3))
+    spec = NetSpec(msg, "TEST"); spec.infer()
+    params = fill_params(spec, seed=77)
+    rng = np.random.default_rng(8)
+    params["cvg/classifier"][1][...] = 1.5
+    params["bbox/regressor"][0][...] = 0
+    params["bbox/regressor"][1][...] = np.tile(np.array([-30, -25, 35, 40], np.float32), 3) + rng.normal(0, 0.5, 12).astype(np.float32)
+    mapping = HeadMapping.detectnet_deploy()
+    lone = FCNObjectDetector(Engine(NetSpec(msg, "TEST"), params=params, device=0, autotune=False), 0.5, 3, 0.2, mapping)
+    pipe = DetectorPipeline(lambda first: Engine(NetSpec(msg, "TEST"), params=params, device=0, autotune=False, tune_from=first), depth=2,
+                            mapping=mapping)
+    batches = [[rng.integers(0, 256, (240, 352, 3), dtype=np.uint8) for _ in range(batch)],
+               [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in ((224, 320), (480, 640), (100, 517), (300, 200))],
+               [rng.integers(0, 256, (224, 320, 3), dtype=np.uint8) for _ in range(batch)]]
+    want = [lone.run_detector_batch(b) for b in batches]
+    got = pipe.run_detector_batches(batches)
+    assert sum(len(bx) for res in want for bx, _ in res) > 0
+    for g, w in zip(got, want):
+        for (gb, gl), (wb, wl) in zip(g, w):
+            assert np.array_equal(gb, wb) and np.array_equal(gl, wl)
+    pipe.close()
+    lone.engine.close()
