@@ -605,7 +605,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_one
     X(13, 2, 2, 2, 2, 2, 32, 3, false) \
     X(14, 1, 1, 2, 2, 1, 32, 3, false) \
     X(15, 2, 1, 2, 2, 1, 32, 3, false) \
-    X(16, 1, 2, 2, 2, 1, 32, 3, false)
+    X(16, 1, 2, 2, 2, 1, 32, 3, false) \
+    X(17, 1, 1, 1, 1, 4, 64, 3, false) \
+    X(18, 1, 1, 1, 1, 4, 32, 4, true)  \
+    X(19, 1, 1, 2, 1, 2, 32, 4, true)  \
+    X(20, 1, 1, 2, 1, 2, 32, 3, false) \
+    X(21, 1, 1, 1, 1, 4, 32, 3, false) \
+    X(22, 1, 1, 4, 1, 1, 32, 3, false)
 
 struct TileCfg { int bm, bn, bk; bool prefetch; };
 constexpr int kCfgThreads[] = {
@@ -613,7 +619,12 @@ constexpr int kCfgThreads[] = {
     FCN_CONV_CONFIGS(X)
 #undef X
 };
-constexpr int kNumCfg = 17;
+constexpr int kCfgLdsBytes[] = {
+#define X(I, A, B, C_, D, E, F, G, H) Cfg<A, B, C_, D, E, F, G, H>::LDS_FLOATS * 4,
+    FCN_CONV_CONFIGS(X)
+#undef X
+};
+constexpr int kNumCfg = 23;
 constexpr TileCfg kCfgs[kNumCfg] = {
 #define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
     FCN_CONV_CONFIGS(X)
@@ -757,6 +768,8 @@ int fcn_conv2d_fwd_f32(const fcn_conv_desc* h_desc, fcn_stream_t s) {
 size_t fcn_conv2d_group_workspace_bytes(int n) { return sizeof(ConvP) * (size_t)(n > 0 ? n : 0); }
 
 int fcn_conv2d_num_configs(void) { return kNumCfg; }
+
+int fcn_conv2d_config_lds_bytes(int cfg) { return cfg >= 0 && cfg < kNumCfg ? kCfgLdsBytes[cfg] : -1; }
 
 int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out) {
     return fcn_conv2d_group_prepare_fused(h_descs, n, nullptr, 0, d_workspace, cfg_request, h_out);

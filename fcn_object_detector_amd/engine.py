@@ -155,7 +155,7 @@ class Engine:
     def __init__(self, spec: NetSpec, data_shapes: Optional[Dict[str, Tuple[int, ...]]] = None,
                  params: Optional[Dict[str, List[np.ndarray]]] = None, device: int = 0,
                  fuse: bool = True, group_convs: bool = True, autotune: bool = True, dtype: str = "f32",
-                 tune_from: Optional["Engine"] = None):
+                 tune_from: Optional["Engine"] = None, tune_max_lds_kb: Optional[int] = None):
         if dtype not in ("f32", "f16"):
             raise ValueError("dtype must be 'f32' or 'f16'")
         if dtype == "f16" and spec.phase != "TEST":
@@ -168,6 +168,9 @@ class Engine:
         self.autotune = autotune
         self._chosen_cfgs: Dict[str, int] = {}          # grouped launch -> tile configuration the autotuner picked
         self._tune_from = tune_from                     # a replica of the same net: reuse its plan instead of timing again
+        # autotuner: only tile configurations whose workgroup holds at most this much LDS (engines that share the GPU with
+        # other streams: small footprints let workgroups of concurrent launches fit on a CU side by side)
+        self._tune_max_lds = int(tune_max_lds_kb if tune_max_lds_kb is not None else os.environ.get("FCN_TUNE_MAX_LDS_KB", "160")) * 1024
         L.call("fcn_init", device)
         sp = C.c_void_p()
         L.call("fcn_stream_create", C.byref(sp))
@@ -569,6 +572,8 @@ class Engine:
                 self._tune_cache = {}
         cache = getattr(self, "_tune_cache", None)
         key = "%s|%s" % (name, "x".join(str(d) for d in self.shapes.get(self.inputs[0], ())) if self.inputs else "")
+        if self._tune_max_lds < 160 * 1024:
+            key += "|lds%d" % (self._tune_max_lds // 1024)
         ncfg = int(L.load().fcn_conv2d_num_configs())
         if self._tune_from is not None and key in self._tune_from._chosen_cfgs:
             self._chosen_cfgs[key] = self._tune_from._chosen_cfgs[key]
@@ -599,6 +604,8 @@ class Engine:
         best, best_ms = -1, 1e30
         grp = L.ConvGroup()
         for cfg in range(int(lib.fcn_conv2d_num_configs())):
+            if int(lib.fcn_conv2d_config_lds_bytes(cfg)) > self._tune_max_lds:
+                continue
             L.call("fcn_conv2d_group_prepare_fused", arr, n, parr, npool, ws.ptr, cfg, C.byref(grp))
             for _ in range(2):
                 L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))
@@ -1036,14 +1043,19 @@ class ForwardPipeline:
     duration (one round of <= 600 workgroups, then a tail): a single stream leaves the MI355X half idle.  The pipeline keeps
     `depth` replicas of the engine - own stream, own activation arena, same weights and the first replica's tile plan - and
     hands consecutive frames to them round-robin, so the hardware queues interleave the launches of different frames
-    (measured: 2478 -> 3632 frames/s at depth 3; deeper is slower again).  Per-frame results are those of a lone engine,
-    bit for bit: the replicas run the same kernels on private buffers."""
+    How many workgroups of DIFFERENT launches fit on a CU is bounded by LDS, so the replicas' autotuner is restricted to tile
+    configurations of at most `max_lds_kb` per workgroup: this costs nothing on a lone stream (2530 frames/s either way) and
+    is worth +20 % once frames overlap.  Measured (8 hardware queues, see lib.load): 2530 frames/s one frame at a time,
+    4000-4130 with three in flight, 4300-4480 with four, 3400 with five.  Per-frame results are those of a lone engine
+    with the same tile plan, bit for bit: the replicas run the same kernels on private buffers."""
 
-    def __init__(self, make_spec: Callable[[], NetSpec], params: Optional[Dict[str, List[np.ndarray]]] = None, device: int = 0, depth: int = 3,
-                 **engine_kw):
+    def __init__(self, make_spec: Callable[[], NetSpec], params: Optional[Dict[str, List[np.ndarray]]] = None, device: int = 0, depth: int = 4,
+                 max_lds_kb: Optional[int] = 36, **engine_kw):
         if depth < 1:
             raise ValueError("depth must be at least 1")
         self.engines: List[Engine] = []
+        if max_lds_kb is not None:
+            engine_kw.setdefault("tune_max_lds_kb", max_lds_kb)
         for i in range(depth):
             self.engines.append(Engine(make_spec(), params=params, device=device, tune_from=self.engines[0] if i else None, **engine_kw))
         self._pending: List[Engine] = []
@@ -1082,24 +1094,41 @@ class ForwardPipeline:
             out.append(self.collect())
         return out
 
-    def run_resident(self, iters: int) -> float:
-        """`iters` forwards in total, round-robin over the replicas, on inputs already in HBM; wall-clock seconds from the
-        first launch to the last replica draining (benchmarks)."""
+    def calibrate(self, depths: Sequence[int] = (3, 4), iters: int = 60) -> int:
+        """Pick how many replicas run_resident() uses: how launches of different streams pack onto the hardware queues is
+        not monotonic in the number of streams, so the candidates are timed once (untimed warm-up work for a benchmark)."""
+        best, best_t = None, 1e30
+        for d in depths:
+            if 1 <= d <= len(self.engines):
+                self.run_resident(iters, depth=d)
+                t = self.run_resident(iters, depth=d)
+                if t < best_t:
+                    best, best_t = d, t
+        self.active = best or len(self.engines)
+        return self.active
+
+    def run_resident(self, iters: int, depth: Optional[int] = None) -> float:
+        """`iters` forwards in total, round-robin over the first `depth` replicas (default: calibrate()'s choice, else all),
+        on inputs already in HBM; wall-clock seconds from the first launch to the last replica draining (benchmarks)."""
         import time
         lib = L.load()
-        for e in self.engines:
+        engines = self.engines[:depth or getattr(self, "active", None) or len(self.engines)]
+        return self._run_resident(engines, iters, lib, time)
+
+    def _run_resident(self, engines, iters, lib, time) -> float:
+        for e in engines:
             if e.graph_core is None:
                 e.forward_resident(1)
             L.call("fcn_stream_sync", e.stream)
         no_graph = os.environ.get("FCN_NO_GRAPH", "0") not in ("", "0")
         t0 = time.perf_counter()
         for i in range(iters):
-            e = self.engines[i % len(self.engines)]
+            e = engines[i % len(engines)]
             if no_graph:
                 e.run_ops(e.stream)
             else:
                 L.check(lib.fcn_graph_launch(e.graph_core, e.stream))
-        for e in self.engines:
+        for e in engines:
             L.call("fcn_stream_sync", e.stream)
         return time.perf_counter() - t0
 

@@ -127,6 +127,9 @@ size_t fcn_conv2d_group_workspace_bytes(int n);
 /* cfg_request: -1 = built-in heuristic, 0 .. fcn_conv2d_num_configs()-1 = that tile configuration (the engine
  * times every configuration once per launch at plan time and keeps the fastest) */
 int  fcn_conv2d_num_configs(void);
+/* LDS bytes one workgroup of that configuration holds (a CU has 160 KiB: it bounds how many workgroups - of this or of a
+ * concurrent launch on another stream - fit on a CU); -1 for an unknown index */
+int  fcn_conv2d_config_lds_bytes(int cfg);
 int  fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out);
 int  fcn_conv2d_fwd_group_f32(const fcn_conv_group* h_group, fcn_stream_t s);
 /* MAX poolings that read the same bottoms as the group's convolutions (an inception module's 3x3 stride-1 pool beside

@@ -53,7 +53,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [str(i) for i in range(17)] + [None])
+@pytest.mark.parametrize("cfg", [str(i) for i in range(23)] + [None])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_matches_oracle(gpu, monkeypatch, case, cfg):
     cin, cout, k, s, p, h, w, n = case

@@ -18,7 +18,8 @@ spec = NetSpec(msg, "TEST")
 spec.infer()
 params = fill_params(spec, seed=1234)
 lib = L.load()
-for k in (1, 2, 3, 4):
+import os
+for k in [int(v) for v in os.environ.get('DEPTHS', '1,2,3,4').split(',')]:
     engs = [Engine(NetSpec(msg, "TEST"), params=params, device=0) for _ in range(k)]
     for e in engs:
         e.host_array("data")[...] = np.random.default_rng(0).random((1, 3, 448, 448), dtype=np.float32)
