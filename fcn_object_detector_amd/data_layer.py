@@ -391,6 +391,7 @@ class DataArgumentationLayer(Layer):
             renderer.render(index, plan)
             all_rects.append(plan["rects"])
             all_labels.append(plan["labels"])
+        renderer.commit()
         self.last_rects, self.last_labels = all_rects, all_labels
         if getattr(self, "device_targets", False):
             return              # the solver hands last_rects to TrainEngine.set_targets: labels are generated in HBM
@@ -432,6 +433,47 @@ class DeviceRenderer(object):
         self.aug_b = [DeviceBuffer(h * w * 3, zero=False) for _ in range(n)]
         self.aug_f32 = DeviceBuffer(h * w * 3 * 4, zero=False)                    # Gaussian blur: row pass result (stream ordered)
         self.final = [None] * n
+        # The renders run on their own stream into a staging copy of `data`, so that they overlap the training step that is
+        # still reading the blob (conv1's weight gradient needs `data` until the very end of backward); commit() hands the
+        # batch over on the engine's stream: wait for the renders, one device copy, the class-mask tops.
+        sp = C.c_void_p()
+        L.call("fcn_stream_create", C.byref(sp))
+        self.side = sp
+        self.stage = DeviceBuffer(self._blob_bytes(self.data), zero=True)
+        self.ev_rendered, self.ev_taken = C.c_void_p(), C.c_void_p()
+        L.call("fcn_event_create", C.byref(self.ev_rendered))
+        L.call("fcn_event_create", C.byref(self.ev_taken))
+        self._taken_pending = False
+        self._batch_open = False
+
+    @staticmethod
+    def _blob_bytes(b) -> int:
+        n, c, H, W = b.shape
+        return n * H * W * b.cstride * 4
+
+    def begin_batch(self) -> None:
+        """First render of a batch: the staging buffer and the per-slot scratch must have been consumed by the last commit()."""
+        if self._taken_pending:
+            self.L.call("fcn_stream_wait_event", self.side, self.ev_taken)
+            self._taken_pending = False
+        self._batch_open = True
+
+    def commit(self) -> None:
+        """Hand the rendered batch to the engine (on the engine's stream, i.e. behind whatever step is still running)."""
+        L, lay, st = self.L, self.layer, self.engine.stream
+        L.call("fcn_event_record", self.ev_rendered, self.side)
+        L.call("fcn_stream_wait_event", st, self.ev_rendered)
+        d = self.data
+        n, c, H, W = d.shape
+        L.call("fcn_memcpy_d2d_async", d.ptr, self.stage.ptr, self._blob_bytes(d), st)
+        if self.label is not None:
+            lb = self.label
+            for index in range(n):
+                L.call("fcn_mask_to_label_f32", self.mask[index].ptr, lay.SCENE_H, lay.SCENE_W, lb.ptr + 4 * index * H * W * lb.cstride, H, W,
+                       lb.cstride, st)
+        L.call("fcn_event_record", self.ev_taken, st)
+        self._taken_pending = True
+        self._batch_open = False
 
     def _upload(self, arr: np.ndarray):
         a = np.ascontiguousarray(arr)
@@ -449,7 +491,10 @@ class DeviceRenderer(object):
         return e
 
     def render(self, index: int, plan: dict) -> None:
-        L, C, lay, st = self.L, self.C, self.layer, self.engine.stream
+        """Enqueue the pixel work of one planned sample on the render stream (commit() makes the batch visible)."""
+        L, C, lay, st = self.L, self.C, self.layer, self.side
+        if not self._batch_open:
+            self.begin_batch()
         recs = self.recs_host[index]
         objs = plan["objects"][:4]
         for i, o in enumerate(objs):
@@ -477,11 +522,8 @@ class DeviceRenderer(object):
         self.final[index] = (img, vh, vw)
         d = self.data
         n, c, H, W = d.shape
-        L.call("fcn_preprocess_bgr8", img.ptr, vh, vw, d.ptr + 4 * index * H * W * d.cstride, H, W, d.cstride,
+        L.call("fcn_preprocess_bgr8", img.ptr, vh, vw, self.stage.ptr + 4 * index * H * W * d.cstride, H, W, d.cstride,
                float(getattr(d, "upload_shift", 0.0) or 0.0), self.minmax.ptr, st)
-        if self.label is not None:
-            lb = self.label
-            L.call("fcn_mask_to_label_f32", self.mask[index].ptr, SH, SW, lb.ptr + 4 * index * H * W * lb.cstride, H, W, lb.cstride, st)
 
     def _color(self, index: int, img, h: int, w: int, color: dict, st):
         """color_space_argumentation on the device: blur (one of three) then the fused Sharpen/Add/Multiply/Grayscale pass;
@@ -513,7 +555,7 @@ class DeviceRenderer(object):
         buf, h, w = self.final[index]
         img = np.empty((h, w, 3), np.uint8)
         msk = np.empty((lay.SCENE_H, lay.SCENE_W), np.uint8)
-        self.L.call("fcn_memcpy_d2h_async", img.ctypes.data, buf.ptr, img.nbytes, self.engine.stream)
-        self.L.call("fcn_memcpy_d2h_async", msk.ctypes.data, self.mask[index].ptr, msk.nbytes, self.engine.stream)
-        self.L.call("fcn_stream_sync", self.engine.stream)
+        self.L.call("fcn_memcpy_d2h_async", img.ctypes.data, buf.ptr, img.nbytes, self.side)
+        self.L.call("fcn_memcpy_d2h_async", msk.ctypes.data, self.mask[index].ptr, msk.nbytes, self.side)
+        self.L.call("fcn_stream_sync", self.side)
         return img, msk

@@ -20,7 +20,7 @@ import numpy as np
 
 from . import lib as L
 from . import proto
-from .engine import Blob, DevView, DeviceBuffer, Engine, Op, _r4
+from .engine import Blob, DevView, DeviceBuffer, Engine, Op, PinnedArray, _r4
 from .netspec import DATA_TYPES, LOSS_TYPES, Layer, NetSpec, kernel_stride_pad
 
 F32 = np.float32
@@ -131,7 +131,10 @@ class TrainEngine(Engine):
         self.segs_dev = DeviceBuffer(max(C.sizeof(segs), 16), zero=False)
         L.call("fcn_memcpy_h2d_async", self.segs_dev.ptr, C.addressof(segs), C.sizeof(segs), None)
         L.call("fcn_device_sync")
-        self.loss_host = {name: np.zeros(1, F32) for name in self.loss_blobs}
+        # pinned: the loss read-back at the end of step_begin() must not hold the host thread until the step has run (a
+        # pageable destination makes the "async" copy synchronous, and the next batch could not be prepared meanwhile)
+        self._loss_pinned = {name: PinnedArray((1,)) for name in self.loss_blobs}
+        self.loss_host = {name: p.array for name, p in self._loss_pinned.items()}
 
     def _grad_view(self, layer: str, index: int) -> DevView:
         for e in self.param_layout:

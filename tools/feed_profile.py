@@ -62,3 +62,29 @@ with tempfile.TemporaryDirectory() as tmp:
     s.step(50, pipeline=True)
     L.call("fcn_stream_sync", s.engine.stream)
     print("pipelined solver iteration %.3f ms" % ((time.perf_counter() - t0) / 50 * 1e3))
+    # where the pipelined iteration spends its host time
+    tb = tf = te = 0.0
+    n = 30
+    s._feed()
+    for _ in range(n):
+        t0 = time.perf_counter()
+        s.engine.step_begin()
+        t1 = time.perf_counter()
+        s._feed()
+        t2 = time.perf_counter()
+        s.engine.step_end()
+        t3 = time.perf_counter()
+        tb += t1 - t0
+        tf += t2 - t1
+        te += t3 - t2
+    print("pipelined loop: step_begin %.3f ms, feed %.3f ms, step_end (wait) %.3f ms, total %.3f ms" % (tb / n * 1e3, tf / n * 1e3, te / n * 1e3, (tb + tf + te) / n * 1e3))
+    tb = te = 0.0
+    for _ in range(n):
+        t0 = time.perf_counter()
+        s.engine.step_begin()
+        t1 = time.perf_counter()
+        s.engine.step_end()
+        t3 = time.perf_counter()
+        tb += t1 - t0
+        te += t3 - t1
+    print("no feed:        step_begin %.3f ms, step_end (wait) %.3f ms, total %.3f ms" % (tb / n * 1e3, te / n * 1e3, (tb + te) / n * 1e3))
