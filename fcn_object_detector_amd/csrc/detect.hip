@@ -8,8 +8,9 @@
 //          (wavefront ballot + popcount prefix, so candidate order == np.where order);
 //       b. candidate = (double)bbox + cell origin, converted to int like the Python->Rect converter;
 //       c. connected components of the SimilarRects relation with a lock-free union-find in LDS
-//          whose roots are always the smallest member index, so "classes numbered by first member"
-//          falls out as the ascending order of roots;
+//          (path halving) whose roots are always the smallest member index, so "classes numbered by
+//          first member" falls out as the ascending order of roots; the M^2/2 similarity tests run
+//          from LDS in 64 x 64 blocks dealt round-robin to the 16 waves;
 //       d. integer sums per component (LDS atomics: exact and order-independent), float mean with
 //          round-half-even, the n <= groupThreshold and containment filters, the height filter of
 //          vote_boxes, and an ordered compaction of the survivors.
@@ -27,6 +28,7 @@ namespace {
 constexpr int kDetThreads = 1024;
 constexpr int kDetWaves = kDetThreads / 64;
 constexpr int kMaxCand = 4096;  // LDS capacity: parent + count + 4 sums = 6 * 16 KiB
+constexpr int kMaxBig = kMaxCand / 2;   // classes with n > groupThreshold >= 1 members: at most M / 2
 
 struct DetP {
     fcn_detect_params p;
@@ -65,13 +67,18 @@ __device__ __forceinline__ int block_excl_scan(bool flag, int* wsum /*[kDetWaves
     return base + within;
 }
 
-__device__ __forceinline__ int uf_find(const int* parent, int x) {
-    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    while (p != x) {
-        x = p;
-        p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+// Lock-free find with path halving.  Invariant: parent[x] <= x and only a ROOT is ever hooked (CAS expecting parent[a] == a),
+// so re-pointing a non-root at its grandparent - another ancestor - races with nothing: concurrent halvings all write
+// ancestors, and a CAS on a non-root fails whatever it holds.  Without it the chains of a dense cluster grow to O(M).
+__device__ __forceinline__ int uf_find(int* parent, int x) {
+    while (true) {
+        const int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p == x) return x;
+        const int gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (gp == p) return p;
+        __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        x = gp;
     }
-    return x;
 }
 
 // union keeping the smaller index as root
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
     __shared__ int parent[kMaxCand];
     __shared__ int cnt[kMaxCand];
     __shared__ int sum[4][kMaxCand];
+    __shared__ int bdx[kMaxBig], bdy[kMaxBig];      // containment margins of the classes with n > groupThreshold
     __shared__ int wsum[kDetWaves];
     __shared__ int s_any;
 
@@ -166,16 +174,51 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
     }
 
     // ---- c: partition(): union every SimilarRects pair ----------------------------------------
-    for (int i = 0; i < M; ++i) {
-        const int xi = rects[0 * G + i], yi = rects[1 * G + i], wi = rects[2 * G + i], hi = rects[3 * G + i];
-        for (int j = i + 1 + tid; j < M; j += kDetThreads) {
-            const int xj = rects[0 * G + j], yj = rects[1 * G + j], wj = rects[2 * G + j], hj = rects[3 * G + j];
-            const double delta = d.eps * (double)(min(wi, wj) + min(hi, hj)) * 0.5;
-            if ((double)abs(xi - xj) <= delta && (double)abs(yi - yj) <= delta && (double)abs(xi + wi - xj - wj) <= delta &&
-                (double)abs(yi + hi - yj - hj) <= delta)
-                uf_union(parent, i, j);
+    // M^2/2 tests (307 k for a full 28x28 grid): the candidates are staged in LDS - the four sum planes are free until
+    // step d - and lane j keeps its own rectangle in registers while all lanes of a wave walk the same i (an LDS
+    // broadcast), so a test costs four LDS reads and a handful of double operations instead of eight global loads.
+    int4* cand = reinterpret_cast<int4*>(&sum[0][0]);           // 4 planes x kMaxCand ints == kMaxCand int4
+    for (int i = tid; i < M; i += kDetThreads) cand[i] = make_int4(rects[0 * G + i], rects[1 * G + i], rects[2 * G + i], rects[3 * G + i]);
+    // floor(eps * s * 0.5) for s = min(w) + min(h) in [0, kMaxCand): the count plane is idle until step d
+    for (int sidx = tid; sidx < kMaxCand; sidx += kDetThreads) cnt[sidx] = (int)floor(fmin(d.eps * (double)sidx * 0.5, 2147483647.0));
+    __syncthreads();
+    // Work items of 64 x 64 tests (lane = one j of a 64-wide block, loop over a 64-wide block of i <= j) dealt round-robin to
+    // the waves: the triangle is balanced over the 16 waves.  The differences are integers, so |d| <= delta (a double) is
+    // |d| <= floor(delta): one double product and one conversion per pair, then integer compares.
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int nb = (M + 63) >> 6;
+        int item = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int j = (b << 6) + lane;
+            const int4 rj = cand[j < M ? j : 0];
+            const int rjx = rj.x + rj.z, rjy = rj.y + rj.w;
+            for (int c = 0; c <= b; ++c, ++item) {
+                if ((item & (kDetWaves - 1)) != wave) continue;
+                const int i0 = c << 6;
+                const int i1 = min(min(i0 + 64, M), j < M ? j : 0);      // this lane's tests of the item: i0 <= i < min(i1, j)
+                const int iw = min(i0 + 64, M);                           // the wave walks the whole block
+#pragma unroll 4
+                for (int i = i0; i < iw; ++i) {
+                    const int4 ri = cand[i];
+                    const int sm = min(ri.z, rj.z) + min(ri.w, rj.w);
+                    int t;
+                    if ((unsigned)sm < (unsigned)kMaxCand) {
+                        t = cnt[sm];
+                    } else {            // sizes outside the table (or negative: delta < 0, nothing is similar)
+                        const double delta = d.eps * (double)sm * 0.5;
+                        t = delta < 0.0 ? -1 : (int)floor(fmin(delta, 2147483647.0));
+                    }
+                    // one predicate, no short-circuit branches: max of the four distances against t
+                    const int far = max(max(abs(ri.x - rj.x), abs(ri.y - rj.y)), max(abs(ri.x + ri.z - rjx), abs(ri.y + ri.w - rjy)));
+                    if ((far <= t) & (i < i1)) uf_union(parent, i, j);
+                }
+            }
         }
     }
+    __syncthreads();
+    for (int i = tid; i < M; i += kDetThreads) sum[0][i] = sum[1][i] = sum[2][i] = sum[3][i] = 0;
+    for (int i = tid; i < kMaxCand; i += kDetThreads) cnt[i] = 0;
     __syncthreads();
 
     // ---- d: per-class integer sums -------------------------------------------------------------
@@ -211,6 +254,25 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
     }
     __syncthreads();
 
+    // Only classes with n > groupThreshold can contain another one: they are compacted first (parent[] is free now and
+    // becomes their root list; their containment margins are rounded once), so the O(nc^2) scan of the reference
+    // becomes O(nc * nk).  "Contained in SOME other class" does not depend on the scan order.
+    int nk = 0;
+    for (int base = 0; base < nc; base += kDetThreads) {
+        const int ci = base + tid;
+        const int r = ci < nc ? list[ci] : 0;
+        const bool big = ci < nc && cnt[r] > P.group_thresh;
+        int tot;
+        const int at = nk + block_excl_scan(big, wsum, &tot);
+        __syncthreads();            // every root test of this pass is done before parent[] is overwritten
+        if (big && at < kMaxBig) {
+            parent[at] = r;
+            bdx[at] = round_coord((double)sum[2][r] * d.eps, FCN_RECT_ROUND_NEAREST_EVEN);
+            bdy[at] = round_coord((double)sum[3][r] * d.eps, FCN_RECT_ROUND_NEAREST_EVEN);
+        }
+        nk += tot;
+    }
+    __syncthreads();
     // filters + ordered emission
     int outn = 0;
     for (int base = 0; base < nc; base += kDetThreads) {
@@ -223,13 +285,12 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
             if (n1 > P.group_thresh) {
                 const int x1 = sum[0][r1], y1 = sum[1][r1], w1 = sum[2][r1], h1 = sum[3][r1];
                 keep = true;
-                for (int cj = 0; cj < nc; ++cj) {
-                    const int r2 = list[cj];
+                for (int k = 0; k < nk; ++k) {
+                    const int r2 = parent[k];
+                    if (r2 == r1) continue;
                     const int n2 = cnt[r2];
-                    if (cj == ci || n2 <= P.group_thresh) continue;
                     const int x2 = sum[0][r2], y2 = sum[1][r2], w2 = sum[2][r2], h2 = sum[3][r2];
-                    const int dx = round_coord((double)w2 * d.eps, FCN_RECT_ROUND_NEAREST_EVEN);
-                    const int dy = round_coord((double)h2 * d.eps, FCN_RECT_ROUND_NEAREST_EVEN);
+                    const int dx = bdx[k], dy = bdy[k];
                     if (x1 >= x2 - dx && y1 >= y2 - dy && x1 + w1 <= x2 + w2 + dx && y1 + h1 <= y2 + h2 + dy &&
                         (n2 > max(3, n1) || n1 < 3)) {
                         keep = false;

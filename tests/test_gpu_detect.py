@@ -235,3 +235,31 @@ def test_batched_detector_pipeline(gpu):
             assert np.array_equal(gb, wb) and np.array_equal(gl, wl)
     pipe.close()
     lone.engine.close()
+
+
+@pytest.mark.parametrize("grid,stride,c", [(28, 16, 2), (56, 8, 1)])
+def test_detect_every_cell_fires(gpu, grid, stride, c):
+    """Worst case of the clustering kernel: every cell is a candidate (M = 784 / 3136, hundreds of thousands of
+    SimilarRects tests, dense and sparse neighbourhoods), as an untrained net produces."""
+    rng = np.random.default_rng(grid)
+    cvg = (0.5 + 0.5 * rng.random((1, c, grid, grid))).astype(np.float32)
+    bb = (rng.standard_normal((1, 4 * c, grid, grid)) * 6).astype(np.float32)            # boxes ~ cell origin: many chains of neighbours
+    assert check(cvg, bb, grid * stride, stride) >= 0
+    bb2 = bb.copy()
+    bb2[0, 2::4] += 60
+    bb2[0, 3::4] += 45                                                                     # a real extent: clusters of overlapping votes
+    assert check(cvg, bb2, grid * stride, stride, min_boxes=2) > 0
+    assert check(cvg, bb2, grid * stride, stride, eps=1.5) >= 0                            # everything similar to everything nearby
+
+
+def test_detect_sizes_outside_the_margin_table(gpu):
+    """min(w) + min(h) beyond the kernel's 4096-entry floor(delta) table and negative sizes take the arithmetic path."""
+    rng = np.random.default_rng(3)
+    cvg = np.zeros((1, 1, 28, 28), np.float32)
+    bb = np.zeros((1, 4, 28, 28), np.float32)
+    for k, (cy, cx) in enumerate([(2, 3), (2, 4), (3, 3), (3, 4), (2, 5), (10, 10), (10, 11), (11, 10), (11, 11), (12, 12)]):
+        cvg[0, 0, cy, cx] = 0.9
+        big = k < 5
+        base = np.array([40, 30, 5200, 4700], np.float32) if big else np.array([-300, -200, -90, -70], np.float32)
+        bb[0, :, cy, cx] = base - np.array([cx * 16, cy * 16, cx * 16, cy * 16], np.float32) + rng.integers(-3, 4, 4)
+    assert check(cvg, bb, 448, 16, min_boxes=2) >= 1          # the large boxes group; negative sizes never do (delta < 0)
