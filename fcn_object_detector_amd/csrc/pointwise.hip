@@ -153,6 +153,17 @@ __device__ __forceinline__ float pow_neg_beta(float s, float beta) {
     return powf(s, -beta);
 }
 
+// The same for results that are rounded to half precision: the hardware reciprocal square root and square root (1 ulp of
+// float32, far below half an f16 ulp) instead of the correctly rounded sequences - the f16 LRN is ALU-bound otherwise
+// (8 outputs per lane, two IEEE square roots and a division each: 114 us for conv2/norm2 at batch 32, 2.7 TB/s).
+__device__ __forceinline__ float pow_neg_beta_fast(float s, float beta) {
+    if (beta == 0.75f) {
+        const float r = __builtin_amdgcn_rsqf(s);
+        return r * __builtin_amdgcn_sqrtf(r);
+    }
+    return powf(s, -beta);
+}
+
 __global__ __launch_bounds__(256) void lrn5_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ scale,
                                                    long long pixels, int C, int x_cstride, int y_cstride, float alpha_over_n,
                                                    float beta, float kk) {
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(256) void lrn5_f16_kernel(const _Float16* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float s = kk + alpha_over_n * (q[e] + q[e + 1] + q[e + 2] + q[e + 3] + q[e + 4]);
-            o[e] = (_Float16)((float)c[e] * pow_neg_beta(s, beta));
+            o[e] = (_Float16)((float)c[e] * pow_neg_beta_fast(s, beta));
         }
         *(h8_t*)(y + (size_t)pix * y_cstride + g * 8) = o;
     }
