@@ -75,7 +75,7 @@ class DetectParams(C.Structure):
     ]
 
 
-CONV_RELU, CONV_SIGMOID2, CONV_ACCUM, CONV_OUT_F32, CONV_F16, CONV_OUT_F16, CONV_MASK = 1, 2, 4, 8, 16, 32, 64
+CONV_RELU, CONV_SIGMOID2, CONV_ACCUM, CONV_OUT_F32, CONV_F16, CONV_OUT_F16, CONV_MASK, CONV_NO_KSPLIT = 1, 2, 4, 8, 16, 32, 64, 128
 ELT_PROD, ELT_SUM, ELT_MAX = 0, 1, 2
 RECT_ROUND_NEAREST_EVEN, RECT_ROUND_TRUNCATE = 0, 1
 
@@ -115,6 +115,7 @@ PROTOTYPES = {
     "fcn_conv2d_group_workspace_bytes": (_sz, [_i]),
     "fcn_conv2d_num_configs": (_i, []),
     "fcn_conv2d_config_lds_bytes": (_i, [_i]),
+    "fcn_conv2d_config_waves_k": (_i, [_i]),
     "fcn_conv2d_group_prepare": (_i, [C.POINTER(ConvDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),
     "fcn_conv2d_group_prepare_fused": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(PoolDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),
     "fcn_conv2d_fwd_group_f32": (_i, [C.POINTER(ConvGroup), _vp]),

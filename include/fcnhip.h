@@ -91,6 +91,7 @@ int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int
 #define FCN_CONV_RELU      1   /* y = max(y, 0)                                  */
 #define FCN_CONV_SIGMOID2  2   /* y2 = sigmoid(y) is written as well (y2 != NULL) */
 #define FCN_CONV_ACCUM     4   /* y += result (gradient fan-in when the kernel runs as a data-gradient pass) */
+#define FCN_CONV_NO_KSPLIT 128 /* planning hint: the built-in heuristic keeps to tile configurations without a K split */
 #define FCN_CONV_MASK     64   /* y = (y2 > 0) ? result : 0 with y2 read at the result's position (y2_cstride / y2_coffset): the ReLU
                                 * backward of the layer below, applied by the LAST data-gradient pass that writes its gradient   */
 #define FCN_CONV_OUT_F32   8   /* with FCN_CONV_F16: y is float32 (the detection heads feed the f32 decode kernel)   */
@@ -130,6 +131,8 @@ int  fcn_conv2d_num_configs(void);
 /* LDS bytes one workgroup of that configuration holds (a CU has 160 KiB: it bounds how many workgroups - of this or of a
  * concurrent launch on another stream - fit on a CU); -1 for an unknown index */
 int  fcn_conv2d_config_lds_bytes(int cfg);
+/* how many waves of a workgroup split K and reduce through LDS in that configuration (1 = no K split); -1 for an unknown index */
+int  fcn_conv2d_config_waves_k(int cfg);
 int  fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out);
 int  fcn_conv2d_fwd_group_f32(const fcn_conv_group* h_group, fcn_stream_t s);
 /* MAX poolings that read the same bottoms as the group's convolutions (an inception module's 3x3 stride-1 pool beside

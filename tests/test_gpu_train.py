@@ -155,3 +155,42 @@ def test_reference_lmdb_fronted_net_equals_python_layer_net(gpu):
     for name in ("conv1/7x7_s2", "inception_4a/1x1", "bbox/regressor"):
         assert rel_err(g_got[name][0], g_want[name][0]) < 1e-5, name
     leng.close()
+
+
+def test_two_stream_step_is_deterministic(gpu, tmp_path):
+    """The weight gradients run on a second stream beside the data-gradient chain: 40 short runs from identical
+    state and data give identical losses, within rounding of the single-stream step.  (This is the check that found the
+    K-split reduction of the convolution kernel reading stale partial sums when a weight-gradient kernel shares its CU.)"""
+    import os
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fcn_object_detector_amd", "python"))
+    from fcn_object_detector_amd.solver import Solver
+    net = tmp_path / "t.prototxt"
+    net.write_text(models.googlenet_detectnet_train("data_argumentation_layer", "DataArgumentationLayer", "128,96,16,2,2,synthetic:2,detectnet",
+                                                    num_classes=2))
+    sol = tmp_path / "s.prototxt"
+    sol.write_text('net: "%s"\nbase_lr: 1e-4\nmomentum: 0.9\nweight_decay: 1e-6\nlr_policy: "fixed"\ndisplay: 0\nmax_iter: 100\nsnapshot: 0\n' % net)
+
+    def run():
+        s = Solver(str(sol), device=0, log=None, autotune=False)
+        random.seed(5)
+        s.py_layers[0][1]._color_rng = np.random.default_rng(1234)
+        out = [s.step(1)["loss"] for _ in range(3)]
+        s.close()
+        return out
+
+    old = os.environ.get("FCN_WGRAD_STREAM")
+    try:
+        os.environ["FCN_WGRAD_STREAM"] = "0"
+        single = run()
+        os.environ["FCN_WGRAD_STREAM"] = "1"
+        ref = run()
+        assert np.allclose(ref, single, rtol=1e-5)      # (the two modes may pick different tile shapes: last-bit differences only)
+        for i in range(40):
+            assert run() == ref, i
+    finally:
+        if old is None:
+            os.environ.pop("FCN_WGRAD_STREAM", None)
+        else:
+            os.environ["FCN_WGRAD_STREAM"] = old
