@@ -247,7 +247,7 @@ def bench_detector_stream(local: int, msg, params, n_frames: int = 300):
     from fcn_object_detector_amd.engine import Engine
     from fcn_object_detector_amd.netspec import NetSpec
     frames = [np.random.default_rng(i).integers(0, 256, (480, 640, 3), dtype=np.uint8) for i in range(8)]
-    pipe = DetectorPipeline(lambda first: Engine(NetSpec(msg, "TEST"), params=params, device=local, tune_from=first, tune_max_lds_kb=48),
+    pipe = DetectorPipeline(lambda first: Engine(NetSpec(msg, "TEST"), params=params, device=local, tune_from=first, tune_max_lds_kb=36),
                             depth=4, mapping=HeadMapping.detectnet_deploy())
     lone = pipe.detectors[0]
     for f in frames:

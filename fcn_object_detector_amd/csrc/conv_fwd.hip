@@ -183,12 +183,7 @@ struct Cfg {
     static constexpr int RING_FLOATS = NBUF * BUF_FLOATS;
     static constexpr int RED_FLOATS = WAVES_M * WAVES_N * (WAVES_K - 1) * WTM * WTN * 16 * 64;
     static constexpr int RING_OR_RED_FLOATS = RING_FLOATS > RED_FLOATS ? RING_FLOATS : RED_FLOATS;
-    // The K-split reduction scratch lies BEHIND the ring, not over it.  Overlaying it (12 KiB less LDS) is legal by the
-    // vmcnt + barrier rules and passed every single-stream test, but with a weight-gradient kernel of another stream
-    // resident on the same CU the reduction read 1 KiB runs of stale partial sums in ~13 % of training steps
-    // (tools/race_hunt*.py); behind the ring that drops to ~0.2 %, and the training engine avoids K-split tiles while
-    // its second stream is on (FCN_CONV_NO_KSPLIT).
-    static constexpr int LDS_FLOATS = RING_FLOATS + RED_FLOATS;
+    static constexpr int LDS_FLOATS = RING_OR_RED_FLOATS;
     static_assert(BK == 32 || BK == 64, "row swizzle is defined for 8 or 16 slots per row");
     static_assert((BK / 8) % WAVES_K == 0, "each wave needs whole k-steps of a chunk");
     static_assert(STEP % 16 == 0, "a lane's rows must agree mod 16 so that its swizzle (and k position) is the same for all of them");
@@ -484,12 +479,18 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         }
     }
     wait_vmcnt<0>();                   // the all-zero chunks issued past K must land before the ring is reused
+    // The last iteration prefetched the fragments of a chunk that does not exist, with inline-asm ds_reads the compiler
+    // cannot see: nothing waits for them, their destination registers are dead, and the register allocator hands those
+    // registers to the epilogue (the accumulator copies).  A read that returns late - LDS contended by a co-resident
+    // kernel of another stream - then overwrites four consecutive accumulator copies AFTER v_accvgpr_read filled them:
+    // a 32-column x 4-register block of stale partial sums (tools/race_hunt3.py found it).  Retire them.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     // ---- K-split reduction across the wk waves of one (wm, wn) -------------------------------
     if (WAVES_K > 1) {
-        float* red = smem + Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::RING_FLOATS;
+        float* red = smem;
         if (wk > 0) {
             float* dst = red + ((size_t)((wm * WAVES_N + wn) * (WAVES_K - 1) + (wk - 1)) * WTM * WTN * 16) * 64 + lane;
 #pragma unroll
@@ -691,10 +692,7 @@ int choose_cfg(const ConvP* ps, int n) {
     if (force && force[0] >= '0' && force[0] <= '9' && atoi(force) < kNumCfg) return atoi(force);
     int best = 0;
     double best_cost = 1e300;
-    bool no_ksplit = false;
-    for (int i = 0; i < n; ++i) no_ksplit |= (ps[i].flags & FCN_CONV_NO_KSPLIT) != 0;
     for (int c = 0; c < kNumCfg; ++c) {
-        if (no_ksplit && kCfgWavesK[c] > 1) continue;
         const double bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = kCfgs[c].bk;
         const double mf = bm * bn * bk / 128.0, ld = (bm + bn) * bk * 4.0 / 12.0;
         const double per_chunk = (mf > ld ? mf : ld) + 150.0 + (kCfgs[c].prefetch ? 0.0 : 200.0 * bk / 8.0);

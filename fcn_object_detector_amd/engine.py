@@ -603,11 +603,8 @@ class Engine:
         e0, e1 = self._tune_events
         best, best_ms = -1, 1e30
         grp = L.ConvGroup()
-        no_ksplit = any(arr[i].flags & L.CONV_NO_KSPLIT for i in range(n))
         for cfg in range(int(lib.fcn_conv2d_num_configs())):
             if int(lib.fcn_conv2d_config_lds_bytes(cfg)) > self._tune_max_lds:
-                continue
-            if no_ksplit and int(lib.fcn_conv2d_config_waves_k(cfg)) > 1:
                 continue
             L.call("fcn_conv2d_group_prepare_fused", arr, n, parr, npool, ws.ptr, cfg, C.byref(grp))
             for _ in range(2):
@@ -1048,12 +1045,12 @@ class ForwardPipeline:
     hands consecutive frames to them round-robin, so the hardware queues interleave the launches of different frames
     How many workgroups of DIFFERENT launches fit on a CU is bounded by LDS, so the replicas' autotuner is restricted to tile
     configurations of at most `max_lds_kb` per workgroup: this costs nothing on a lone stream (2530 frames/s either way) and
-    is worth +15-20 % once frames overlap.  Measured (8 hardware queues, see lib.load): 2530 frames/s one frame at a time,
-    ~4000 with three in flight, 4200-4300 with four, 3400 with five.  Per-frame results are those of a lone engine
+    is worth +20 % once frames overlap.  Measured (8 hardware queues, see lib.load): 2530 frames/s one frame at a time,
+    4000-4130 with three in flight, 4300-4480 with four, 3400 with five.  Per-frame results are those of a lone engine
     with the same tile plan, bit for bit: the replicas run the same kernels on private buffers."""
 
     def __init__(self, make_spec: Callable[[], NetSpec], params: Optional[Dict[str, List[np.ndarray]]] = None, device: int = 0, depth: int = 4,
-                 max_lds_kb: Optional[int] = 48, **engine_kw):
+                 max_lds_kb: Optional[int] = 36, **engine_kw):
         if depth < 1:
             raise ValueError("depth must be at least 1")
         self.engines: List[Engine] = []

@@ -75,7 +75,7 @@ class DetectParams(C.Structure):
     ]
 
 
-CONV_RELU, CONV_SIGMOID2, CONV_ACCUM, CONV_OUT_F32, CONV_F16, CONV_OUT_F16, CONV_MASK, CONV_NO_KSPLIT = 1, 2, 4, 8, 16, 32, 64, 128
+CONV_RELU, CONV_SIGMOID2, CONV_ACCUM, CONV_OUT_F32, CONV_F16, CONV_OUT_F16, CONV_MASK = 1, 2, 4, 8, 16, 32, 64
 ELT_PROD, ELT_SUM, ELT_MAX = 0, 1, 2
 RECT_ROUND_NEAREST_EVEN, RECT_ROUND_TRUNCATE = 0, 1
 

@@ -258,11 +258,6 @@ class TrainEngine(Engine):
                 d.y2, d.y2_cstride, d.y2_coffset = act.buf.ptr, act.cstride, act.coffset
                 d.flags |= L.CONV_MASK
                 ops.remove(rop)
-            if self._wgrad_stream() is not None:
-                # these launches share the GPU with the weight-gradient stream: no K-split tiles (see Cfg::LDS_FLOATS in conv_fwd.hip)
-                for rec in dgrad_records:
-                    for dd in rec["descs"]:
-                        dd.flags |= L.CONV_NO_KSPLIT
             for rec in dgrad_records:
                 n_ = len(rec["descs"])
                 arr = (L.ConvDesc * n_)(*rec["descs"])

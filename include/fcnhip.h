@@ -91,7 +91,6 @@ int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int
 #define FCN_CONV_RELU      1   /* y = max(y, 0)                                  */
 #define FCN_CONV_SIGMOID2  2   /* y2 = sigmoid(y) is written as well (y2 != NULL) */
 #define FCN_CONV_ACCUM     4   /* y += result (gradient fan-in when the kernel runs as a data-gradient pass) */
-#define FCN_CONV_NO_KSPLIT 128 /* planning hint: the built-in heuristic keeps to tile configurations without a K split */
 #define FCN_CONV_MASK     64   /* y = (y2 > 0) ? result : 0 with y2 read at the result's position (y2_cstride / y2_coffset): the ReLU
                                 * backward of the layer below, applied by the LAST data-gradient pass that writes its gradient   */
 #define FCN_CONV_OUT_F32   8   /* with FCN_CONV_F16: y is float32 (the detection heads feed the f32 decode kernel)   */

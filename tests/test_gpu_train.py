@@ -160,7 +160,7 @@ def test_reference_lmdb_fronted_net_equals_python_layer_net(gpu):
 def test_two_stream_step_is_deterministic(gpu, tmp_path):
     """The weight gradients run on a second stream beside the data-gradient chain: 40 short runs from identical
     state and data give identical losses, within rounding of the single-stream step.  (This is the check that found the
-    K-split reduction of the convolution kernel reading stale partial sums when a weight-gradient kernel shares its CU.)"""
+    convolution kernel's un-waited tail prefetch overwriting accumulator copies when a weight-gradient kernel shares its CU.)"""
     import os
     import random
     import sys
