@@ -184,7 +184,7 @@ def bench_infer32(local: int, dtype: str, reps: int = 10):
     """BASELINE configs[4]: 32 uint8 frames resident in HBM -> pre-processing -> one forward -> one fused decode +
     groupRectangles launch for all (image, class) pairs -> boxes on the host (FCNObjectDetector.run_detector_batch minus
     the frame upload).  dtype "f16": activations and weights stored as halves, v_mfma_f32_32x32x16_f16 with f32
-    accumulation (the image and conv1's weights stay f32: the net shifts a [0,1] image by -127); "f32" beside it.
+    accumulation (the image is half too: the net's Power(-127) is folded into conv1's filters); "f32" beside it.
     Measured one batch at a time and with two batches in flight on replica engines (the read-back and the host-side
     unpacking of one batch overlap the forward of the next)."""
     from fcn_object_detector_amd import lib as L, models, proto

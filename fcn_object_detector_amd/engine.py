@@ -211,8 +211,30 @@ class Engine:
         data_tops = set(self.inputs)
         # f16 mode: everything is stored as halves except what leaves the net towards the f32 decode kernel - the output
         # blobs and the input / output of a Sigmoid head (written by the convolution epilogue in f32)
+        # f16 mode, the image itself: the nets shift a [0,1] image by -127 (Power layer), which leaves 16 half-float levels
+        # for the whole input range - but a convolution is linear, conv(x + s) = conv(x) + s * conv(indicator), and the
+        # indicator of "inside the image" is what zero padding makes of a constant-1 channel.  The half image therefore
+        # holds the UN-shifted pixels in channels 0..2 and the constant 1 in channels 3 and 4 of its 8-channel segment
+        # (written once), and the first convolution's filters carry s * sum_c(w_c) per tap in those two channels, split
+        # into a half and its rounding remainder (_packed_weight): exact to 2^-22 of the shift term.
+        self._half_inputs: Dict[str, Tuple[str, float]] = {}      # data top -> (Power top, shift)
+        if self.f16 and self.fuse and os.environ.get("FCN_F16_IMAGE", "1") != "0":
+            for d in data_tops:
+                cons = consumers.get(d, [])
+                if len(self.shapes[d]) != 4 or self.shapes[d][1] > 3 or len(cons) != 1 or cons[0].type != "Power":
+                    continue
+                pw = cons[0].sub("power_param")
+                t = cons[0].tops[0]
+                if (float(pw.get("power", 1.0)) != 1.0 or float(pw.get("scale", 1.0)) != 1.0 or t == d or t in self.outputs
+                        or [q.type for q in consumers.get(t, [])] != ["Convolution"]):
+                    continue
+                self._half_inputs[d] = (t, float(pw.get("shift", 0.0)))
+        half_image = set(self._half_inputs) | {t for t, _s in self._half_inputs.values()}
         esize: Dict[str, int] = {}
         for name, shp in self.shapes.items():
+            if name in half_image:
+                esize[name] = 2
+                continue
             wide = (not self.f16 or len(shp) != 4 or name in self.outputs or name in data_tops      # inputs stay float32 (Power(-127) quirk)
                     or any(q.type == "Power" and q.bottoms[0] in data_tops for q in producers.get(name, []))
                     or any(q.type == "Sigmoid" for q in consumers.get(name, [])) or any(q.type == "Sigmoid" for q in producers.get(name, [])))
@@ -305,12 +327,20 @@ class Engine:
             if b.esize != r.esize:
                 raise NotImplementedError("f16 engine: blob %s (%d-byte elements) is a view of %s (%d-byte)" % (name, b.esize, root, r.esize))
             b.buf, b.coffset, b.cstride = r.buf, r.coffset + off, r.cstride
-            if total_shift:
+            if total_shift and root in self._half_inputs:
+                b.lazy_shift = total_shift        # the device keeps the un-shifted half image: reading the Power top adds the shift
+            elif total_shift:
                 r.upload_shift = total_shift      # device copy of the input = host value + shift
                 r.lazy_shift = -total_shift       # reading the input back undoes it
         for nm in self.inputs:
             if nm in self.blobs:
                 self.blobs[nm].is_input = True
+        for d in self._half_inputs:                 # the two constant-1 channels, once: every writer of the image touches channels 0..2 only
+            b = self.blobs[d]
+            ones = np.zeros((b.pixels, b.cstride), np.float16)
+            ones[:, 3:5] = 1.0
+            L.call("fcn_memcpy_h2d_async", b.buf.ptr, ones.ctypes.data, ones.nbytes, None)
+            L.call("fcn_device_sync")
 
     def _alloc_params(self, params: Optional[Dict[str, List[np.ndarray]]]) -> None:
         """All learnable blobs live in ONE flat device buffer in the kernels' layout (conv weights OHWI with Cin padded
@@ -356,6 +386,13 @@ class Engine:
             xs = self.blobs[l.bottoms[0]].esize              # element type of the layer's input: 16-byte segments of it
             out = np.zeros((co, kh, kw, _ra(ci, xs)), np.float16 if xs == 2 else F32)   # OHWI, Cin padded to whole segments
             out[..., :ci] = w.transpose(0, 2, 3, 1)
+            for _d, (t, sh) in getattr(self, "_half_inputs", {}).items():
+                if l.bottoms[0] == t and sh:
+                    # the folded Power shift: channels 3 and 4 see the constant 1 (zero in the padding, like the shifted image)
+                    term = np.float64(sh) * out[..., :ci].astype(np.float64).sum(-1)      # of the ROUNDED filters: what the device multiplies
+                    hi = term.astype(np.float16)
+                    out[..., 3] = hi
+                    out[..., 4] = (term - hi.astype(np.float64)).astype(np.float16)
             return out
         if l.type == "Deconvolution":
             c, cog, kh, kw = w.shape

@@ -166,7 +166,9 @@ def test_f16_engine_forward_of_the_detectnet_deploy_net(gpu):
     spec.infer()
     params = fill_params(spec, seed=21)
     eng = Engine(NetSpec(msg, "TEST"), params={k: [a.copy() for a in v] for k, v in params.items()}, device=0, autotune=False, dtype="f16")
-    assert eng.blobs["data"].esize == 4 and eng.blobs["conv1/7x7_s2"].esize == 2 and eng.blobs["inception_3a/output"].esize == 2
+    # the image is half too: un-shifted pixels + two constant-1 channels that carry the folded Power(-127) (engine._half_inputs)
+    assert eng.blobs["data"].esize == 2 and eng.blobs["data"].cstride == 8 and eng._half_inputs == {"data": ("transformed_data", -127.0)}
+    assert eng.blobs["conv1/7x7_s2"].esize == 2 and eng.blobs["inception_3a/output"].esize == 2
     assert eng.blobs["coverage"].esize == 4 and eng.blobs["bboxes"].esize == 4 and eng.blobs["cvg/classifier"].esize == 4
     x = np.random.default_rng(1).random((2, 3, 96, 128), dtype=np.float32)
     eng.host_array("data")[...] = x
@@ -176,13 +178,35 @@ def test_f16_engine_forward_of_the_detectnet_deploy_net(gpu):
     rb = ref.forward()
     for name in ("coverage", "bboxes"):
         assert rel_err(out[name], rb[name]) < 2e-2, name                      # fp16 storage of 60+ layers vs pure f32
-    # (b) same rounding points: weights of every layer but conv1 are halves, every internal activation is rounded to half
-    p16 = {k: [(_round16(v[0]) if k != "conv1/7x7_s2" else v[0])] + [a.copy() for a in v[1:]] for k, v in params.items()}
+    # (b) same rounding points: the weights of every layer are halves, the image and every internal activation are rounded to
+    # half (the shifted image is not: the shift lives in the first layer's filters, exact to 2^-22)
+    p16 = {k: [_round16(v[0])] + [a.copy() for a in v[1:]] for k, v in params.items()}
     ref16 = RefNet(msg, "TEST", p16)
-    ref16.blobs["data"] = x
+    ref16.blobs["data"] = _round16(x)
     ref16.round_activations = lambda name, a: a if name in ("data", "transformed_data", "coverage", "bboxes", "cvg/classifier") else _round16(a)
     rb16 = ref16.forward()
     for name in ("coverage", "bboxes"):
         assert rel_err(out[name], rb16[name]) < 3e-3, name
     assert rel_err(eng.read_blob("inception_4a/output"), rb16["inception_4a/output"]) < 3e-3
+    # reading the Power top back adds the shift that the device copy no longer carries
+    assert np.abs(eng.read_blob("transformed_data") - (x + np.float32(-127.0))).max() <= 2.0 ** -11 + 1e-5
+    # the first layer alone, against float64 on the same half operands: the folded shift is exact to ~1e-5 of the bias-sized term
+    w16 = _round16(params["conv1/7x7_s2"][0]).astype(np.float64)
+    from oracle import caffe_ref as R
+    want = R.relu(R.conv2d((_round16(x).astype(np.float64) - 127.0), w16, params["conv1/7x7_s2"][1].astype(np.float64), 3, 2))
+    got = eng.read_blob("conv1/7x7_s2")
+    assert np.abs(got - want).max() <= np.abs(want).max() * 2.0 ** -10
+    # FCN_F16_IMAGE=0 keeps the float32 image and first layer
+    import os
+    os.environ["FCN_F16_IMAGE"] = "0"
+    try:
+        eng32 = Engine(NetSpec(msg, "TEST"), params={k: [a.copy() for a in v] for k, v in params.items()}, device=0, autotune=False, dtype="f16")
+        assert eng32.blobs["data"].esize == 4 and not eng32._half_inputs
+        eng32.host_array("data")[...] = x
+        o32 = eng32.forward()
+        for name in ("coverage", "bboxes"):
+            assert rel_err(o32[name], rb[name]) < 2e-2
+        eng32.close()
+    finally:
+        del os.environ["FCN_F16_IMAGE"]
     eng.close()
