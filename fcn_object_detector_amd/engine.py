@@ -572,6 +572,17 @@ class Engine:
         self.levels = max(levels) + 1 if levels else 0
 
     def _fusable_pool_desc(self, l: Layer) -> Optional[L.PoolDesc]:
+        if os.environ.get("FCN_FUSE_POOLS", "1") == "0":      # (experiments: pools as launches of their own)
+            return None
+        # Measured on MI355X: riding in the convolution launch saves a launch (what counts at batch 1-8: 2520 vs 2270
+        # frames/s at batch 1) but the pool workgroups are shaped by the convolution's tile; on the half-float batch-32
+        # path the dedicated 8-channels-per-lane kernel is faster than its share of the fused launch (forward 2.11 -> 2.02 ms).
+        xb = self.blobs.get(l.bottoms[0])
+        if self.f16 and xb is not None and xb.pixels >= 16384:
+            return None
+        return self._fusable_pool_desc_impl(l)
+
+    def _fusable_pool_desc_impl(self, l: Layer) -> Optional[L.PoolDesc]:
         """fcn_pool_desc of a MAX pooling that can ride in a convolution launch (16-byte channel groups), else None."""
         if l.type != "Pooling":
             return None
