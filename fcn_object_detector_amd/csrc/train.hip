@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
 // MAX pool backward in gather form: every input element sums the output gradients whose argmax it is
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx, float* __restrict__ dx,
                                                           int N, int H, int W, int C, int dx_cstride, int dx_coffset, int k, int stride,
-                                                          int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate) {
+                                                          int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate,
+                                                          const float* __restrict__ relu_y, int ry_cstride, int ry_coffset) {
     const long long total = (long long)N * H * W * C;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(t % C);
@@ -458,14 +459,17 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                 if (idx[o * C + c] == me) g += dy[o * dy_cstride + dy_coffset + c];
             }
         float* d = dx + ((size_t)(n * H + iy) * W + ix) * dx_cstride + dx_coffset + c;
-        *d = accumulate ? *d + g : g;
+        if (accumulate) g += *d;
+        if (relu_y && !(relu_y[((size_t)(n * H + iy) * W + ix) * ry_cstride + ry_coffset + c] > 0.f)) g = 0.f;
+        *d = g;
     }
 }
 
 // same, 4 channels (16 bytes) per lane: the shapes of the reference nets always allow it
 __global__ __launch_bounds__(256) void maxpool_bwd_v4_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx, float* __restrict__ dx,
                                                              int N, int H, int W, int C, int dx_cstride, int dx_coffset, int k, int stride,
-                                                             int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate) {
+                                                             int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate,
+                                                             const float* __restrict__ relu_y, int ry_cstride, int ry_coffset) {
     const unsigned C4 = (unsigned)C >> 2;
     const unsigned total = (unsigned)N * H * W * C4;
     for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
@@ -491,6 +495,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_v4_kernel(const float* __rest
             }
         v4f* dst = reinterpret_cast<v4f*>(dx + (size_t)pix * dx_cstride + dx_coffset + c);
         if (accumulate) g += *dst;
+        if (relu_y) {       // the ReLU backward of the blob this gradient belongs to, when this pass is its last writer
+            const v4f y = *reinterpret_cast<const v4f*>(relu_y + (size_t)pix * ry_cstride + ry_coffset + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+        }
         *dst = g;
     }
 }
@@ -989,20 +998,30 @@ int fcn_sigmoid_bwd_f32(const float* y, const float* dy, float* dx, size_t count
     return 0;
 }
 
-int fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, int H, int W, int C, int dx_cstride, int dx_coffset, int k,
-                        int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, fcn_stream_t s) {
+int fcn_maxpool_bwd_mask_f32(const float* dy, const int32_t* idx, float* dx, int N, int H, int W, int C, int dx_cstride, int dx_coffset, int k,
+                             int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, const float* relu_y,
+                             int relu_y_cstride, int relu_y_coffset, fcn_stream_t s) {
     FCN_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && OH > 0 && OW > 0, FCN_E_ARG, "maxpool_bwd: bad args");
     FCN_REQUIRE(dx_cstride >= dx_coffset + C && dy_cstride >= dy_coffset + C, FCN_E_ARG, "maxpool_bwd: channel slice out of range");
+    FCN_REQUIRE(!relu_y || (relu_y_coffset >= 0 && relu_y_cstride >= relu_y_coffset + C), FCN_E_ARG, "maxpool_bwd: mask slice out of range");
     const bool v4 = C % 4 == 0 && dx_cstride % 4 == 0 && dx_coffset % 4 == 0 && dy_cstride % 4 == 0 && dy_coffset % 4 == 0 &&
-                    (long long)N * H * W * (C / 4) < (1ll << 31) && (((uintptr_t)dy | (uintptr_t)idx | (uintptr_t)dx) & 15) == 0;
+                    (long long)N * H * W * (C / 4) < (1ll << 31) && (((uintptr_t)dy | (uintptr_t)idx | (uintptr_t)dx) & 15) == 0 &&
+                    (!relu_y || (relu_y_cstride % 4 == 0 && relu_y_coffset % 4 == 0 && ((uintptr_t)relu_y & 15) == 0));
     if (v4)
         hipLaunchKernelGGL(maxpool_bwd_v4_kernel, dim3(stream_grid((long long)N * H * W * (C / 4), 256)), dim3(256), 0, as_stream(s), dy, idx, dx, N, H,
-                           W, C, dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate);
+                           W, C, dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate, relu_y, relu_y_cstride,
+                           relu_y_coffset);
     else
         hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(stream_grid((long long)N * H * W * C, 256)), dim3(256), 0, as_stream(s), dy, idx, dx, N, H, W, C,
-                           dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate);
+                           dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate, relu_y, relu_y_cstride, relu_y_coffset);
     FCN_LAUNCH_CHECK("maxpool_bwd");
     return 0;
+}
+
+int fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, int H, int W, int C, int dx_cstride, int dx_coffset, int k,
+                        int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, fcn_stream_t s) {
+    return fcn_maxpool_bwd_mask_f32(dy, idx, dx, N, H, W, C, dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate,
+                                    nullptr, 0, 0, s);
 }
 
 int fcn_deconv_depthwise_bwd_f32(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int dx_cstride, int k, int stride,

@@ -159,6 +159,7 @@ PROTOTYPES = {
     "fcn_relu_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "fcn_sigmoid_bwd_f32": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "fcn_maxpool_bwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp]),
+    "fcn_maxpool_bwd_mask_f32": (_i, [_vp, _vp, _vp] + [_i] * 14 + [_vp, _i, _i, _vp]),
     "fcn_lrn_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp]),
     "fcn_dropout_f32": (_i, [_vp, _vp] + [_i] * 8 + [_f, C.c_uint, C.c_uint, _vp]),
     "fcn_stream_wait_event": (_i, [_vp, _vp]),

@@ -253,6 +253,11 @@ class TrainEngine(Engine):
                 rec = w[-1] if w else None
                 if not isinstance(rec, dict) or rop not in ops:
                     continue
+                if "pool" in rec:        # the last writer is a pooling backward of exactly this blob
+                    if rec["pool"] == x:
+                        rec["mask"] = (B[x].buf.ptr, B[x].cstride, B[x].coffset)
+                        ops.remove(rop)
+                    continue
                 d = rec["descs"][rec["targets"].index(x)]
                 act = B[x]
                 d.y2, d.y2_cstride, d.y2_coffset = act.buf.ptr, act.cstride, act.coffset
@@ -440,6 +445,7 @@ class TrainEngine(Engine):
             if gbot is None:
                 continue
             acc = 1 if state(gbot) == "full" else 0
+            pool_writer = None
             if t == "Pooling":
                 pp = l.sub("pooling_param")
                 if str(pp.get("pool", "MAX")) != "MAX":
@@ -449,9 +455,12 @@ class TrainEngine(Engine):
                 _, _, oh, ow = yb.shape
                 k, s, pad = kernel_stride_pad(pp)
                 idx = self.aux_dev[l.name]
-                ops.append(Op("maxpool_bwd", l.name, lambda st, a=gtop, b=gbot, idx=idx, g=(n, h, w, c), kk=(k, s, pad, oh, ow), acc=acc: L.check(
-                    lib.fcn_maxpool_bwd_f32(a.buf.ptr, idx.ptr, b.buf.ptr, g[0], g[1], g[2], g[3], b.cstride, b.coffset, kk[0], kk[1], kk[2],
-                                            kk[3], kk[4], a.cstride, a.coffset, acc, st))))
+                prec = dict(pool=l.bottoms[0], mask=(None, 0, 0))      # finish_dgrads may fold a ReLU backward into this pass
+                ops.append(Op("maxpool_bwd", l.name, lambda st, a=gtop, b=gbot, idx=idx, g=(n, h, w, c), kk=(k, s, pad, oh, ow), acc=acc, r=prec:
+                              L.check(lib.fcn_maxpool_bwd_mask_f32(a.buf.ptr, idx.ptr, b.buf.ptr, g[0], g[1], g[2], g[3], b.cstride, b.coffset,
+                                                                   kk[0], kk[1], kk[2], kk[3], kk[4], a.cstride, a.coffset, acc, r["mask"][0],
+                                                                   r["mask"][1], r["mask"][2], st))))
+                pool_writer = prec
             elif t == "LRN":
                 xb, yb = B[l.bottoms[0]], B[l.tops[0]]
                 p = l.sub("lrn_param")
@@ -508,7 +517,7 @@ class TrainEngine(Engine):
                 continue        # input transform: nothing upstream learns
             else:
                 raise NotImplementedError("backward of layer type %s (%s)" % (t, l.name))
-            mark(gbot)
+            mark(gbot, pool_writer)
         finish_dgrads()
         self._ws = DeviceBuffer(ws_floats * 4, zero=False)
         self.bwd_ops = ops

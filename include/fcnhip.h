@@ -326,6 +326,11 @@ int  fcn_relu_bwd_f32(const float* dy, const float* y, float* dx, int pixels, in
 int  fcn_sigmoid_bwd_f32(const float* y, const float* dy, float* dx, size_t count, int accumulate, fcn_stream_t s);
 int  fcn_maxpool_bwd_f32(const float* dy, const int32_t* idx, float* dx, int N, int H, int W, int C, int dx_cstride, int dx_coffset,
                          int k, int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate, fcn_stream_t s);
+/* The same with the ReLU backward of the blob dx belongs to folded in (relu_y = that blob's activation, may be NULL): used when
+ * the pooling backward is the LAST pass that writes the gradient (FCN_CONV_MASK is the convolution's counterpart). */
+int  fcn_maxpool_bwd_mask_f32(const float* dy, const int32_t* idx, float* dx, int N, int H, int W, int C, int dx_cstride, int dx_coffset,
+                              int k, int stride, int pad, int OH, int OW, int dy_cstride, int dy_coffset, int accumulate,
+                              const float* relu_y, int relu_y_cstride, int relu_y_coffset, fcn_stream_t s);
 int  fcn_lrn_bwd_f32(const float* x, const float* y, const float* scale, const float* dy, float* dx, int pixels, int C,
                      int x_cstride, int y_cstride, int local_size, float alpha, float beta, int accumulate, fcn_stream_t s);
 /* Dropout (TRAIN): y = x * mask / (1 - ratio); mask of element (n,c,h,w) = hash(NCHW index, seed) >= ratio * 2^32.

@@ -113,6 +113,14 @@ def test_maxpool_bwd(gpu, k, s, p, h, w, c, cs_dy, co_dy, cs_dx, co_dx):
     assert np.allclose(nchw(dev_to(dxd, (2, h, w, cs_dx)), c, co_dx), base + ref, rtol=1e-6, atol=1e-6)
     L.call("fcn_maxpool_bwd_f32", dyd.ptr, idd.ptr, dxd.ptr, 2, h, w, c, cs_dx, co_dx, k, s, p, oh, ow, cs_dy, co_dy, 0, None)
     assert np.allclose(nchw(dev_to(dxd, (2, h, w, cs_dx)), c, co_dx), ref, rtol=1e-6, atol=1e-6)
+    # with the ReLU backward of the blob folded in (fcn_maxpool_bwd_mask_f32): the total is zeroed where the activation is not positive
+    act = np.maximum(rng.standard_normal(x.shape), 0).astype(np.float32)
+    actd = dev_from(nhwc(act, cs_dx, co_dx))
+    dxd2 = dev_from(nhwc(base, cs_dx, co_dx))
+    L.call("fcn_maxpool_bwd_mask_f32", dyd.ptr, idd.ptr, dxd2.ptr, 2, h, w, c, cs_dx, co_dx, k, s, p, oh, ow, cs_dy, co_dy, 1, actd.ptr, cs_dx, co_dx, None)
+    got = nchw(dev_to(dxd2, (2, h, w, cs_dx)), c, co_dx)
+    assert np.allclose(got, (base + ref) * (act > 0), rtol=1e-6, atol=1e-6) and np.all(got[act <= 0] == 0)
+    assert np.array_equal(dev_to(dxd2, (2, h, w, cs_dx))[..., :co_dx], nhwc(base, cs_dx, co_dx)[..., :co_dx])      # neighbours of the slice untouched
 
 
 @pytest.mark.parametrize("c,ls,beta", [(64, 5, 0.75), (64, 5, 0.6), (6, 3, 0.75), (10, 5, 0.75)])   # 16-byte fast path / generic kernel
