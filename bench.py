@@ -456,7 +456,10 @@ def main() -> None:
     pipe.close()
     if not args.no_train:
         tsteps = args.train_steps or max(min(args.steps, 30), 1)
-        tr = bench_train(cp, rank, world, local, args.train_batch, tsteps, max(min(args.warmup, 5), 2))
+        try:
+            tr = bench_train(cp, rank, world, local, args.train_batch, tsteps, max(min(args.warmup, 5), 2))
+        except Exception as e:      # the headline measured above must survive a failure in the secondary measurement
+            tr = {"error": "%s: %s" % (type(e).__name__, e)}
         if out is not None:
             out["train"] = tr
     if out is not None and world == 1 and not args.no_secondary:
