@@ -297,6 +297,18 @@ def bench_vgg(steps: int = 5):
     out = {"net": "train/fcn_bbox (VGG16-FCN), f32", "forward_448_b1": {"frames_per_s": round(1e3 / ms, 1), "ms_per_frame": round(ms, 3),
            "gflop_per_frame": round(fl / 1e9, 2), "achieved_tflops": round(fl / ms / 1e9, 1), "frac_of_f32_mfma_peak": round(fl / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 3)}}
     eng.close()
+    # the same forward with three frames in flight (engine.ForwardPipeline; no LDS cap: these launches are large)
+    from fcn_object_detector_amd.engine import ForwardPipeline
+    params = fill_params(spec, seed=1)
+    pipe = ForwardPipeline(lambda: NetSpec(msg, "TEST"), params=params, device=0, depth=3, max_lds_kb=None)
+    for e in pipe.engines:
+        e.host_array("data")[...] = np.random.default_rng(0).random((1, 3, 448, 448), dtype=np.float32)
+        e.upload_inputs()
+    pipe.run_resident(6)
+    dt = pipe.run_resident(60) / 60
+    out["forward_448_b1"]["frames_per_s_3_in_flight"] = round(1.0 / dt, 1)
+    out["forward_448_b1"]["achieved_tflops_3_in_flight"] = round(fl / dt / 1e12, 1)
+    pipe.close()
     n, size, classes = 24, 288, 11
     msg = proto.parse_text(models.vgg16_fcn_bbox_train("synthetic", "Boxes", "288,288,8,11,%d,none" % n, num_classes=classes))
     shapes = {"data": (n, 3, size, size), "label": (n, 1, size, size)}
