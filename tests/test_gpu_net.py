@@ -118,6 +118,21 @@ def test_forward_pipeline_equals_lone_engine(gpu):
     lone.close()
 
 
+def test_frames_in_flight_are_reproducible(gpu):
+    """2000 copies of one frame through four replicas that share the GPU: every result carries the first one's bits (kernels
+    that overlap must not disturb each other - the check that pins the convolution kernel's tail-prefetch fix)."""
+    from fcn_object_detector_amd.engine import ForwardPipeline
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(1, 96, 128, 4))
+    spec = NetSpec(msg, "TEST")
+    spec.infer()
+    pipe = ForwardPipeline(lambda: NetSpec(msg, "TEST"), params=fill_params(spec, seed=3), device=0, depth=4)
+    x = np.random.default_rng(0).random((1, 3, 96, 128), dtype=np.float32)
+    outs = pipe.map([{"data": x}] * 2000)
+    bad = [i for i, o in enumerate(outs) if not all(np.array_equal(o[k], outs[0][k]) for k in outs[0])]
+    assert not bad, bad[:10]
+    pipe.close()
+
+
 def test_pycaffe_front_end(gpu, tmp_path):
     """The reference's calling sequence (fcn_object_detector.py:68-69,82,87,317-328) against our `caffe` package."""
     if PYCAFFE not in sys.path:
