@@ -19,6 +19,8 @@
 //     JaccardCoeff.iou :26-55, generate_box_labels :272-278, grid_region :283-292).
 #include <math.h>
 
+#include <atomic>
+
 #include "common.h"
 
 using namespace fcn;
@@ -29,6 +31,14 @@ constexpr int kDetThreads = 1024;
 constexpr int kDetWaves = kDetThreads / 64;
 constexpr int kMaxCand = 4096;  // LDS capacity: parent + count + 4 sums = 6 * 16 KiB
 constexpr int kMaxBig = kMaxCand / 2;   // classes with n > groupThreshold >= 1 members: at most M / 2
+constexpr int kSliceMinCand = 192;      // below this many candidates one workgroup does the whole problem
+constexpr int kMaxSlices = 8;
+
+// workgroups per (image, class): enough to spread a lone frame's tests over the chip, one when the batch already fills it
+inline int detect_slices(long long problems) {
+    long long s = 256 / (problems > 0 ? problems : 1);
+    return (int)(s < 1 ? 1 : (s > kMaxSlices ? kMaxSlices : s));
+}
 
 struct DetP {
     fcn_detect_params p;
@@ -36,7 +46,9 @@ struct DetP {
     const float* cvg;
     const float* bbox;
     size_t cvg_image_stride, box_image_stride;
-    int* ws;            // per problem: rects[4*G] + list[G]
+    int* ws;            // per problem: rects[4*G] + list[G] + slice forests[S*G]; behind all problems: one arrival word each
+    int slices;         // workgroups per (image, class): the SimilarRects tests of a problem are dealt to S workgroups
+    unsigned seq;       // launch sequence number (24 bits used): the arrival words need no reset and no zero-initialised workspace
     int32_t* out_rects;
     int32_t* out_weights;
     int32_t* out_count;
@@ -100,18 +112,24 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
     __shared__ int bdx[kMaxBig], bdy[kMaxBig];      // containment margins of the classes with n > groupThreshold
     __shared__ int wsum[kDetWaves];
     __shared__ int s_any;
+    __shared__ int s_last;
 
     const fcn_detect_params& P = d.p;
-    const int cls = blockIdx.x % P.num_classes;
-    const int img = blockIdx.x / P.num_classes;
+    const int S = d.slices;
+    const int prob = blockIdx.x / S;                 // (image, class)
+    const int slice = blockIdx.x - prob * S;         // which share of the problem's SimilarRects tests this workgroup runs
+    const int cls = prob % P.num_classes;
+    const int img = prob / P.num_classes;
     const int G = P.gy * P.gx;
     const int tid = threadIdx.x;
     const float* cvg = d.cvg + (size_t)img * d.cvg_image_stride;
     const float* box = d.bbox + (size_t)img * d.box_image_stride;
-    int* rects = d.ws + (size_t)blockIdx.x * 5 * G;  // [4][G] as x | y | w | h planes
-    int* list = rects + 4 * (size_t)G;               // compacted root / survivor lists
-    int32_t* o_rects = d.out_rects + (size_t)blockIdx.x * P.max_out * 4;
-    int32_t* o_w = d.out_weights + (size_t)blockIdx.x * P.max_out;
+    int* rects = d.ws + (size_t)prob * (5 + S) * G;  // [4][G] as x | y | w | h planes (every slice writes the same values)
+    int* list = rects + 4 * (size_t)G;               // compacted root / survivor lists (used by the finishing workgroup only)
+    int* forests = list + G;                         // [S][G]: each slice's component roots
+    unsigned* arrive = reinterpret_cast<unsigned*>(d.ws + (size_t)gridDim.x / S * (5 + S) * G) + prob;
+    int32_t* o_rects = d.out_rects + (size_t)prob * P.max_out * 4;
+    int32_t* o_w = d.out_weights + (size_t)prob * P.max_out;
 
     if (tid == 0) s_any = 0;
 
@@ -147,13 +165,14 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
     }
     __syncthreads();
     // vote_boxes: `if not propose_boxes.any(): return []`
-    if (M == 0 || s_any == 0) {
-        if (tid == 0) d.out_count[blockIdx.x] = 0;
+    if (M == 0 || s_any == 0) {                      // (every slice of the problem sees the same M and takes the same exit)
+        if (tid == 0 && slice == 0) d.out_count[prob] = 0;
         return;
     }
 
     // groupRectangles: groupThreshold <= 0 returns the input untouched with weight 1
     if (P.group_thresh <= 0) {
+        if (slice != 0) return;
         int outn = 0;
         for (int base = 0; base < M; base += kDetThreads) {
             const int i = base + tid;
@@ -169,9 +188,12 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
             }
             outn += tot;
         }
-        if (tid == 0) d.out_count[blockIdx.x] = outn;
+        if (tid == 0) d.out_count[prob] = outn;
         return;
     }
+    // Few candidates: one workgroup is faster than the hand-over between several
+    const bool sliced = S > 1 && M > kSliceMinCand;
+    if (!sliced && slice != 0) return;
 
     // ---- c: partition(): union every SimilarRects pair ----------------------------------------
     // M^2/2 tests (307 k for a full 28x28 grid): the candidates are staged in LDS - the four sum planes are free until
@@ -194,7 +216,12 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
             const int4 rj = cand[j < M ? j : 0];
             const int rjx = rj.x + rj.z, rjy = rj.y + rj.w;
             for (int c = 0; c <= b; ++c, ++item) {
-                if ((item & (kDetWaves - 1)) != wave) continue;
+                // items round-robin over the slices, a slice's items round-robin over its 16 waves
+                if (sliced) {
+                    if (item % S != slice || ((item / S) & (kDetWaves - 1)) != wave) continue;
+                } else if ((item & (kDetWaves - 1)) != wave) {
+                    continue;
+                }
                 const int i0 = c << 6;
                 const int i1 = min(min(i0 + 64, M), j < M ? j : 0);      // this lane's tests of the item: i0 <= i < min(i1, j)
                 const int iw = min(i0 + 64, M);                           // the wave walks the whole block
@@ -217,6 +244,39 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
         }
     }
     __syncthreads();
+    if (sliced) {
+        // Each slice publishes its forest (root of every candidate); the workgroup that arrives LAST merges the others'
+        // into its own - M * (S - 1) unions - and finishes the problem.  Nobody waits for anybody: no spinning.
+        for (int i = tid; i < M; i += kDetThreads) forests[(size_t)slice * G + i] = uf_find(parent, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();                                   // release: this workgroup's stores before its arrival
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned tag = d.seq & 0xFFFFFFu;
+            unsigned old = __hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+            while (true) {                                     // (launch tag | arrivals): a stale word of an earlier launch counts as zero
+                want = (old >> 8) == tag ? old + 1 : ((tag << 8) | 1u);
+                const unsigned prev = atomicCAS(arrive, old, want);
+                if (prev == old) break;
+                old = prev;
+            }
+            s_last = (int)(want & 0xFFu) == S;
+            __threadfence();                                   // acquire: the other slices' forests
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (!s_last) return;
+        for (int s2 = 0; s2 < S; ++s2) {
+            if (s2 == slice) continue;
+            const int* f = forests + (size_t)s2 * G;
+            for (int i = tid; i < M; i += kDetThreads) {
+                const int r = __builtin_nontemporal_load(f + i);
+                if (r != i) uf_union(parent, i, r);
+            }
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < M; i += kDetThreads) sum[0][i] = sum[1][i] = sum[2][i] = sum[3][i] = 0;
     for (int i = tid; i < kMaxCand; i += kDetThreads) cnt[i] = 0;
     __syncthreads();
@@ -312,7 +372,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
         }
         outn += tot;
     }
-    if (tid == 0) d.out_count[blockIdx.x] = outn;
+    if (tid == 0) d.out_count[prob] = outn;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,7 +456,8 @@ extern "C" {
 
 size_t fcn_detect_workspace_bytes(const fcn_detect_params* h_p, int batch) {
     if (!h_p || batch <= 0) return 0;
-    return (size_t)batch * h_p->num_classes * 5 * (size_t)h_p->gy * h_p->gx * sizeof(int32_t);
+    const size_t problems = (size_t)batch * h_p->num_classes;
+    return (problems * (5 + detect_slices((long long)problems)) * (size_t)h_p->gy * h_p->gx + problems) * sizeof(int32_t);
 }
 
 int fcn_detect_decode_group(const float* cvg, const float* bbox, int batch, size_t cvg_image_stride, size_t box_image_stride,
@@ -421,7 +482,12 @@ int fcn_detect_decode_group(const float* cvg, const float* bbox, int batch, size
     d.out_rects = out_rects;
     d.out_weights = out_weights;
     d.out_count = out_count;
-    hipLaunchKernelGGL(detect_kernel, dim3(batch * P.num_classes), dim3(kDetThreads), 0, as_stream(s), d);
+    static std::atomic<unsigned> launch_seq{1};
+    d.slices = detect_slices((long long)batch * P.num_classes);
+    do {
+        d.seq = launch_seq.fetch_add(1, std::memory_order_relaxed);
+    } while ((d.seq & 0xFFFFFFu) == 0);      // tag 0 is what a zero-filled workspace holds
+    hipLaunchKernelGGL(detect_kernel, dim3(batch * P.num_classes * d.slices), dim3(kDetThreads), 0, as_stream(s), d);
     FCN_LAUNCH_CHECK("detect_decode_group");
     return 0;
 }

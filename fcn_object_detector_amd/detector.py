@@ -69,7 +69,7 @@ class GridDecoder:
         self.params = p
         lib = L.load()
         slots = self.batch * self.C
-        self.ws = DeviceBuffer(max(int(lib.fcn_detect_workspace_bytes(C.byref(p), self.batch)), 16), zero=False)
+        self.ws = DeviceBuffer(max(int(lib.fcn_detect_workspace_bytes(C.byref(p), self.batch)), 16), zero=True)
         self.d_rects = DeviceBuffer(slots * p.max_out * 16, zero=True)
         self.d_weights = DeviceBuffer(slots * p.max_out * 4, zero=True)
         self.d_count = DeviceBuffer(slots * 4, zero=True)

@@ -274,7 +274,11 @@ typedef struct fcn_detect_params {
     int32_t round_mode;      /* FCN_RECT_ROUND_*             */
     int32_t max_out;         /* capacity of the output arrays per (image, class) slot */
 } fcn_detect_params;
-/* One workgroup per (image, class); slot = image * num_classes + class.  Outputs per slot:
+/* One to eight workgroups per (image, class) - the SimilarRects tests of a problem with many candidates are dealt to
+ * several workgroups whose forests the last one to arrive merges (small batches only: a full batch fills the chip with one
+ * per problem); slot = image * num_classes + class.  Zero-fill the workspace once after allocating it (the arrival words
+ * carry a launch tag and are never reset; an uninitialised word matches a live tag with probability 2^-24) and do not
+ * share it between launches that may run concurrently.  Outputs per slot:
  * out_rects[slot][max_out][4] int32 (x, y, w, h exactly as groupRectangles returns them, in its
  * cluster order), out_weights[slot][max_out] int32 (cluster size n; the reference's confidence is
  * log(n)), out_count[slot] int32 (may exceed max_out: then only max_out entries were stored).
