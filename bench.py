@@ -467,9 +467,9 @@ def main() -> None:
     cp.barrier()
     pipe.close()
     if out is not None and world == 1 and not args.no_secondary:
-        # measured right after the headline's replicas are gone and before the training / batch-32 engines exist: the runtime
-        # deals streams to its 8 hardware queues in creation order, and replica streams that share a queue do not overlap
-        # (2300-2550 instead of 3450 frames/s with other engines' streams alive)
+        # measured right after the headline's replicas are gone: the runtime deals streams to its hardware queues in creation
+        # order and replica streams that share a queue do not overlap (with 8 queues and other engines' streams alive: 2550
+        # instead of 3450 frames/s; lib.load() asks for 16)
         out["detector_batch1"] = bench_detector_stream(local, msg, params)
     if not args.no_train:
         tsteps = args.train_steps or max(min(args.steps, 30), 1)

@@ -1093,7 +1093,7 @@ class ForwardPipeline:
     hands consecutive frames to them round-robin, so the hardware queues interleave the launches of different frames
     How many workgroups of DIFFERENT launches fit on a CU is bounded by LDS, so the replicas' autotuner is restricted to tile
     configurations of at most `max_lds_kb` per workgroup: this costs nothing on a lone stream (2530 frames/s either way) and
-    is worth +20 % once frames overlap.  Measured (8 hardware queues, see lib.load): 2530 frames/s one frame at a time,
+    is worth +20 % once frames overlap.  Measured (enough hardware queues, see lib.load): 2530 frames/s one frame at a time,
     4000-4130 with three in flight, 4300-4480 with four, 3400 with five.  Per-frame results are those of a lone engine
     with the same tile plan, bit for bit: the replicas run the same kernels on private buffers."""
 

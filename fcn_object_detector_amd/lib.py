@@ -188,11 +188,13 @@ def load() -> C.CDLL:
             raise FcnLibraryError(
                 "libfcnhip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C fcn_object_detector_amd/csrc`. There is no CPU fallback." % LIB_PATH)
-        # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when
-        # the runtime initialises.  The frame pipelines (4 replica streams) and the training step (main + weight-gradient
-        # + RCCL streams, plus the null stream) need their streams on distinct queues to overlap: with 4 queues a fourth
-        # replica stream aliases another one and throughput DROPS (3460 vs 4300 frames/s), training runs 6.60 vs 6.37 ms.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), in creation
+        # order and counting idle streams; it reads the variable once, when it initialises.  Streams that share a queue do
+        # not overlap: with 4 queues a fourth replica stream of a frame pipeline aliases another one and throughput DROPS
+        # (3460 vs 4300 frames/s), the two-stream training step runs 6.60 vs 6.37 ms; with 8 the node pipeline lost a third
+        # of its rate as soon as another pipeline's four idle streams existed (2590 vs 3600 frames/s).  16 covers the
+        # engines a process of this package keeps alive at once; no measured cost against 8.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         try:
             lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
         except OSError as e:  # pragma: no cover - depends on the box
