@@ -209,6 +209,24 @@ typedef void __attribute__((address_space(3))) * lds_ptr;
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Diagnostic build only (make stamps -> libfcnhip_stamps.so, tools/conv_timeline.py): wave 0 of every workgroup records
+// the constant 100 MHz clock and the shader clock at fixed points of conv_body into a buffer of its own.  No stamp exists
+// in the product build; no output value depends on one.
+#ifdef FCN_CONV_STAMPS
+constexpr int kStampWords = 16;
+__device__ unsigned long long* g_conv_stamps = nullptr;
+__device__ int g_conv_stamps_cap = 0;
+#define FCN_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        if (g_conv_stamps && (int)blockIdx.x < g_conv_stamps_cap && threadIdx.x == 0) {                       \
+            g_conv_stamps[(size_t)blockIdx.x * kStampWords + 2 * (i)] = __builtin_amdgcn_s_memrealtime();     \
+            g_conv_stamps[(size_t)blockIdx.x * kStampWords + 2 * (i) + 1] = __builtin_amdgcn_s_memtime();     \
+        }                                                                                                     \
+    } while (0)
+#else
+#define FCN_STAMP(i) do { } while (0)
+#endif
+
 // T = float: v_mfma_f32_32x32x2_f32, 4 elements per 16-byte segment.  T = _Float16 (inference with f16 activations and
 // weights, f32 accumulation, BASELINE configs[4]): v_mfma_f32_32x32x16_f16, 8 elements per segment - the staging, the LDS
 // image, the swizzle and the pipeline are byte-for-byte the same (BK counts 4-byte words), a chunk just covers twice the
@@ -225,6 +243,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const T* px = reinterpret_cast<const T*>(p.x);
     const T* pw = reinterpret_cast<const T*>(p.w);
 
+    FCN_STAMP(0);      // kernel entry (after the kernarg loads of the group prologue)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base goes through M0)
@@ -427,6 +446,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         buf_issue = next(buf_issue);
     }
     int buf_cur = 0;                   // ring slot of chunk c
+    FCN_STAMP(1);      // prologue issued
     if (PF) {
         wait_vmcnt<INST*(D - 1)>();   // chunk 0 landed (this wave's pieces) ...
         __builtin_amdgcn_s_barrier();  // ... and everybody else's
@@ -444,6 +464,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 wait_vmcnt<INST*(D - 1 - (PF ? 1 : 0))>();
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#ifdef FCN_CONV_STAMPS
+                if (c0 + u == 0) FCN_STAMP(2);      // first chunk usable
+#endif
                 if (PF) {
                     // The wave has one instruction stream: address arithmetic, DMA issue and fragment reads placed in
                     // front of the MFMAs would leave the matrix core idle meanwhile (with one wave per SIMD nobody
@@ -478,6 +501,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             }
         }
     }
+    FCN_STAMP(3);      // main loop done
     wait_vmcnt<0>();                   // the all-zero chunks issued past K must land before the ring is reused
     // The last iteration prefetched the fragments of a chunk that does not exist, with inline-asm ds_reads the compiler
     // cannot see: nothing waits for them, their destination registers are dead, and the register allocator hands those
@@ -514,6 +538,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             }
         }
     }
+    FCN_STAMP(4);      // K-split reduction done
     if (wk != 0) return;
 
     // ---- epilogue: bias, ReLU / sigmoid, NHWC store at a channel offset ----------------------
@@ -556,6 +581,18 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             }
         }
     }
+#ifdef FCN_CONV_STAMPS
+    FCN_STAMP(5);      // stores issued
+    wait_vmcnt<0>();
+    FCN_STAMP(6);      // stores acknowledged
+    if (g_conv_stamps && (int)blockIdx.x < g_conv_stamps_cap && threadIdx.x == 0) {
+        unsigned xcc = 0, hwid = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        g_conv_stamps[(size_t)blockIdx.x * kStampWords + 14] = xcc;
+        g_conv_stamps[(size_t)blockIdx.x * kStampWords + 15] = hwid;
+    }
+#endif
 }
 
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
@@ -759,6 +796,15 @@ std::unordered_map<const void*, HostGroup> g_groups;
 }  // namespace
 
 extern "C" {
+
+#ifdef FCN_CONV_STAMPS
+// diagnostic build: d_buf holds cap * 16 u64 (per workgroup: 7 x {100 MHz clock, shader clock}, XCC id, HW id)
+int fcn_debug_conv_stamps(void* d_buf, int cap) {
+    FCN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps), &d_buf, sizeof(d_buf)));
+    FCN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_stamps_cap), &cap, sizeof(cap)));
+    return 0;
+}
+#endif
 
 int fcn_conv2d_fwd_f32(const fcn_conv_desc* h_desc, fcn_stream_t s) {
     FCN_REQUIRE(h_desc, FCN_E_ARG, "fcn_conv2d_fwd_f32: null desc");

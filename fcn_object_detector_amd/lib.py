@@ -11,7 +11,9 @@ import threading
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcnhip.so")
+# $FCN_LIB_PATH selects another BUILD of the same HIP library (the stamped diagnostic build of tools/conv_timeline.py);
+# there is still no CPU path behind it.
+LIB_PATH = os.environ.get("FCN_LIB_PATH") or os.path.join(_HERE, "libfcnhip.so")
 
 
 class FcnLibraryError(RuntimeError):

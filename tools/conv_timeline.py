@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""GPU diagnostic: where the time of ONE convolution launch goes, from clock stamps taken inside the kernel.
+
+Needs the stamped build (`make -C fcn_object_detector_amd/csrc stamps`) and loads it through $FCN_LIB_PATH:
+
+    FCN_LIB_PATH=fcn_object_detector_amd/libfcnhip_stamps.so python tools/conv_timeline.py [shape ...]
+
+Per shape and tile configuration: the launch's HIP-event time (back to back, caches warm) and, from one stamped launch,
+the spread over workgroups of: entry, prologue issued, first chunk usable, main loop done, K-split reduction done, stores
+issued, stores acknowledged - all in microseconds after the first workgroup's entry (constant 100 MHz clock)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("FCN_LIB_PATH", os.path.join(ROOT, "fcn_object_detector_amd", "libfcnhip_stamps.so"))
+from fcn_object_detector_amd import lib as L  # noqa: E402
+from fcn_object_detector_amd.engine import DeviceBuffer  # noqa: E402
+from gpu_util import conv_desc, dev_from  # noqa: E402
+from conv_sweep import SHAPES  # noqa: E402
+
+NAMES = ("entry", "issued", "chunk0", "loop", "ksplit", "stored", "acked")
+CAP = 4096
+
+
+def main():
+    want = sys.argv[1:] or ["4a_A", "4a_B", "5b_B", "heads", "conv2_3x3", "3a_A"]
+    cfgs_env = [int(c) for c in os.environ.get("SWEEP_CFGS", "").split(",") if c]
+    cold = bool(os.environ.get("TIMELINE_COLD"))
+    L.call("fcn_init", 0)
+    lib = L.load()
+    lib.fcn_debug_conv_stamps.restype = C.c_int
+    lib.fcn_debug_conv_stamps.argtypes = [C.c_void_p, C.c_int]
+    sp = C.c_void_p()
+    L.call("fcn_stream_create", C.byref(sp))
+    st = sp.value
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    L.call("fcn_event_create", C.byref(e0))
+    L.call("fcn_event_create", C.byref(e1))
+    stamps = DeviceBuffer(CAP * 16 * 8)
+    flush = DeviceBuffer(512 << 20, zero=False)
+    rng = np.random.default_rng(0)
+    for name, probs in SHAPES:
+        if name not in want:
+            continue
+        keep, descs, flops = [], [], 0.0
+        for (cin, cout, k, pad, s, h, w) in probs:
+            oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
+            x = dev_from(rng.standard_normal((1, h, w, cin)).astype(np.float32))
+            wt = dev_from((rng.standard_normal((cout, k, k, cin)) * 0.05).astype(np.float32))
+            b = dev_from(np.zeros(cout, np.float32))
+            y = dev_from(np.zeros((1, oh, ow, cout), np.float32))
+            keep += [x, wt, b, y]
+            descs.append(conv_desc(x, wt, b, y, 1, h, w, cin, cin, cout, k, pad, s, oh, ow, cout, 0, L.CONV_RELU))
+            flops += 2.0 * oh * ow * cout * cin * k * k
+        arr = (L.ConvDesc * len(descs))(*descs)
+        ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(descs))), zero=False)
+        timed = []
+        for cfg in (cfgs_env or range(lib.fcn_conv2d_num_configs())):
+            grp = L.ConvGroup()
+            L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, cfg, C.byref(grp))
+            if grp.total_tiles > CAP:
+                continue
+            L.check(lib.fcn_debug_conv_stamps(None, 0))
+            for _ in range(3):
+                L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
+            L.call("fcn_event_record", e0, st)
+            for _ in range(30):
+                L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
+            L.call("fcn_event_record", e1, st)
+            L.call("fcn_event_sync", e1)
+            ms = C.c_float()
+            L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+            timed.append((ms.value / 30 * 1e3, cfg, grp.total_tiles))
+        timed.sort()
+        print("== %s  %.3f GFLOP  (ideal %.2f us at 157.3 TF)   best configs: %s" % (
+            name, flops / 1e9, flops / 157.3e6, "  ".join("c%d/%dwg %.1fus" % (c, t, u) for u, c, t in timed[:6])), flush=True)
+        for us, cfg, tiles in timed[:int(os.environ.get("TIMELINE_TOP", "3"))]:
+            grp = L.ConvGroup()
+            L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, cfg, C.byref(grp))
+            L.call("fcn_memset_async", stamps.ptr, 0, stamps.nbytes, st)
+            if cold:
+                L.call("fcn_memset_async", flush.ptr, 1, flush.nbytes, st)      # push the operands out of L2 and the Infinity Cache
+            L.call("fcn_stream_sync", st)
+            L.check(lib.fcn_debug_conv_stamps(stamps.ptr, CAP))
+            L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
+            L.call("fcn_stream_sync", st)
+            L.check(lib.fcn_debug_conv_stamps(None, 0))
+            raw = np.empty((CAP, 16), np.uint64)
+            L.call("fcn_memcpy_d2h_async", raw.ctypes.data, stamps.ptr, raw.nbytes, None)
+            L.call("fcn_device_sync")
+            raw = raw[:tiles]
+            real = raw[:, 0:14:2].astype(np.int64)
+            cyc = raw[:, 1:14:2].astype(np.int64)
+            ok = real[:, 0] > 0
+            t = (real[ok] - real[ok, 0].min()) / 100.0      # us
+            clk = (cyc[ok, 6] - cyc[ok, 0]) / np.maximum((real[ok, 6] - real[ok, 0]) * 10.0, 1)      # GHz
+            xcc = raw[ok, 14].astype(np.int64) & 0xF
+            print("  cfg %d  %d workgroups (%d stamped)  event %.2f us%s  span %.2f us  shader clock %.2f GHz  wg per XCC %s" % (
+                cfg, tiles, int(ok.sum()), us, " (cold)" if cold else "", t[:, 6].max(), float(np.median(clk)),
+                np.bincount(xcc, minlength=8).tolist()))
+            for i, nm in enumerate(NAMES):
+                col = t[:, i]
+                print("    %-7s min %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f   | own duration since entry p50 %6.2f max %6.2f" % (
+                    nm, col.min(), np.median(col), np.percentile(col, 90), col.max(), np.median(col - t[:, 0]), (col - t[:, 0]).max()))
+        sys.stdout.flush()
+
+
+if __name__ == "__main__":
+    main()
