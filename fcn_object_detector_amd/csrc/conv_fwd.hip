@@ -31,6 +31,7 @@
 //     split each chunk's k range (WAVES_K) and reduce through LDS at the end.
 // Several independent problems (the branches of an inception module) share ONE launch
 // (fcn_conv2d_fwd_group_f32).
+#include <cstddef>
 #include <mutex>
 #include <unordered_map>
 #include <type_traits>
@@ -89,7 +90,9 @@ struct ConvP {
     int M, K, tiles_m, tiles_n, tile_end;  // tile_end: exclusive prefix end of this problem's tiles in a group launch
     unsigned ow_magic, oh_magic;          // ceil(2^32 / OW), ceil(2^32 / OH) when exact for every m < M, else 0 (= divide)
     const float* zero_page;               // 16 zero bytes in HBM: what out-of-image / out-of-tile lanes load
+    int pad_[2];                          // 160 bytes: the group kernel fetches a problem with three wide scalar loads
 };
+static_assert(sizeof(ConvP) == 160, "conv_fwd_group loads a ConvP as 16 + 16 + 8 dwords");
 
 // A group launch carries its problems in the kernel arguments: a workgroup finds its problem with scalar
 // compares on the prefix table and ONE scalar load, instead of chasing a table in global memory (three or four
@@ -181,9 +184,8 @@ struct Cfg {
     static constexpr int KS = BK / 8 / WAVES_K;         // k-steps of 8 each wave runs per chunk
     static constexpr int BUF_FLOATS = (BM + BN) * BK;   // one ring slot: A rows then B rows, unpadded
     static constexpr int RING_FLOATS = NBUF * BUF_FLOATS;
-    static constexpr int RED_FLOATS = WAVES_M * WAVES_N * (WAVES_K - 1) * WTM * WTN * 16 * 64;
-    static constexpr int RING_OR_RED_FLOATS = RING_FLOATS > RED_FLOATS ? RING_FLOATS : RED_FLOATS;
-    static constexpr int LDS_FLOATS = RING_OR_RED_FLOATS;
+    static constexpr int EPI_FLOATS = NW * WTM * WTN * 1024;   // every wave parks its 32x32 accumulator tiles for the epilogue
+    static constexpr int LDS_FLOATS = RING_FLOATS > EPI_FLOATS ? RING_FLOATS : EPI_FLOATS;
     static_assert(BK == 32 || BK == 64, "row swizzle is defined for 8 or 16 slots per row");
     static_assert((BK / 8) % WAVES_K == 0, "each wave needs whole k-steps of a chunk");
     static_assert(STEP % 16 == 0, "a lane's rows must agree mod 16 so that its swizzle (and k position) is the same for all of them");
@@ -429,12 +431,14 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         }
     };
 
-    // the bias is needed only by the epilogue: fetch it now so that its latency is not exposed at the end
-    float bias_v[WTN];
+    // the bias is needed only by the epilogue (4 consecutive channels per thread): fetch it now so that its latency is
+    // not exposed at the end
+    float bias_v[4];
+    {
+        const int nb = n0 + 4 * (tid % (C::BN / 4));
 #pragma unroll
-    for (int j = 0; j < WTN; ++j) {
-        const int n = n0 + (wn * WTN + j) * 32 + (lane & 31);
-        bias_v[j] = p.bias ? *(const float __attribute__((address_space(1)))*)(p.bias + (n < p.Cout ? n : p.Cout - 1)) : 0.f;
+        for (int e = 0; e < 4; ++e)
+            bias_v[e] = p.bias ? *(const float __attribute__((address_space(1)))*)(p.bias + (nb + e < p.Cout ? nb + e : p.Cout - 1)) : 0.f;
     }
 
     // ---- prologue: chunks 0 .. D-1 in flight (chunks past K are all-zero, so the counts below never change) ----
@@ -512,73 +516,92 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    // ---- K-split reduction across the wk waves of one (wm, wn) -------------------------------
-    if (WAVES_K > 1) {
-        float* red = smem;
-        if (wk > 0) {
-            float* dst = red + ((size_t)((wm * WAVES_N + wn) * (WAVES_K - 1) + (wk - 1)) * WTM * WTN * 16) * 64 + lane;
+    // ---- epilogue: every wave parks its accumulators in LDS, then ALL threads of the workgroup reduce the K-split
+    // partials (fixed order wk = 0, 1, ..), add the bias, apply ReLU / accumulate / mask / sigmoid and store 4 consecutive
+    // channels per lane (one 16-byte store).  The former epilogue - wave wk = 0 alone, one 4-byte store per accumulator
+    // register behind a ladder of per-element branches - was 1700 instructions of straight-line code executed once:
+    // 2.0 us of a 9 us launch at M = 784 (tools/conv_timeline.py), most of it instruction fetch.
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    {
+        float* slab = smem + (size_t)(((wm * WAVES_N + wn) * WAVES_K + wk) * WTM * WTN) * 1024 + (lane >> 5) * 128 + (lane & 31);
 #pragma unroll
-            for (int i = 0; i < WTM; ++i)
+        for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j)
+            for (int j = 0; j < WTN; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) dst[((i * WTN + j) * 16 + r) * 64] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (wk == 0) {
-#pragma unroll
-            for (int s = 0; s < WAVES_K - 1; ++s) {
-                const float* src = red + ((size_t)((wm * WAVES_N + wn) * (WAVES_K - 1) + s) * WTM * WTN * 16) * 64 + lane;
-#pragma unroll
-                for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WTN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * WTN + j) * 16 + r) * 64];
-            }
-        }
+                for (int r = 0; r < 16; ++r) slab[(i * WTN + j) * 1024 + ((r & 3) + 8 * (r >> 2)) * 32] = acc[i][j][r];
     }
-    FCN_STAMP(4);      // K-split reduction done
-    if (wk != 0) return;
-
-    // ---- epilogue: bias, ReLU / sigmoid, NHWC store at a channel offset ----------------------
-    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    __syncthreads();
+    FCN_STAMP(4);      // accumulators parked
+    constexpr int C4 = C::BN / 4;                   // float4 columns of the output tile
+    static_assert(C::NT % C4 == 0, "every thread keeps one float4 column");
+    const int c4 = tid % C4;                        // the same for all items of this thread
+    const int n = n0 + 4 * c4;
+    if (n >= p.Cout) return;
     const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
     const bool do_sig2 = (p.flags & FCN_CONV_SIGMOID2) != 0 && p.y2 != nullptr;
     const bool do_mask = (p.flags & FCN_CONV_MASK) != 0 && p.y2 != nullptr;      // ReLU backward of the layer below (y2 = its activation)
     const bool do_accum = (p.flags & FCN_CONV_ACCUM) != 0;
     const bool out_f32 = (p.flags & FCN_CONV_OUT_F32) != 0;      // f16 inputs, f32 output blob (the detection heads)
     const bool out_f16 = (p.flags & FCN_CONV_OUT_F16) != 0;      // f32 inputs, f16 output blob (the first layer of an f16 net)
+    const bool half_out = (F16 && !out_f32) || (!F16 && out_f16);
+    // 16-byte (8-byte for halves) accesses need the whole group inside the output slice and aligned
+    const bool vec = n + 3 < p.Cout && ((p.y_cstride | p.y_coffset) & 3) == 0 && ((p.y2_cstride | p.y2_coffset) & 3) == 0 &&
+                     ((unsigned)(size_t)p.y & 15) == 0 && ((unsigned)(size_t)p.y2 & 15) == 0;
+    const int wn_t = (4 * c4) / (32 * WTN), jt = ((4 * c4) / 32) % WTN, lc = (4 * c4) & 31;
+    const float* lds_col = smem + (size_t)(wn_t * WAVES_K * WTM * WTN + jt) * 1024 + lc;
+#pragma unroll 1
+    for (int it = tid / C4; it < BM; it += C::NT / C4) {
+        const int m = m0 + it;
+        if (m >= p.M) break;
+        const int wm_t = it / (32 * WTM), i_t = (it / 32) % WTM;
+        const float* src = lds_col + (size_t)(wm_t * WAVES_N * WAVES_K * WTM * WTN + i_t * WTN) * 1024 + (it & 31) * 32;
+        v4f v = *(const v4f*)src;
 #pragma unroll
-    for (int j = 0; j < WTN; ++j) {
-        const int n = n0 + (wn * WTN + j) * 32 + (lane & 31);
-        if (n >= p.Cout) continue;
-        const float bv = bias_v[j];
+        for (int s = 1; s < WAVES_K; ++s) v += *(const v4f*)(src + (size_t)s * WTM * WTN * 1024);
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) {
-            const int mrow = m0 + (wm * WTM + i) * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow + (r & 3) + 8 * (r >> 2);
-                if (m < p.M) {
-                    float v = acc[i][j][r] + bv;
-                    const size_t o = (size_t)m * p.y_cstride + p.y_coffset + n;
-                    if ((F16 && !out_f32) || (!F16 && out_f16)) {      // f16 activations: rounded once, after bias and ReLU
-                        typedef f16_t __attribute__((address_space(1))) * gh_ptr;
-                        gh_ptr dst = (gh_ptr)(reinterpret_cast<f16_t*>(p.y) + o);
-                        if (do_accum) v += (float)*dst;
-                        if (do_relu) v = fmaxf(v, 0.f);
-                        *dst = (f16_t)v;
-                    } else {
-                        gf_ptr dst = (gf_ptr)(p.y + o);
-                        if (do_accum) v += *dst;
-                        if (do_relu) v = fmaxf(v, 0.f);
-                        if (do_mask) v = *(gf_ptr)(p.y2 + (size_t)m * p.y2_cstride + p.y2_coffset + n) > 0.f ? v : 0.f;
-                        *dst = v;
+        for (int e = 0; e < 4; ++e) v[e] += bias_v[e];
+        const size_t o = (size_t)m * p.y_cstride + p.y_coffset + n;
+        const size_t o2 = (size_t)m * p.y2_cstride + p.y2_coffset + n;
+        if (half_out) {      // f16 activations: rounded once, after bias and ReLU
+            typedef f16_t v4h __attribute__((ext_vector_type(4)));
+            f16_t* dst = reinterpret_cast<f16_t*>(p.y) + o;
+            if (vec) {
+                if (do_accum) { const v4h old = *(const v4h*)dst; for (int e = 0; e < 4; ++e) v[e] += (float)old[e]; }
+                if (do_relu) for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                v4h h;
+                for (int e = 0; e < 4; ++e) h[e] = (f16_t)v[e];
+                *(v4h*)dst = h;
+            } else {
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.Cout) {
+                        float t = v[e];
+                        if (do_accum) t += (float)dst[e];
+                        if (do_relu) t = fmaxf(t, 0.f);
+                        dst[e] = (f16_t)t;
                     }
-                    if (do_sig2) *(gf_ptr)(p.y2 + (size_t)m * p.y2_cstride + p.y2_coffset + n) = 1.f / (1.f + expf(-v));
-                }
             }
+        } else if (vec) {
+            float* dst = p.y + o;
+            if (do_accum) v += *(const v4f*)dst;
+            if (do_relu) for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            if (do_mask) { const v4f a = *(const v4f*)(p.y2 + o2); for (int e = 0; e < 4; ++e) v[e] = a[e] > 0.f ? v[e] : 0.f; }
+            *(v4f*)dst = v;
+            if (do_sig2) {
+                v4f sg;
+                for (int e = 0; e < 4; ++e) sg[e] = 1.f / (1.f + expf(-v[e]));
+                *(v4f*)(p.y2 + o2) = sg;
+            }
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.Cout) {
+                    float t = v[e];
+                    if (do_accum) t += p.y[o + e];
+                    if (do_relu) t = fmaxf(t, 0.f);
+                    if (do_mask) t = p.y2[o2 + e] > 0.f ? t : 0.f;
+                    p.y[o + e] = t;
+                    if (do_sig2) p.y2[o2 + e] = 1.f / (1.f + expf(-t));
+                }
         }
     }
 #ifdef FCN_CONV_STAMPS
@@ -598,8 +621,20 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
+    // The launch's fixed cost is what counts at M = 784 (9 us launches, 1.5 us of MFMA work): the problem table and the
+    // problem itself are fetched from the kernarg segment with TWO scalar round trips - written as inline asm because the
+    // compiler sinks each field's load to its first use and pays four or five dependent round trips instead.
+    typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+    typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
+    karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(offsetof(GroupArgs, nprob) == 0 && offsetof(GroupArgs, tile_end) == 4 && offsetof(GroupArgs, npool) == 4 + 4 * kMaxGroup &&
+                      kMaxGroup == 8, "head of GroupArgs = one s_load_dwordx16");
+    u32x16 head;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(head) : "s"(ka) : "memory");
     const int tile = blockIdx.x;
-    const int conv_tiles = a.tile_end[kMaxGroup - 1];      // the host repeats the last prefix in the unused entries
+    const int nprob = (int)head[0];
+    const int conv_tiles = (int)head[kMaxGroup];      // the host repeats the last prefix in the unused entries
     if (tile >= conv_tiles) {      // workgroups behind the convolution tiles: the poolings fused into this launch
         const int w = tile - conv_tiles;
         if (w < a.pool[0].wg_end) pool_body<T, 64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[0], w);
@@ -609,17 +644,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_gro
     int pi = 0, begin = 0;
 #pragma unroll
     for (int i = 0; i < kMaxGroup - 1; ++i) {      // tile_end is increasing: count the problems that end at or before this tile
-        const bool past = i + 1 < a.nprob && tile >= a.tile_end[i];
+        const int end_i = (int)head[1 + i];
+        const bool past = i + 1 < nprob && tile >= end_i;
         pi += past ? 1 : 0;
-        begin = past ? a.tile_end[i] : begin;
+        begin = past ? end_i : begin;
     }
-    typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
-    karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    union { ConvP p; unsigned w[sizeof(ConvP) / 4]; } u;     // scalar loads from the kernarg segment at a scalar offset
-    const unsigned __attribute__((address_space(4)))* src = (const unsigned __attribute__((address_space(4)))*)&ka->p[pi];
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(ConvP) / 4); ++i) u.w[i] = src[i];
-    conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(u.p, tile - begin, smem);
+    u32x16 ra, rb;
+    u32x8 rc;
+    pi = __builtin_amdgcn_readfirstlane(pi);      // (the compiler takes the asm's outputs for divergent)
+    begin = __builtin_amdgcn_readfirstlane(begin);
+    const ConvP __attribute__((address_space(4)))* pbase = &ka->p[pi];
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx8 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(ra), "=&s"(rb), "=&s"(rc)
+                 : "s"(pbase)
+                 : "memory");
+    ConvP prob;
+    __builtin_memcpy((char*)&prob, &ra, 64);
+    __builtin_memcpy((char*)&prob + 64, &rb, 64);
+    __builtin_memcpy((char*)&prob + 128, &rc, 32);
+    conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(prob, tile - begin, smem);
 }
 
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
@@ -719,6 +762,7 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
     p.ow_magic = (d.OW > 1 && (long long)p.M * d.OW < (1ll << 32)) ? (unsigned)(((1ull << 32) + d.OW - 1) / d.OW) : 0u;
     p.oh_magic = (d.OH > 1 && (long long)p.M * d.OH < (1ll << 32)) ? (unsigned)(((1ull << 32) + d.OH - 1) / d.OH) : 0u;
     p.zero_page = zero_page;
+    p.pad_[0] = p.pad_[1] = 0;
 }
 
 // Heuristic used when the caller does not autotune (cfg_request = -1).  Fitted to tools/conv_sweep.py on

@@ -10,8 +10,10 @@ control plane: barrier, small all-gathers (timings, the RCCL unique id) over loc
 """
 from __future__ import annotations
 
+import hashlib
+import hmac
+import json
 import os
-import pickle
 import socket
 import struct
 import time
@@ -37,55 +39,100 @@ def shard_range(total: int, rank: int, world: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def _send(sock: socket.socket, obj: Any) -> None:
-    data = pickle.dumps(obj, protocol=4)
-    sock.sendall(struct.pack("!Q", len(data)) + data)
+MAX_MESSAGE = 1 << 20      # control-plane messages are ranks, timings, error strings and the 128-byte RCCL id
+_MAC = 32
 
 
-def _recv(sock: socket.socket) -> Any:
-    hdr = b""
-    while len(hdr) < 8:
-        chunk = sock.recv(8 - len(hdr))
-        if not chunk:
-            raise ConnectionError("control plane: peer closed the connection")
-        hdr += chunk
-    (n,) = struct.unpack("!Q", hdr)
+def _to_wire(obj: Any) -> Any:
+    if isinstance(obj, (bytes, bytearray)):
+        return {"__bytes__": bytes(obj).hex()}
+    if isinstance(obj, (list, tuple)):
+        return [_to_wire(v) for v in obj]
+    if isinstance(obj, dict):
+        return {str(k): _to_wire(v) for k, v in obj.items()}
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    raise TypeError("control plane: cannot send a %s (only None, bool, int, float, str, bytes, list, dict)" % type(obj).__name__)
+
+
+def _from_wire(obj: Any) -> Any:
+    if isinstance(obj, dict):
+        if set(obj) == {"__bytes__"}:
+            return bytes.fromhex(obj["__bytes__"])
+        return {k: _from_wire(v) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_from_wire(v) for v in obj]
+    return obj
+
+
+def _recv_exact(sock: socket.socket, n: int) -> bytes:
     buf = bytearray()
     while len(buf) < n:
-        chunk = sock.recv(min(1 << 20, n - len(buf)))
+        chunk = sock.recv(min(1 << 16, n - len(buf)))
         if not chunk:
             raise ConnectionError("control plane: peer closed the connection")
         buf += chunk
-    return pickle.loads(bytes(buf))
+    return bytes(buf)
+
+
+def _send(sock: socket.socket, obj: Any, key: bytes) -> None:
+    """One message = u32 length | HMAC-SHA256(key, payload) | JSON payload.  Nothing on this wire is ever unpickled."""
+    data = json.dumps(_to_wire(obj), separators=(",", ":"), allow_nan=True).encode("utf-8")
+    if len(data) > MAX_MESSAGE:
+        raise ValueError("control plane: message of %d bytes exceeds the %d-byte limit" % (len(data), MAX_MESSAGE))
+    sock.sendall(struct.pack("!I", len(data)) + hmac.new(key, data, hashlib.sha256).digest() + data)
+
+
+def _recv(sock: socket.socket, key: bytes) -> Any:
+    (n,) = struct.unpack("!I", _recv_exact(sock, 4))
+    if n > MAX_MESSAGE:
+        raise ConnectionError("control plane: peer announced a %d-byte message (limit %d)" % (n, MAX_MESSAGE))
+    mac = _recv_exact(sock, _MAC)
+    data = _recv_exact(sock, n)
+    if not hmac.compare_digest(mac, hmac.new(key, data, hashlib.sha256).digest()):
+        raise ConnectionError("control plane: message authentication failed")
+    return _from_wire(json.loads(data.decode("utf-8")))
 
 
 class ControlPlane:
-    """Star-topology collectives over TCP on one node: rank 0 serves, the others connect."""
+    """Star-topology collectives over TCP on one node: rank 0 serves, the others connect.
+
+    Framing is fixed-size headers + JSON (never pickle).  A connection is authenticated before anything it sends is
+    parsed: rank 0 sends a random nonce, the peer answers with its rank and HMAC-SHA256(secret, nonce | rank), rank 0
+    proves itself with HMAC(secret, nonce | "srv"); every later message carries its own MAC.  The secret is $FCN_DP_SECRET
+    (bench.py and the `caffe` tool generate one per job for the ranks they start); without it the job token is used, which
+    is NOT a secret - so rank 0 listens on the loopback interface only unless $FCN_DP_BIND names another address."""
 
     PORT_OFFSETS = tuple(range(1, 33))
 
     def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, addr: Optional[str] = None,
-                 base_port: Optional[int] = None, token: Optional[str] = None, timeout: float = 120.0):
+                 base_port: Optional[int] = None, token: Optional[str] = None, timeout: float = 120.0, secret: Optional[str] = None):
         self.rank = env_rank() if rank is None else int(rank)
         self.world = env_world_size() if world is None else int(world)
         self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         self.base_port = int(base_port if base_port is not None else os.environ.get("MASTER_PORT", "29500"))
         self.token = token or os.environ.get("TORCHELASTIC_RUN_ID", "fcn") + ":%d" % self.world
+        secret = secret if secret is not None else os.environ.get("FCN_DP_SECRET")
+        self.key = hashlib.sha256(("fcn-dp|%s|%s" % (self.token, secret or "")).encode("utf-8")).digest()
         self.timeout = timeout
         self.peers: List[socket.socket] = []
         self.sock: Optional[socket.socket] = None
         if self.world > 1:
             self._connect()
 
+    def _hello_mac(self, nonce: bytes, who: bytes) -> bytes:
+        return hmac.new(self.key, nonce + who, hashlib.sha256).digest()
+
     def _connect(self) -> None:
         deadline = time.time() + self.timeout
         if self.rank == 0:
+            bind_addr = os.environ.get("FCN_DP_BIND", "127.0.0.1")
             srv = None
             for off in self.PORT_OFFSETS:
                 try:
                     srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                    srv.bind((self.addr if self.addr not in ("localhost",) else "127.0.0.1", self.base_port + off))
+                    srv.bind((bind_addr, self.base_port + off))
                     break
                 except OSError:
                     srv.close()
@@ -98,20 +145,23 @@ class ControlPlane:
             while got < self.world - 1:
                 srv.settimeout(max(deadline - time.time(), 0.1))
                 conn, _ = srv.accept()
-                conn.settimeout(self.timeout)
+                conn.settimeout(min(self.timeout, 10.0))
                 try:
-                    hello = _recv(conn)
+                    nonce = os.urandom(16)
+                    conn.sendall(nonce)
+                    reply = _recv_exact(conn, 4 + _MAC)      # fixed size: nothing is parsed before the MAC checks out
+                    (r,) = struct.unpack("!I", reply[:4])
+                    ok = hmac.compare_digest(reply[4:], self._hello_mac(nonce, reply[:4])) and 0 < r < self.world and slots[r] is None
+                    if not ok:
+                        conn.close()
+                        continue
+                    conn.sendall(self._hello_mac(nonce, b"srv"))
                 except Exception:
                     conn.close()
                     continue
-                if not (isinstance(hello, tuple) and len(hello) == 2 and hello[0] == self.token and 0 < hello[1] < self.world
-                        and slots[hello[1]] is None):
-                    _send(conn, "reject")
-                    conn.close()
-                    continue
-                _send(conn, "ok")
+                conn.settimeout(self.timeout)
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                slots[hello[1]] = conn
+                slots[r] = conn
                 got += 1
             srv.close()
             self.peers = [s for s in slots[1:]]
@@ -121,14 +171,17 @@ class ControlPlane:
                 for off in self.PORT_OFFSETS:
                     try:
                         s = socket.create_connection((self.addr, self.base_port + off), timeout=2.0)
-                        s.settimeout(self.timeout)
-                        _send(s, (self.token, self.rank))
-                        if _recv(s) == "ok":
+                        s.settimeout(5.0)
+                        nonce = _recv_exact(s, 16)
+                        me = struct.pack("!I", self.rank)
+                        s.sendall(me + self._hello_mac(nonce, me))
+                        if hmac.compare_digest(_recv_exact(s, _MAC), self._hello_mac(nonce, b"srv")):
+                            s.settimeout(self.timeout)
                             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                             self.sock = s
                             break
                         s.close()
-                    except Exception as e:  # not up yet / someone else's port
+                    except Exception as e:  # not up yet / someone else's port / wrong job
                         last_err = e
                 if self.sock is None:
                     time.sleep(0.2)
@@ -136,16 +189,17 @@ class ControlPlane:
                 raise RuntimeError("control plane: rank %d could not reach rank 0 (%s)" % (self.rank, last_err))
 
     def all_gather(self, obj: Any) -> List[Any]:
-        """Every rank contributes one picklable object; every rank gets the list ordered by rank."""
+        """Every rank contributes one value (None, bool, int, float, str, bytes, lists / dicts of those); every rank gets
+        the list ordered by rank."""
         if self.world == 1:
             return [obj]
         if self.rank == 0:
-            vals = [obj] + [_recv(p) for p in self.peers]
+            vals = [obj] + [_recv(p, self.key) for p in self.peers]
             for p in self.peers:
-                _send(p, vals)
+                _send(p, vals, self.key)
             return vals
-        _send(self.sock, obj)
-        return _recv(self.sock)
+        _send(self.sock, obj, self.key)
+        return _recv(self.sock, self.key)
 
     def barrier(self) -> None:
         self.all_gather(None)

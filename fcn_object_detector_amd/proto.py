@@ -147,10 +147,12 @@ def parse_file(path: str) -> Msg:
 # ----------------------------------------------------------------------------
 # Binary NetParameter (".caffemodel") — the subset that carries weights.
 #
-#   NetParameter { string name = 1; repeated LayerParameter layer = 100; }
+#   NetParameter { string name = 1; repeated V1LayerParameter layers = 2; repeated LayerParameter layer = 100; }
 #   LayerParameter { string name = 1; string type = 2; repeated BlobProto blobs = 7; }
-#   BlobProto { BlobShape shape = 7; repeated float data = 5 [packed];
-#               int32 num=1, channels=2, height=3, width=4 (legacy 4-d shape) }
+#   V1LayerParameter { string name = 4; LayerType type = 5; repeated BlobProto blobs = 6; }
+#   BlobProto { BlobShape shape = 7; repeated float data = 5 [packed]; repeated double double_data = 8 [packed];
+#               int32 num=1, channels=2, height=3, width=4 (legacy 4-d shape);
+#               NVCaffe: Type raw_data_type = 10; bytes raw_data = 12 }
 #   BlobShape { repeated int64 dim = 1 [packed]; }
 # Field numbers restated from the public BVLC caffe.proto (not vendored by the
 # reference); unknown fields are skipped on read.
@@ -206,10 +208,26 @@ def _fields(buf: bytes) -> Iterator[Tuple[int, int, Any]]:
         yield num, wt, v
 
 
+# NVCaffe's BlobProto extension (0.16+; restated from the public NVIDIA/caffe caffe.proto): enum Type and raw byte storage
+_NV_TYPE_DTYPE = {0: "<f8", 1: "<f4", 2: "<f2", 3: "<i4", 4: "<u4"}      # DOUBLE, FLOAT, FLOAT16, INT, UINT
+
+
+def _packed_or_single(chunks: List[np.ndarray], wt: int, v: Any, dtype: str, single_wt: int) -> None:
+    if wt == 2 or wt == single_wt:      # packed run, or one un-packed element (both are legal encodings of a repeated scalar)
+        chunks.append(np.frombuffer(bytes(v), dtype=dtype))
+
+
 def _decode_blob(buf: bytes) -> np.ndarray:
+    """BlobProto -> float32 array.  `data` (5, float) / `double_data` (8, double, what a double-precision Caffe build
+    writes) / NVCaffe `raw_data` (12, bytes, element type in `raw_data_type` = 10); shape from BlobShape (7) or the legacy
+    num / channels / height / width (1..4) of V1-era files; diff fields (6, 9, 11, 13) are ignored as Caffe ignores them
+    when copying trained layers."""
     dims: List[int] = []
     legacy = {}
-    chunks: List[np.ndarray] = []
+    f32: List[np.ndarray] = []
+    f64: List[np.ndarray] = []
+    raw: Optional[bytes] = None
+    raw_type = 1
     for num, wt, v in _fields(buf):
         if num == 7 and wt == 2:  # BlobShape
             for n2, wt2, v2 in _fields(v):
@@ -220,13 +238,26 @@ def _decode_blob(buf: bytes) -> np.ndarray:
                         dims.append(d)
                 elif n2 == 1 and wt2 == 0:
                     dims.append(v2)
-        elif num == 5 and wt == 2:
-            chunks.append(np.frombuffer(v, dtype="<f4"))
-        elif num == 5 and wt == 5:
-            chunks.append(np.frombuffer(v, dtype="<f4"))
+        elif num == 5:
+            _packed_or_single(f32, wt, v, "<f4", 5)
+        elif num == 8:
+            _packed_or_single(f64, wt, v, "<f8", 1)
+        elif num == 10 and wt == 0:
+            raw_type = int(v)
+        elif num == 12 and wt == 2:
+            raw = bytes(v)
         elif num in (1, 2, 3, 4) and wt == 0:
             legacy[num] = v
-    data = np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+    if f32:
+        data = np.concatenate(f32)
+    elif f64:
+        data = np.concatenate(f64).astype(np.float32)
+    elif raw is not None:
+        if raw_type not in _NV_TYPE_DTYPE:
+            raise ValueError("caffemodel: raw_data of unknown raw_data_type %d" % raw_type)
+        data = np.frombuffer(raw, dtype=_NV_TYPE_DTYPE[raw_type]).astype(np.float32)
+    else:
+        data = np.zeros(0, np.float32)
     if not dims and legacy:
         dims = [legacy.get(k, 1) for k in (1, 2, 3, 4)]
     if dims and int(np.prod(dims)) == data.size:
@@ -235,23 +266,61 @@ def _decode_blob(buf: bytes) -> np.ndarray:
 
 
 def read_caffemodel(path: str) -> Dict[str, List[np.ndarray]]:
-    """Return ``{layer_name: [blob0, blob1, ...]}`` from a binary NetParameter."""
+    """Return ``{layer_name: [blob0, blob1, ...]}`` from a binary NetParameter.
+
+    Both generations of the format are read: ``layer`` (field 100, LayerParameter: name = 1, blobs = 7) and the V1
+    ``layers`` (field 2, V1LayerParameter: name = 4, blobs = 6) that model-zoo files such as
+    VGG_ILSVRC_16_layers.caffemodel - the fine-tune source of the reference's train/bounding_box/train.sh:12-15 - are
+    stored in.  Caffe upgrades V1 nets on load (UpgradeV1Net) and then copies by layer name; the names survive unchanged."""
     with open(path, "rb") as f:
         buf = f.read()
     out: Dict[str, List[np.ndarray]] = {}
     for num, wt, v in _fields(buf):
-        if num != 100 or wt != 2:  # V2 'layer'; V1 'layers'=2 is not produced by the reference's Caffe
+        if wt != 2 or num not in (100, 2):
             continue
+        name_field, blob_field = (1, 7) if num == 100 else (4, 6)
         name: Optional[str] = None
         blobs: List[np.ndarray] = []
         for n2, wt2, v2 in _fields(v):
-            if n2 == 1 and wt2 == 2:
+            if n2 == name_field and wt2 == 2:
                 name = bytes(v2).decode("utf-8")
-            elif n2 == 7 and wt2 == 2:
+            elif n2 == blob_field and wt2 == 2:
                 blobs.append(_decode_blob(v2))
+            elif num == 2 and n2 == 1 and wt2 == 2:
+                raise ValueError("%s: V0-format layer (V1LayerParameter.layer = 1) - upgrade the file with Caffe's upgrade_net_proto_binary" % path)
         if name is not None and blobs:
             out[name] = blobs
     return out
+
+
+def copy_trained_layers(path: str, params_host: Dict[str, List[np.ndarray]], set_params, log=None) -> List[str]:
+    """Net::CopyTrainedLayersFrom: copy the blobs of every layer of `path` whose NAME the net has; source layers the net
+    lacks are ignored (logged, as Caffe does), layers of the net the file lacks keep their values.  Blob counts and
+    element counts must fit.  A file that holds no parameter blobs at all is an error, and a file none of whose layers
+    match is reported loudly: `--weights` would otherwise train from the fillers while claiming to fine-tune."""
+    import sys
+    if log is None:
+        log = lambda m: sys.stderr.write(m + "\n")      # noqa: E731
+    blobs = read_caffemodel(path)
+    if not blobs:
+        raise ValueError("%s: no layer with parameter blobs found (not a binary NetParameter, or a format this reader does not know)" % path)
+    copied: List[str] = []
+    for lname, arrs in blobs.items():
+        want = params_host.get(lname)
+        if want is None:
+            log("Ignoring source layer %s" % lname)
+            continue
+        if len(arrs) != len(want):
+            raise ValueError("Incompatible number of blobs for layer %s: %s has %d, the net needs %d" % (lname, path, len(arrs), len(want)))
+        for a, w in zip(arrs, want):
+            if a.size != w.size:
+                raise ValueError("Cannot copy param of layer %s: %s holds %s, the net needs %s" % (lname, path, a.shape, w.shape))
+        set_params(lname, [a.reshape(w.shape) for a, w in zip(arrs, want)])
+        copied.append(lname)
+    if not copied:
+        log("WARNING: %s matched NONE of the net's %d parameter layers (%d source layers ignored): every layer keeps its filler values"
+            % (path, len(params_host), len(blobs)))
+    return copied
 
 
 def _ld(num: int, payload: bytes) -> bytes:

@@ -210,17 +210,9 @@ class Net(object):
     # ---- weights ------------------------------------------------------
     def copy_from(self, weights_path: str) -> None:
         """Load a binary .caffemodel by layer name (Net::CopyTrainedLayersFrom)."""
-        blobs = _proto.read_caffemodel(weights_path)
-        for lname, arrs in blobs.items():
-            if lname not in self._engine.params_host:
-                continue
-            want = self._engine.params_host[lname]
-            if len(arrs) != len(want):
-                raise ValueError("layer %s: caffemodel has %d blobs, net needs %d" % (lname, len(arrs), len(want)))
-            for a, w in zip(arrs, want):
-                if a.size != w.size:
-                    raise ValueError("layer %s: cannot copy param of %d elements into %s" % (lname, a.size, w.shape))
-            self._engine.set_params(lname, [a.reshape(w.shape) for a, w in zip(arrs, want)])
+        if not os.path.isfile(weights_path):
+            raise IOError("weights file not found: %s" % weights_path)
+        _proto.copy_trained_layers(weights_path, self._engine.params_host, self._engine.set_params)
 
     def save(self, path: str) -> None:
         layers = [(l.name, l.type, self._engine.params_host[l.name]) for l in self._spec.param_layers()]

@@ -81,13 +81,7 @@ class TrainNet(object):
         if not os.path.isfile(weights_path):
             raise IOError("weights file not found: %s" % weights_path)
         eng = self._s.engine
-        for lname, arrs in proto.read_caffemodel(weights_path).items():
-            want = eng.params_host.get(lname)
-            if want is None:
-                continue
-            if len(arrs) != len(want) or any(a.size != w.size for a, w in zip(arrs, want)):
-                raise ValueError("layer %s: parameter blobs in %s do not fit the net" % (lname, weights_path))
-            eng.set_params(lname, [a.reshape(w.shape) for a, w in zip(arrs, want)])
+        proto.copy_trained_layers(weights_path, eng.params_host, eng.set_params, log=self._s.log)
 
     def save(self, path: str) -> None:
         self._s.engine.save(path)

@@ -59,3 +59,70 @@ def test_single_rank_is_local():
     assert cp.all_gather(5) == [5] and cp.max(2.5) == 2.5
     cp.barrier()
     assert dp.shard_range(7, 0, 1) == (0, 7)
+
+
+def _rank0_with_intruder(port, q):
+    cp = dp.ControlPlane(0, 2, "127.0.0.1", port, token="t:2", timeout=30, secret="s3cret")
+    q.put(("gathered", cp.all_gather("zero")))
+    cp.close()
+
+
+def test_unauthenticated_peers_are_dropped_before_anything_is_parsed():
+    """A peer that does not know the job secret (wrong MAC, a pickle bomb, a huge length prefix) never reaches the
+    message parser; the real rank 1 still joins afterwards."""
+    import pickle
+    import struct
+    import time
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    p0 = ctx.Process(target=_rank0_with_intruder, args=(port, q))
+    p0.start()
+    deadline = time.time() + 20
+    intruded = 0
+    payloads = [struct.pack("!I", 1) + b"\0" * 32,                                   # right shape, wrong MAC
+                struct.pack("!Q", 1 << 40) + pickle.dumps(("t:2", 1, "x" * 64)),    # the old pickle hello with a giant length
+                b"\xff" * 36]
+    while intruded < len(payloads) and time.time() < deadline:
+        for off in dp.ControlPlane.PORT_OFFSETS:
+            try:
+                s = socket.create_connection(("127.0.0.1", port + off), timeout=1.0)
+            except OSError:
+                continue
+            s.settimeout(5.0)
+            assert len(s.recv(16)) == 16                                             # the nonce
+            s.sendall(payloads[intruded])
+            try:
+                assert s.recv(64) == b""                                             # dropped: no "srv" proof, no data
+            except ConnectionResetError:
+                pass
+            s.close()
+            intruded += 1
+            break
+        else:
+            time.sleep(0.1)
+    assert intruded == len(payloads)
+    cp = dp.ControlPlane(1, 2, "127.0.0.1", port, token="t:2", timeout=30, secret="s3cret")
+    assert cp.all_gather("one") == ["zero", "one"]
+    cp.close()
+    assert q.get(timeout=30) == ("gathered", ["zero", "one"])
+    p0.join(30)
+    assert p0.exitcode == 0
+
+
+def test_wire_format_is_json_with_bytes_and_a_size_cap():
+    import pytest
+    a, b = socket.socketpair()
+    key = b"k" * 32
+    msg = {"uid": bytes(range(128)), "t": [1.5, None, "x"], "n": 3}
+    dp._send(a, msg, key)
+    assert dp._recv(b, key) == msg
+    dp._send(a, "tampered", key)
+    with pytest.raises(ConnectionError, match="authentication"):
+        dp._recv(b, b"another key".ljust(32, b"."))
+    with pytest.raises(ValueError, match="exceeds"):
+        dp._send(a, "x" * (dp.MAX_MESSAGE + 1), key)
+    with pytest.raises(TypeError):
+        dp._send(a, object(), key)
+    a.close()
+    b.close()
