@@ -124,6 +124,31 @@ def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
            "workload": "configs[%d]: DetectNet GoogLeNet train step (device target generation + fwd + bwd + %s + SGD), batch %d/GPU, 448x448, f32"
                        % (2 if world == 1 else 3, "RCCL all-reduce of 23.9 MB grads" if world > 1 else "no collective", n)}
     res["achieved_tflops"] = round(45.9e-3 * res["imgs_per_s"], 2)
+    if comm is not None:
+        # the collective by itself, and how much of it the backward pass hides.  "dry" = the same step
+        # with every bucket's hand-off (events, stream waits) but no ncclAllReduce behind it.
+        ar = eng.time_allreduce(reps=10)
+        cp.barrier()
+        eng.comm_dry = True
+        for it in range(2):
+            eng.step(seed=it, upload=False)
+        L.call("fcn_device_sync")
+        cp.barrier()
+        t0 = time.perf_counter()
+        dry_steps = max(min(steps, 10), 3)
+        for it in range(dry_steps):
+            eng.step(seed=2000 + it, upload=False)
+        L.call("fcn_device_sync")
+        t_dry = cp.max(time.perf_counter() - t0) * 1e3 / dry_steps
+        eng.comm_dry = False
+        ar_us = cp.max(ar["allreduce_us"])
+        exposed_us = max(res["ms_per_step"] - t_dry, 0.0) * 1e3
+        res["allreduce"] = {"us_alone": round(ar_us, 1), "bytes": ar["bytes"], "buckets": ar["buckets"],
+                            "bus_GBps": round(2.0 * (world - 1) / world * ar["bytes"] / (ar_us * 1e-6) / 1e9, 1) if ar_us else 0.0,
+                            "ms_per_step_without_collective": round(t_dry, 3), "exposed_us_per_step": round(exposed_us, 1),
+                            "overlap_fraction": round(min(max(1.0 - exposed_us / ar_us, 0.0), 1.0), 3) if ar_us else None,
+                            "note": "us_alone = all gradient buckets back to back on an otherwise idle GPU (max over ranks); "
+                                    "exposed = step time with the collective - step time without it; bus GB/s = 2(G-1)/G x bytes / us_alone"}
     eng.close()
     # The same step driven by the reference's data layer (BASELINE configs[2] names it): DataArgumentationLayer plans a
     # scene per image on the host (RNG + box bookkeeping), the device composes / normalises it from HBM-resident object
@@ -352,16 +377,25 @@ def main() -> None:
     ap.add_argument("--in-flight", type=int, default=4, help="frames in flight: replicas of the batch-1 engine on their own streams "
                                                              "(1 = one stream, launches strictly serial)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the VGG16-FCN (train/fcn_bbox) measurements reported under 'secondary'")
+    ap.add_argument("--devices", default="", help="GPU id of every rank, comma separated (default 0..N-1; rehearsals on a one-GPU box: 0,0 with --no-train)")
     args = ap.parse_args()
 
-    from fcn_object_detector_amd import dp, lib as L, models, proto
+    from fcn_object_detector_amd import dp      # (touches no GPU)
+    if args.gpus > 1 and not dp.launched_as_rank():
+        # `python bench.py --gpus N` by itself: start one fresh process per GPU BEFORE anything in this process touches the
+        # GPU (a process that has initialised HIP is never re-executed or forked); this launcher only waits.  Rank 0 prints
+        # the JSON line on the inherited stdout.  Under `python -m torch.distributed.run` the ranks already exist.
+        devices = [int(d) for d in args.devices.split(",") if d != ""] or list(range(args.gpus))
+        if len(devices) != args.gpus:
+            raise SystemExit("bench.py: --devices names %d GPUs for --gpus %d" % (len(devices), args.gpus))
+        sys.exit(dp.spawn_ranks(__file__, sys.argv[1:], devices))
+    rank, world, local = dp.env_rank(), dp.env_world_size(), dp.env_device()
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
+
+    from fcn_object_detector_amd import lib as L, models, proto
     from fcn_object_detector_amd.engine import Engine, ForwardPipeline
     from fcn_object_detector_amd.netspec import NetSpec, fill_params
-
-    rank, world, local = dp.env_rank(), dp.env_world_size(), dp.env_local_rank()
-    if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     cp = dp.ControlPlane(rank, world)
 
     msg = proto.parse_text(models.googlenet_detectnet_deploy(args.batch, 448, 448, 4))

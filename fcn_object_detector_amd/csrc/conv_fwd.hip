@@ -88,9 +88,11 @@ struct ConvP {
     float in_shift;   // unused by the kernel (kept so the struct mirrors fcn_conv_desc)
     int kw_magic;
     int M, K, tiles_m, tiles_n, tile_end;  // tile_end: exclusive prefix end of this problem's tiles in a group launch
-    unsigned ow_magic, oh_magic;          // ceil(2^32 / OW), ceil(2^32 / OH) when exact for every m < M, else 0 (= divide)
+    unsigned ow_magic, oh_magic;          // ceil(2^32 / OW), ceil(2^32 / OH): exact for every m < M (validate()); 0: OW / OH == 1
     const float* zero_page;               // 16 zero bytes in HBM: what out-of-image / out-of-tile lanes load
-    int pad_[2];                          // 160 bytes: the group kernel fetches a problem with three wide scalar loads
+    unsigned tiles_n_magic;               // ceil(2^32 / tiles_n): tile / tiles_n without a division (tiles * tiles_n < 2^32), 0: tiles_n == 1
+    unsigned cin_magic24;                 // ceil(2^24 / Cin): k / Cin for k < 256 (Cin <= 16384)
+                                          // (160 bytes: the group kernel fetches a problem with three wide scalar loads)
 };
 static_assert(sizeof(ConvP) == 160, "conv_fwd_group loads a ConvP as 16 + 16 + 8 dwords");
 
@@ -163,9 +165,10 @@ __device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
     }
 }
 
-__device__ __forceinline__ int fast_div(int m, unsigned magic, int d) {
-    return magic ? (int)__umulhi((unsigned)m, magic) : m / d;
-}
+// m / d through the host's multiplier ceil(2^32 / d) (exact while m * d < 2^32, which validate() / plan_tiles_cfg guarantee);
+// magic 0 stands for d == 1.  No division fallback on purpose: an integer division is ~30 instructions, and the launch
+// prologue is straight-line code that every workgroup runs once from a cold instruction cache.
+__device__ __forceinline__ int fast_div(int m, unsigned magic) { return magic ? (int)__umulhi((unsigned)m, magic) : m; }
 
 
 template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
@@ -253,7 +256,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const int wn = (wid / WAVES_K) % WAVES_N;
     const int wm = wid / (WAVES_K * WAVES_N);
 
-    const int tile_m = tile / p.tiles_n;
+    // (an integer division is ~30 instructions of straight-line code that every workgroup executes once from a cold
+    // instruction cache: the launch prologue uses host-computed multipliers instead)
+    const int tile_m = fast_div(tile, p.tiles_n_magic);
     const int tile_n = tile - tile_m * p.tiles_n;
     const int m0 = tile_m * BM;
     const int n0 = tile_n * C::BN;
@@ -263,18 +268,18 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const int lseg = (lane % SEGS) ^ swz<SEGS>(lrow);          // k-segment this lane fetches (same for all its rows)
     // k position of that segment, kept as (tap, channel) and advanced by BK per chunk without branches
     int kc = lseg * EPS;
-    int kt = kc / p.Cin;
+    int kt = (int)(((unsigned)kc * p.cin_magic24) >> 24);      // kc / Cin (kc < 256)
     kc -= kt * p.Cin;
-    const int bk_taps = BKE / p.Cin, bk_rem = BKE - bk_taps * p.Cin;
+    const int bk_taps = (int)(((unsigned)BKE * p.cin_magic24) >> 24), bk_rem = BKE - bk_taps * p.Cin;      // BKE / Cin
     int a_iy0[IA], a_ix0[IA], a_off[IA];   // window origin and its element offset (32-bit: validated on the host)
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
         const int m = m0 + STEP * i + lrow;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int t = fast_div(mm, p.ow_magic, p.OW);
+        const int t = fast_div(mm, p.ow_magic);
         const int ox = mm - t * p.OW;
-        const int img = fast_div(t, p.oh_magic, p.OH);
+        const int img = fast_div(t, p.oh_magic);
         const int oy = t - img * p.OH;
         a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);   // rows past M never pass the bounds test
         a_ix0[i] = ox * p.stride - p.pad;
@@ -444,8 +449,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // ---- prologue: chunks 0 .. D-1 in flight (chunks past K are all-zero, so the counts below never change) ----
     int buf_issue = 0;                 // ring slot of the next chunk to issue
     auto next = [](int b) { return b + 1 == NBUF ? 0 : b + 1; };
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
+#pragma unroll 1
+    for (int c = 0; c < D; ++c) {      // rolled: straight-line code costs instruction fetches, and this runs once
         issue_chunk(buf_issue);
         buf_issue = next(buf_issue);
     }
@@ -511,10 +516,20 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // cannot see: nothing waits for them, their destination registers are dead, and the register allocator hands those
     // registers to the epilogue (the accumulator copies).  A read that returns late - LDS contended by a co-resident
     // kernel of another stream - then overwrites four consecutive accumulator copies AFTER v_accvgpr_read filled them:
-    // a 32-column x 4-register block of stale partial sums (tools/race_hunt3.py found it).  Retire them.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // a 32-column x 4-register block of stale partial sums (tools/race_hunt3.py found it).  Retire them -
+    // and keep the fragment registers ALIVE across the wait (frags_landed pins them and ends with a scheduling barrier):
+    // a bare `s_waitcnt` asm orders memory operations only, and the scheduler did hoist the epilogue's v_accvgpr_read
+    // into those registers above it (round 2: the two-stream determinism tests caught exactly that).
+    if (PF) {
+        frags_landed(0, 0, KS);
+        frags_landed(1, 0, KS);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue: every wave parks its accumulators in LDS, then ALL threads of the workgroup reduce the K-split
     // partials (fixed order wk = 0, 1, ..), add the bias, apply ReLU / accumulate / mask / sigmoid and store 4 consecutive
@@ -619,22 +634,25 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 }
 
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const GroupArgs a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const int nprob, const int te0, const int te1, const int te2,
+                                                                                  const int te3, const int te4, const int te5, const int te6,
+                                                                                  const int te7, const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
-    // The launch's fixed cost is what counts at M = 784 (9 us launches, 1.5 us of MFMA work): the problem table and the
-    // problem itself are fetched from the kernarg segment with TWO scalar round trips - written as inline asm because the
-    // compiler sinks each field's load to its first use and pays four or five dependent round trips instead.
+    // The launch's fixed cost is what counts at M = 784 (9 us launches, 1.5 us of MFMA work).  The problem table (nprob and
+    // the exclusive tile prefix of every problem) travels as the kernel's first nine SCALAR arguments: the build preloads
+    // them into SGPRs at wave launch (-amdgpu-kernarg-preload-count, Makefile), so a workgroup knows its problem without
+    // a memory round trip, and the problem itself is ONE round trip to the kernarg segment - written as inline asm because
+    // the compiler sinks each field's load to its first use and pays four or five dependent round trips instead.
     typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
     typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
-    karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    static_assert(offsetof(GroupArgs, nprob) == 0 && offsetof(GroupArgs, tile_end) == 4 && offsetof(GroupArgs, npool) == 4 + 4 * kMaxGroup &&
-                      kMaxGroup == 8, "head of GroupArgs = one s_load_dwordx16");
-    u32x16 head;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(head) : "s"(ka) : "memory");
+    // the GroupArgs copy sits behind the nine ints in the kernarg segment, at its natural alignment
+    constexpr size_t kArgsOffset = (9 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
+    karg_ptr ka = (karg_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kArgsOffset);
+    const int head[1 + kMaxGroup] = {nprob, te0, te1, te2, te3, te4, te5, te6, te7};
+    static_assert(kMaxGroup == 8, "the tile prefix travels as eight scalar kernel arguments");
     const int tile = blockIdx.x;
-    const int nprob = (int)head[0];
-    const int conv_tiles = (int)head[kMaxGroup];      // the host repeats the last prefix in the unused entries
+    const int conv_tiles = head[kMaxGroup];      // the host repeats the last prefix in the unused entries
     if (tile >= conv_tiles) {      // workgroups behind the convolution tiles: the poolings fused into this launch
         const int w = tile - conv_tiles;
         if (w < a.pool[0].wg_end) pool_body<T, 64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[0], w);
@@ -644,14 +662,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_gro
     int pi = 0, begin = 0;
 #pragma unroll
     for (int i = 0; i < kMaxGroup - 1; ++i) {      // tile_end is increasing: count the problems that end at or before this tile
-        const int end_i = (int)head[1 + i];
+        const int end_i = head[1 + i];
         const bool past = i + 1 < nprob && tile >= end_i;
         pi += past ? 1 : 0;
         begin = past ? end_i : begin;
     }
     u32x16 ra, rb;
     u32x8 rc;
-    pi = __builtin_amdgcn_readfirstlane(pi);      // (the compiler takes the asm's outputs for divergent)
+    pi = __builtin_amdgcn_readfirstlane(pi);      // (uniform already; keeps the address arithmetic below on the scalar unit)
     begin = __builtin_amdgcn_readfirstlane(begin);
     const ConvP __attribute__((address_space(4)))* pbase = &ka->p[pi];
     asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx8 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
@@ -745,6 +763,9 @@ int validate(const fcn_conv_desc& d) {
     FCN_REQUIRE(!((d.flags & FCN_CONV_SIGMOID2) && (d.flags & FCN_CONV_MASK)), FCN_E_ARG, "conv: FCN_CONV_SIGMOID2 and FCN_CONV_MASK both use y2");
     FCN_REQUIRE(!((d.flags & FCN_CONV_MASK) && (d.flags & FCN_CONV_F16)), FCN_E_UNSUPPORTED, "conv: FCN_CONV_MASK is a float32 (training) feature");
     FCN_REQUIRE((long long)d.N * d.OH * d.OW < (1ll << 31), FCN_E_UNSUPPORTED, "conv: problem too large for int32 indexing");
+    // the kernel decodes pixel and tile indices with multiply-high by host-computed reciprocals (no division code on the device)
+    FCN_REQUIRE((long long)d.N * d.OH * d.OW * (d.OW > d.OH ? d.OW : d.OH) < (1ll << 32) && d.Cin <= 16384, FCN_E_UNSUPPORTED,
+                "conv: N*OH*OW*max(OH,OW) must stay below 2^32 and Cin at most 16384 (split the batch)");
     return 0;
 }
 
@@ -759,10 +780,11 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
     p.tiles_m = p.tiles_n = p.tile_end = 0;
     p.kw_magic = (65536 + d.kw - 1) / d.kw;
     // m / OW == umulhi(m, ceil(2^32 / OW)) for every m with m * OW < 2^32 (error term < OW per 2^32)
-    p.ow_magic = (d.OW > 1 && (long long)p.M * d.OW < (1ll << 32)) ? (unsigned)(((1ull << 32) + d.OW - 1) / d.OW) : 0u;
-    p.oh_magic = (d.OH > 1 && (long long)p.M * d.OH < (1ll << 32)) ? (unsigned)(((1ull << 32) + d.OH - 1) / d.OH) : 0u;
+    p.ow_magic = d.OW > 1 ? (unsigned)(((1ull << 32) + d.OW - 1) / d.OW) : 0u;
+    p.oh_magic = d.OH > 1 ? (unsigned)(((1ull << 32) + d.OH - 1) / d.OH) : 0u;
     p.zero_page = zero_page;
-    p.pad_[0] = p.pad_[1] = 0;
+    p.tiles_n_magic = 0;      // plan_tiles_cfg
+    p.cin_magic24 = (unsigned)(((1u << 24) + d.Cin - 1) / d.Cin);
 }
 
 // Heuristic used when the caller does not autotune (cfg_request = -1).  Fitted to tools/conv_sweep.py on
@@ -802,6 +824,9 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
     for (int i = 0; i < n; ++i) {
         ps[i].tiles_m = cdiv(ps[i].M, bm);
         ps[i].tiles_n = cdiv(ps[i].Cout, bn);
+        const long long tl = (long long)ps[i].tiles_m * ps[i].tiles_n;
+        if (tl * ps[i].tiles_n >= (1ll << 32)) return -1;      // (M < 2^31 and Cout * K < 2^31 keep this far away)
+        ps[i].tiles_n_magic = ps[i].tiles_n > 1 ? (unsigned)(((1ull << 32) + ps[i].tiles_n - 1) / ps[i].tiles_n) : 0u;
         total += ps[i].tiles_m * ps[i].tiles_n;
         ps[i].tile_end = total;
     }
@@ -825,7 +850,9 @@ void launch_group_cfg(int cfg, const GroupArgs& ga, int total, hipStream_t st) {
     switch (cfg) {
 #define X(I, A, B, C_, D, E, F, G, H)                                                                                                     \
     case I:                                                                                                                               \
-        hipLaunchKernelGGL((conv_fwd_group<T, A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, ga); \
+        hipLaunchKernelGGL((conv_fwd_group<T, A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, ga.nprob,      \
+                           ga.tile_end[0], ga.tile_end[1], ga.tile_end[2], ga.tile_end[3], ga.tile_end[4], ga.tile_end[5], ga.tile_end[6],          \
+                           ga.tile_end[7], ga);                                                                                                    \
         break;
         FCN_CONV_CONFIGS(X)
 #undef X
@@ -860,6 +887,7 @@ int fcn_conv2d_fwd_f32(const fcn_conv_desc* h_desc, fcn_stream_t s) {
     fill(p, *h_desc, zp);
     const int cfg = choose_cfg(&p, 1);
     const int total = plan_tiles_cfg(cfg, &p, 1);
+    FCN_REQUIRE(total > 0, FCN_E_UNSUPPORTED, "conv: too many tiles for the 32-bit tile decode");
     if (h_desc->flags & FCN_CONV_F16) launch_one_cfg<f16_t>(cfg, p, total, as_stream(s));
     else launch_one_cfg<float>(cfg, p, total, as_stream(s));
     FCN_LAUNCH_CHECK("conv_fwd_one");
@@ -917,6 +945,7 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
     }
     const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
     const int total = plan_tiles_cfg(cfg, ps, n);
+    FCN_REQUIRE(total > 0, FCN_E_UNSUPPORTED, "conv group: too many tiles for the 32-bit tile decode");
     FCN_HIP(hipMemcpy(d_workspace, ps, sizeof(ConvP) * n, hipMemcpyHostToDevice));
     {
         std::lock_guard<std::mutex> lock(g_groups_mu);

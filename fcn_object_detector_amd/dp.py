@@ -39,6 +39,48 @@ def shard_range(total: int, rank: int, world: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def launched_as_rank() -> bool:
+    """True inside a rank process (started by spawn_ranks() or by `python -m torch.distributed.run`)."""
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def spawn_ranks(script: str, argv: List[str], devices: List[int], extra_env: Optional[dict] = None) -> int:
+    """Start one fresh process per GPU (`script argv...`, rank i on devices[i]) and wait for all of them; returns the
+    first non-zero exit code.  MUST be called before the calling process has touched the GPU - it never does afterwards
+    either: the launcher only waits.  Children find each other through RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT (what torch.distributed.run would set), FCN_DEVICE (the GPU of the rank) and a per-job FCN_DP_SECRET."""
+    import secrets
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    secret = secrets.token_hex(16)
+    procs = []
+    for rank, dev in enumerate(devices):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(len(devices)), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FCN_DEVICE=str(dev), FCN_DP_SECRET=secret)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL's intra-node transport needs on this driver
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
+    rc = 0
+    try:
+        for p in procs:
+            rc = p.wait() or rc
+    except BaseException:
+        for p in procs:      # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+        raise
+    return rc
+
+
+def env_device() -> int:
+    """GPU of this rank: FCN_DEVICE when a launcher of this package set it, else LOCAL_RANK."""
+    return int(os.environ.get("FCN_DEVICE", env_local_rank()))
+
+
 MAX_MESSAGE = 1 << 20      # control-plane messages are ranks, timings, error strings and the 128-byte RCCL id
 _MAC = 32
 

@@ -675,7 +675,8 @@ class TrainEngine(Engine):
                             L.check(lib.fcn_stream_wait_event(side, b["ready_main"]))
                         L.check(lib.fcn_event_record(b["ready"], side if side_used else self.stream))
                         L.check(lib.fcn_stream_wait_event(self.comm_stream, b["ready"]))
-                        self.comm.all_reduce_sum(self.grad_flat.ptr + 4 * b["offset"], b["count"], self.comm_stream)
+                        if not getattr(self, "comm_dry", False):      # (benchmarks: the same step without the collective)
+                            self.comm.all_reduce_sum(self.grad_flat.ptr + 4 * b["offset"], b["count"], self.comm_stream)
                         L.check(lib.fcn_event_record(b["done"], self.comm_stream))
             for b in self.buckets:
                 L.check(lib.fcn_stream_wait_event(self.stream, b["done"]))
@@ -691,6 +692,36 @@ class TrainEngine(Engine):
                 self._step_done = ev
             L.check(lib.fcn_event_record(self._step_done, self.stream))
             self._in_flight = (list(self._tgt["tops"]) if dev_targets else []) + list(fed)
+
+    def time_allreduce(self, reps: int = 10) -> Dict[str, float]:
+        """The step's gradient all-reduce alone: every bucket back to back on the communication stream, nothing else on
+        the GPU (every rank must call this together).  Returns microseconds per full-gradient all-reduce, the bytes summed
+        and the bus bandwidth 2 (G-1)/G * bytes / time of the usual collective accounting."""
+        if self.comm is None or not self.buckets:
+            return {"allreduce_us": 0.0, "bytes": 0, "bus_GBps": 0.0, "buckets": 0}
+        with self.lock:
+            L.call("fcn_device_sync")
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            L.call("fcn_event_create", C.byref(e0))
+            L.call("fcn_event_create", C.byref(e1))
+            scratch = DeviceBuffer(self.grad_flat.nbytes)      # summing zeros: the gradients themselves stay untouched
+            for r in range(reps + 2):
+                if r == 2:
+                    L.call("fcn_event_record", e0, self.comm_stream)
+                for b in self.buckets:
+                    self.comm.all_reduce_sum(scratch.ptr + 4 * b["offset"], b["count"], self.comm_stream)
+            L.call("fcn_event_record", e1, self.comm_stream)
+            L.call("fcn_event_sync", e1)
+            ms = C.c_float()
+            L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+            L.call("fcn_event_destroy", e0)
+            L.call("fcn_event_destroy", e1)
+            scratch.free()
+        nbytes = 4 * sum(b["count"] for b in self.buckets)
+        us = ms.value * 1e3 / reps
+        g = self.comm.world
+        return {"allreduce_us": us, "bytes": nbytes, "buckets": len(self.buckets),
+                "bus_GBps": (2.0 * (g - 1) / g * nbytes / (us * 1e-6) / 1e9) if us > 0 else 0.0}
 
     def step_end(self) -> Dict[str, float]:
         with self.lock:

@@ -126,3 +126,42 @@ def test_wire_format_is_json_with_bytes_and_a_size_cap():
         dp._send(a, object(), key)
     a.close()
     b.close()
+
+
+def test_spawn_ranks_starts_one_process_per_device(tmp_path):
+    """What `bench.py --gpus N` and `caffe train --gpu=a,b` do before touching a GPU: N fresh processes that find each other
+    through the environment the launcher hands them (no GPU involved here: the rank script only uses the control plane)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "rank.py"
+    out = tmp_path / "out.json"
+    script.write_text(
+        "import json, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from fcn_object_detector_amd import dp\n"
+        "assert dp.launched_as_rank() and os.environ['FCN_DP_SECRET'] and os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
+        "cp = dp.ControlPlane()\n"
+        "got = cp.all_gather({'rank': dp.env_rank(), 'device': dp.env_device(), 'arg': sys.argv[1]})\n"
+        "cp.barrier()\n"
+        "if dp.env_rank() == 0:\n"
+        "    json.dump(got, open(%r, 'w'))\n"
+        "cp.close()\n"
+        "sys.exit(3 if sys.argv[1] == 'fail' and dp.env_rank() == 1 else 0)\n" % (ROOT, str(out)))
+    code = ("import sys; sys.path.insert(0, %r); from fcn_object_detector_amd import dp; "
+            "sys.exit(dp.spawn_ranks(%r, [sys.argv[1]], [5, 2, 7]))" % (ROOT, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FCN_DP_SECRET")}
+    assert subprocess.run([sys.executable, "-c", code, "hello"], env=env, timeout=120).returncode == 0
+    assert json.load(open(out)) == [{"rank": r, "device": d, "arg": "hello"} for r, d in enumerate((5, 2, 7))]
+    assert subprocess.run([sys.executable, "-c", code, "fail"], env=env, timeout=120).returncode == 3      # a rank's failure is the job's
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

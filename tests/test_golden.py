@@ -168,3 +168,53 @@ def test_hip_matches_training_fixture(gpu):
         assert rel_err(got[name][0], g["dw_" + key]) < 5e-3, name
         assert rel_err(after[name][0], g["w_after_" + key]) < 1e-3, name
     eng.close()
+
+
+# ---- vectors computed by the REFERENCE's own functions (tests/golden/make_reference_golden.py; CPU twins in
+# tests/test_reference_golden.py): SURVEY.md rows A4 and A7 on the device ------------------------------------------------
+
+def _ref_rows():
+    return np.load(os.path.join(GOLDEN, "reference_numpy_rows.npz"))
+
+
+@pytest.mark.gpu
+def test_hip_target_generation_matches_reference_vectors(gpu):
+    """fcn_gen_targets against what argumentation_engine.py:69-109 itself produced (float64 there, float32 tops here)."""
+    from fcn_object_detector_amd.detector import generate_targets
+    G = _ref_rows()
+    n = 0
+    for name in (str(v) for v in G["a4_names"]):
+        h, w, s, c = (int(v) for v in G["a4_%s_meta" % name])
+        rects = [tuple(int(v) for v in r) for r in G["a4_%s_rects" % name]]
+        labels = [int(v) for v in G["a4_%s_labels" % name]]
+        got = generate_targets([rects], [labels], w, h, s, c)
+        for key, arr in zip(("fg", "bbox", "size", "obj", "cvg"), got):
+            with np.errstate(all="ignore"):
+                ref = G["a4_%s_%s" % (name, key)].astype(np.float32)      # the layer stores into float32 tops (:113-121)
+            assert arr[0].shape == ref.shape and np.array_equal(arr[0], ref, equal_nan=True), (name, key)
+        n += 1
+    assert n >= 10
+
+
+@pytest.mark.gpu
+def test_hip_decode_matches_reference_gridbox_vectors(gpu):
+    """The decode half of fcn_detect_decode_group against the reference's gridbox_to_boxes output (fcn_object_detector.py:357-394
+    at stride 8, boundary_refinement.py:265-302 at stride 16): with groupThreshold 0 cv::groupRectangles returns its input, so the
+    kernel's output is the candidate list itself - the reference's float64 boxes through the cv2 Rect converter, in np.where order."""
+    from fcn_object_detector_amd.detector import detect_from_maps
+    G = _ref_rows()
+    i = checked = 0
+    while "a7_%d_s8_meta" % i in G:
+        for tag in ("s8", "s16"):
+            key = "a7_%d_%s" % (i, tag)
+            net_w, net_h, stride = (int(v) for v in G[key + "_meta"])
+            cvg, bb, boxes = G[key + "_cvg"], G[key + "_bbox"], G[key + "_boxes"]
+            for mode, lmode in (("nearest_even", 0), ("trunc", 1)):
+                dets, labels = detect_from_maps(cvg[None, None], bb[None], net_w, net_h, float(G[key + "_thresh"]), 0, 0.2,
+                                                min_height=-(1 << 30), round_mode=lmode)[0]
+                want = np.array([D.to_rect(b, mode) for b in boxes.tolist()], np.float64).reshape(-1, 4) if boxes.any() else np.zeros((0, 4))
+                assert dets.shape == (len(want), 5) and np.array_equal(dets[:, :4], want), (key, mode)
+                assert not dets[:, 4].any() and not labels.any()      # log(weight 1) = 0, class 0
+                checked += len(want)
+        i += 1
+    assert i == 5 and checked > 8000
