@@ -218,7 +218,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // the constant 100 MHz clock and the shader clock at fixed points of conv_body into a buffer of its own.  No stamp exists
 // in the product build; no output value depends on one.
 #ifdef FCN_CONV_STAMPS
-constexpr int kStampWords = 16;
+constexpr int kStampWords = 32;
 __device__ unsigned long long* g_conv_stamps = nullptr;
 __device__ int g_conv_stamps_cap = 0;
 #define FCN_STAMP(i)                                                                                          \
@@ -446,18 +446,24 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             bias_v[e] = p.bias ? *(const float __attribute__((address_space(1)))*)(p.bias + (nb + e < p.Cout ? nb + e : p.Cout - 1)) : 0.f;
     }
 
-    // ---- prologue: chunks 0 .. D-1 in flight (chunks past K are all-zero, so the counts below never change) ----
+    FCN_STAMP(7);      // addresses set up
+    // ---- prologue: chunks 0 .. D-1 in flight ---------------------------------------------------------------
+    // While chunk c + D exists, iteration c issues it and the counted waits see a constant number of instructions in
+    // flight; the last D iterations issue nothing and drain with vmcnt(0) instead.  (Round 1 issued all-zero chunks past K
+    // to keep the count constant - and then every workgroup waited a full memory latency for them behind its last MFMA:
+    // 0.4 us of every launch, tools/conv_timeline.py.)
     int buf_issue = 0;                 // ring slot of the next chunk to issue
     auto next = [](int b) { return b + 1 == NBUF ? 0 : b + 1; };
 #pragma unroll 1
-    for (int c = 0; c < D; ++c) {      // rolled: straight-line code costs instruction fetches, and this runs once
+    for (int c = 0; c < D && c < nchunks; ++c) {      // rolled: straight-line code costs instruction fetches, and this runs once
         issue_chunk(buf_issue);
         buf_issue = next(buf_issue);
     }
     int buf_cur = 0;                   // ring slot of chunk c
     FCN_STAMP(1);      // prologue issued
     if (PF) {
-        wait_vmcnt<INST*(D - 1)>();   // chunk 0 landed (this wave's pieces) ...
+        if (nchunks >= D) wait_vmcnt<INST*(D - 1)>();   // chunk 0 landed (this wave's pieces) ...
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();  // ... and everybody else's
         asm volatile("" ::: "memory");
         read_frags(0, 0);
@@ -470,7 +476,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {      // unrolled by 2: the fragment parity is a compile-time constant
             if (c0 + u < nchunks) {
-                wait_vmcnt<INST*(D - 1 - (PF ? 1 : 0))>();
+                const bool do_issue = c0 + u + D < nchunks;      // chunk c + D exists
+                if (c0 + u + D <= nchunks) wait_vmcnt<INST*(D - 1 - (PF ? 1 : 0))>();      // steady state: a constant number in flight
+                else wait_vmcnt<0>();                                                      // tail: whatever is left
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
 #ifdef FCN_CONV_STAMPS
@@ -493,6 +501,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
                         for (int q = g * NP / NG; q < (g + 1) * NP / NG; ++q) {
                             if (q < KS) read_step((u + 1) & 1, q, q, nslot);
+                            else if (!do_issue) continue;
                             else if (q == KS) issue_pre(buf_issue);
                             else if (q < KS + 1 + IA) issue_a(q - KS - 1);
                             else if (q < KS + 1 + IA + IB) issue_b(q - KS - 1 - IA);
@@ -502,16 +511,19 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                     }
                     buf_issue = next(buf_issue);
                 } else {
-                    issue_chunk(buf_issue);
+                    if (do_issue) issue_chunk(buf_issue);
                     buf_issue = next(buf_issue);
                     mfma_chunk(u & 1, buf_cur);
                 }
                 buf_cur = next(buf_cur);
+#ifdef FCN_CONV_STAMPS
+                if (c0 + u < 4) FCN_STAMP(8 + c0 + u);      // iterations 0..3 done
+#endif
             }
         }
     }
     FCN_STAMP(3);      // main loop done
-    wait_vmcnt<0>();                   // the all-zero chunks issued past K must land before the ring is reused
+    wait_vmcnt<0>();                   // (nothing is in flight any more: the tail iterations drained)
     // The last iteration prefetched the fragments of a chunk that does not exist, with inline-asm ds_reads the compiler
     // cannot see: nothing waits for them, their destination registers are dead, and the register allocator hands those
     // registers to the epilogue (the accumulator copies).  A read that returns late - LDS contended by a co-resident
@@ -565,10 +577,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                      ((unsigned)(size_t)p.y & 15) == 0 && ((unsigned)(size_t)p.y2 & 15) == 0;
     const int wn_t = (4 * c4) / (32 * WTN), jt = ((4 * c4) / 32) % WTN, lc = (4 * c4) & 31;
     const float* lds_col = smem + (size_t)(wn_t * WAVES_K * WTM * WTN + jt) * 1024 + lc;
-#pragma unroll 1
-    for (int it = tid / C4; it < BM; it += C::NT / C4) {
-        const int m = m0 + it;
-        if (m >= p.M) break;
+    auto reduced = [&](const int it) {      // K-split partials of one item in the fixed order wk = 0, 1, .. , plus the bias
         const int wm_t = it / (32 * WTM), i_t = (it / 32) % WTM;
         const float* src = lds_col + (size_t)(wm_t * WAVES_N * WAVES_K * WTM * WTN + i_t * WTN) * 1024 + (it & 31) * 32;
         v4f v = *(const v4f*)src;
@@ -576,6 +585,29 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         for (int s = 1; s < WAVES_K; ++s) v += *(const v4f*)(src + (size_t)s * WTM * WTN * 1024);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bias_v[e];
+        return v;
+    };
+    // the common case first and on its own - float32 out, bias (+ ReLU), whole aligned groups: code that runs once per
+    // launch costs what its instruction fetches cost, so the path every forward layer takes is kept short and branch-free
+    const bool plain = vec && !half_out && (p.flags & (FCN_CONV_ACCUM | FCN_CONV_MASK | FCN_CONV_SIGMOID2)) == 0;
+    if (__builtin_expect(plain, 1)) {
+#pragma unroll 1
+        for (int it = tid / C4; it < BM; it += C::NT / C4) {
+            const int m = m0 + it;
+            if (m >= p.M) break;
+            v4f v = reduced(it);
+            if (do_relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *(v4f*)(p.y + ((size_t)m * p.y_cstride + p.y_coffset + n)) = v;
+        }
+    } else {
+#pragma unroll 1
+    for (int it = tid / C4; it < BM; it += C::NT / C4) {
+        const int m = m0 + it;
+        if (m >= p.M) break;
+        v4f v = reduced(it);
         const size_t o = (size_t)m * p.y_cstride + p.y_coffset + n;
         const size_t o2 = (size_t)m * p.y2_cstride + p.y2_coffset + n;
         if (half_out) {      // f16 activations: rounded once, after bias and ReLU
@@ -619,6 +651,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 }
         }
     }
+    }
 #ifdef FCN_CONV_STAMPS
     FCN_STAMP(5);      // stores issued
     wait_vmcnt<0>();
@@ -627,8 +660,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         unsigned xcc = 0, hwid = 0;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        g_conv_stamps[(size_t)blockIdx.x * kStampWords + 14] = xcc;
-        g_conv_stamps[(size_t)blockIdx.x * kStampWords + 15] = hwid;
+        g_conv_stamps[(size_t)blockIdx.x * kStampWords + 30] = xcc;
+        g_conv_stamps[(size_t)blockIdx.x * kStampWords + 31] = hwid;
     }
 #endif
 }

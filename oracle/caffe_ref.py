@@ -75,7 +75,10 @@ def conv2d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], pad: int, stri
     cog = cout // group
     for i in range(n):
         for g in range(group):
-            col = im2col(x[i, g * cin_g:(g + 1) * cin_g], kh, kw, pad, pad, stride, stride)
+            if kh == 1 and kw == 1 and pad == 0 and stride == 1:      # Caffe's is_1x1_: the input IS the column buffer
+                col = x[i, g * cin_g:(g + 1) * cin_g].reshape(cin_g, h * wd)
+            else:
+                col = im2col(x[i, g * cin_g:(g + 1) * cin_g], kh, kw, pad, pad, stride, stride)
             wg = w[g * cog:(g + 1) * cog].reshape(cog, cin_g * kh * kw)
             y[i, g * cog:(g + 1) * cog] = (wg @ col).reshape(cog, oh, ow)
     if b is not None:
@@ -123,32 +126,48 @@ def power(x: np.ndarray, power_: float = 1.0, scale: float = 1.0, shift: float =
 
 def max_pool(x: np.ndarray, k: int, s: int, p: int, return_index: bool = False):
     """Caffe PoolingLayer MAX: window clipped to the image, first maximum in raster order wins
-    (`>` compare, initial -FLT_MAX)."""
+    (`>` compare, initial -FLT_MAX).  One pass per window element (r, q) in raster order over strided VIEWS of the
+    input and output (no gathers: this runs inside the CPU baseline bench.py times)."""
     n, c, h, w = x.shape
     oh, ow = pool_out(h, k, p, s), pool_out(w, k, p, s)
-    y = np.full((n, c, oh, ow), -np.finfo(F32).max, dtype=F32)
-    idx = np.full((n, c, oh, ow), -1, dtype=np.int64)
+    # channels innermost while pooling: the window strides then sit on outer dimensions and every compare / masked copy
+    # runs over contiguous channel runs
+    xt = np.ascontiguousarray(x.transpose(0, 2, 3, 1))
+    y = np.full((n, oh, ow, c), -np.finfo(F32).max, dtype=F32)
+    idx = np.full((n, oh, ow, c), -1, dtype=np.int64) if return_index else None
+
+    def span(r, size, out):
+        # output positions o in [o0, o1) whose window element r falls inside the image: 0 <= o * s - p + r < size
+        o0 = max(0, -((r - p) // s))
+        o1 = min(out, (size - 1 + p - r) // s + 1)
+        return o0, o1
+
     for r in range(k):
+        oy0, oy1 = span(r, h, oh)
+        if oy1 <= oy0:
+            continue
+        iy0 = oy0 * s - p + r
         for q in range(k):
-            # output positions whose window element (r,q) falls inside the image
-            oy = np.arange(oh)
-            ox = np.arange(ow)
-            iy = oy * s - p + r
-            ix = ox * s - p + q
-            vy = (iy >= 0) & (iy < h)
-            vx = (ix >= 0) & (ix < w)
-            if not vy.any() or not vx.any():
+            ox0, ox1 = span(q, w, ow)
+            if ox1 <= ox0:
                 continue
-            oy, iy, ox, ix = oy[vy], iy[vy], ox[vx], ix[vx]
-            cand = x[:, :, iy[:, None], ix[None, :]]
-            cur = y[:, :, oy[:, None], ox[None, :]]
+            ix0 = ox0 * s - p + q
+            cand = xt[:, iy0:iy0 + (oy1 - oy0 - 1) * s + 1:s, ix0:ix0 + (ox1 - ox0 - 1) * s + 1:s, :]
+            cur = y[:, oy0:oy1, ox0:ox1, :]
+            if not return_index:
+                # values only (TEST phase, the CPU baseline): the running maximum, vectorised.  Same numbers as the strict
+                # `>` update below for finite inputs (which of two equal zeros survives is the only freedom, and no layer of
+                # these nets can tell them apart)
+                np.maximum(cur, cand, out=cur)
+                continue
             take = cand > cur
-            y[:, :, oy[:, None], ox[None, :]] = np.where(take, cand, cur)
+            np.copyto(cur, cand, where=take)
             if return_index:
-                flat = (iy[:, None] * w + ix[None, :])[None, None]
-                ci = idx[:, :, oy[:, None], ox[None, :]]
-                idx[:, :, oy[:, None], ox[None, :]] = np.where(take, flat, ci)
-    return (y, idx) if return_index else y
+                flat = (np.arange(iy0, iy0 + (oy1 - oy0 - 1) * s + 1, s)[:, None] * w +
+                        np.arange(ix0, ix0 + (ox1 - ox0 - 1) * s + 1, s)[None, :])[None, :, :, None]
+                np.copyto(idx[:, oy0:oy1, ox0:ox1, :], np.broadcast_to(flat, take.shape), where=take)
+    y = np.ascontiguousarray(y.transpose(0, 3, 1, 2))
+    return (y, np.ascontiguousarray(idx.transpose(0, 3, 1, 2))) if return_index else y
 
 
 def ave_pool(x: np.ndarray, k: int, s: int, p: int) -> np.ndarray:

@@ -147,8 +147,11 @@ class RefNet:
                 p = l.get("pooling_param")
                 k, s, pad = _ksp(p)
                 if p.get("pool", "MAX") == "MAX":
-                    y, idx = R.max_pool(bots[0], k, s, pad, return_index=True)
-                    self.aux[name] = idx
+                    if self.phase == "TRAIN":      # the argmax is what backward routes the gradient through
+                        y, idx = R.max_pool(bots[0], k, s, pad, return_index=True)
+                        self.aux[name] = idx
+                    else:
+                        y = R.max_pool(bots[0], k, s, pad)
                     B[tops[0]] = y
                 else:
                     B[tops[0]] = R.ave_pool(bots[0], k, s, pad)
@@ -216,11 +219,13 @@ class RefNet:
     def total_loss(self) -> float:
         return float(sum(w * self.losses[k] for k, w in self.loss_weights().items()))
 
-    def backward(self) -> Dict[str, List[np.ndarray]]:
-        """Net::Backward: returns {layer: [dW, db]}; blob gradients are left in self.diffs."""
+    def backward(self, stop_at: Optional[str] = None) -> Dict[str, List[np.ndarray]]:
+        """Net::Backward: returns {layer: [dW, db]}; blob gradients are left in self.diffs.  `stop_at`: the last layer
+        (walking backwards) whose gradients are wanted - full-size checks only need the top of the net."""
         B = self.blobs
         D: Dict[str, np.ndarray] = {}
         grads: Dict[str, List[np.ndarray]] = {}
+        self._bwd_stop = False
         lw = self.loss_weights()
         data_tops = set(self.inputs)
         for l in self.layers:
@@ -255,6 +260,10 @@ class RefNet:
                 ign = lp.get("ignore_label", None) if lp else None
                 acc(bots[0], R.softmax_loss_grad(B[bots[0]], B[bots[1]], norm, ign, lw.get(tops[0], 0.0)))
                 continue
+            if stop_at is not None and getattr(self, "_bwd_stop", False):
+                break
+            if name == stop_at:
+                self._bwd_stop = True      # this layer is still processed, the ones below it are not
             if tops[0] not in D:
                 continue   # nothing flows back through this layer
             dy = D[tops[0]]

@@ -53,3 +53,21 @@ def pack_ohwi(w: np.ndarray) -> np.ndarray:
     out = np.zeros((co, kh, kw, ci4), np.float32)
     out[..., :ci] = w.transpose(0, 2, 3, 1)
     return out
+
+
+def adopt_device_activations(ref, eng, spec, keep=()):
+    """Make the oracle's backward run on the DEVICE's forward pass: every 4-d blob of `ref` (except `keep`, the inputs) is
+    replaced by the engine's, and the pooling argmaxes / LRN scales are recomputed from them.  ReLU masks and max-pool
+    argmaxes are discontinuous: two independently rounded forward passes flip a handful of near-zero activations / near-tied
+    windows, and a flipped mask says nothing about the backward kernels or the solver.  With identical masks what is left
+    is the backward arithmetic itself, which is held to the north-star tolerance (1e-3)."""
+    from oracle import caffe_ref as R
+    for name in list(ref.blobs):
+        if name in eng.blobs and len(eng.blobs[name].shape) == 4 and name not in keep:
+            ref.blobs[name] = eng.read_blob(name).copy()
+    for l in spec.layers:
+        if l.type == "Pooling" and str(l.sub("pooling_param").get("pool", "MAX")) == "MAX":
+            k, s_, p_ = (int(l.sub("pooling_param").get(q, d)) for q, d in (("kernel_size", 0), ("stride", 1), ("pad", 0)))
+            ref.aux[l.name] = R.max_pool(ref.blobs[l.bottoms[0]], k, s_, p_, return_index=True)[1]
+        elif l.type == "LRN":
+            ref.aux[l.name] = R.lrn_across(ref.blobs[l.bottoms[0]], 5, 1e-4, 0.75, 1.0, return_scale=True)[1]

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import rel_err
+from gpu_util import adopt_device_activations
 from fcn_object_detector_amd import models, proto
 from fcn_object_detector_amd.netspec import NetSpec, fill_params
 from fcn_object_detector_amd.train import SolverParams, TrainEngine
@@ -63,16 +64,7 @@ def test_forward_backward_gradients_match_oracle(gpu):
     assert abs(out["loss"] - ref.total_loss()) < 1e-3 * abs(ref.total_loss())
     for name in ("coverage", "bboxes", "pool5/drop_s1", "inception_3a/output"):
         assert rel_err(eng.read_blob(name), ref.blobs[name]) < 1e-3, name
-    # oracle backward on the device's activations
-    for name in list(ref.blobs):
-        if name in eng.blobs and len(eng.blobs[name].shape) == 4 and name not in data:
-            ref.blobs[name] = eng.read_blob(name).copy()
-    for l in spec.layers:
-        if l.type == "Pooling":
-            k, s_, p_ = (int(l.sub("pooling_param").get(q, d)) for q, d in (("kernel_size", 0), ("stride", 1), ("pad", 0)))
-            ref.aux[l.name] = R.max_pool(ref.blobs[l.bottoms[0]], k, s_, p_, return_index=True)[1]
-        elif l.type == "LRN":
-            ref.aux[l.name] = R.lrn_across(ref.blobs[l.bottoms[0]], 5, 1e-4, 0.75, 1.0, return_scale=True)[1]
+    adopt_device_activations(ref, eng, spec, keep=data)      # oracle backward on the device's activations
     grads = ref.backward()
     for name in ("bboxes", "cvg/classifier", "pool5/drop_s1", "inception_5a/1x1", "inception_4e/pool", "pool3/3x3_s2", "inception_3a/5x5",
                  "conv2/norm2", "conv2/3x3", "pool1/norm1", "pool1/3x3_s2", "conv1/7x7_s2"):
@@ -104,22 +96,16 @@ def test_three_solver_steps_match_oracle(gpu, kind):
         ref.dropout_seed = 100 + it
         ref.forward()
         rlosses.append(ref.total_loss())
+        # the oracle's backward runs on the device's forward pass of this step (identical ReLU masks and pooling argmaxes, see
+        # adopt_device_activations): the trajectory then compares the backward kernels and the solver, at the north-star 1e-3
+        adopt_device_activations(ref, eng, spec, keep=batch)
         rsolver.apply(ref.backward())
     for a, b in zip(losses, rlosses):
         assert abs(a - b) < 1e-3 * abs(b), (losses, rlosses)
     got = eng.download_params()
-    # Adam divides by sqrt(v): an element whose gradient differs through a flipped ReLU mask / pool argmax (see the test above)
-    # still moves by ~lr per step, so its weights are held to 5e-3 instead of 1e-3
-    # (the Adam kernel itself is held to 2e-5 in test_gpu_train_kernels.py::test_solver_updates); here the weights get 1e-2
-    # max-relative and the UPDATE vector must agree with the oracle's in direction and size
-    tol = 1e-3 if kind == "SGD" else 1e-2
-    init = fill_params(spec, seed=1234)
     for name, ps in ref.params.items():
-        for g, r, w0 in zip(got[name], ps, init[name]):
-            assert rel_err(g, r) < tol, name
-            du, dr = (g - w0).astype(np.float64).ravel(), (r - w0).astype(np.float64).ravel()
-            if np.linalg.norm(dr) > 0:
-                assert np.linalg.norm(du - dr) < 0.25 * np.linalg.norm(dr), name
+        for g, r in zip(got[name], ps):
+            assert rel_err(g, r) < 1e-3, name
     eng.close()
 
 

@@ -23,7 +23,8 @@ from fcn_object_detector_amd.engine import DeviceBuffer  # noqa: E402
 from gpu_util import conv_desc, dev_from  # noqa: E402
 from conv_sweep import SHAPES  # noqa: E402
 
-NAMES = ("entry", "issued", "chunk0", "loop", "ksplit", "stored", "acked")
+NAMES = ("entry", "setup", "issued", "chunk0", "iter0", "iter1", "iter2", "iter3", "loop", "parked", "stored", "acked")
+ORDER = (0, 7, 1, 2, 8, 9, 10, 11, 3, 4, 5, 6)      # stamp slot of each name
 CAP = 4096
 
 
@@ -41,7 +42,7 @@ def main():
     e0, e1 = C.c_void_p(), C.c_void_p()
     L.call("fcn_event_create", C.byref(e0))
     L.call("fcn_event_create", C.byref(e1))
-    stamps = DeviceBuffer(CAP * 16 * 8)
+    stamps = DeviceBuffer(CAP * 32 * 8)
     flush = DeviceBuffer(512 << 20, zero=False)
     rng = np.random.default_rng(0)
     for name, probs in SHAPES:
@@ -90,23 +91,25 @@ def main():
             L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
             L.call("fcn_stream_sync", st)
             L.check(lib.fcn_debug_conv_stamps(None, 0))
-            raw = np.empty((CAP, 16), np.uint64)
+            raw = np.empty((CAP, 32), np.uint64)
             L.call("fcn_memcpy_d2h_async", raw.ctypes.data, stamps.ptr, raw.nbytes, None)
             L.call("fcn_device_sync")
             raw = raw[:tiles]
-            real = raw[:, 0:14:2].astype(np.int64)
-            cyc = raw[:, 1:14:2].astype(np.int64)
+            real = raw[:, [2 * k for k in ORDER]].astype(np.int64)
+            cyc = raw[:, [2 * k + 1 for k in ORDER]].astype(np.int64)
             ok = real[:, 0] > 0
             t = (real[ok] - real[ok, 0].min()) / 100.0      # us
-            clk = (cyc[ok, 6] - cyc[ok, 0]) / np.maximum((real[ok, 6] - real[ok, 0]) * 10.0, 1)      # GHz
-            xcc = raw[ok, 14].astype(np.int64) & 0xF
+            clk = (cyc[ok, -1] - cyc[ok, 0]) / np.maximum((real[ok, -1] - real[ok, 0]) * 10.0, 1)      # GHz
+            xcc = raw[ok, 30].astype(np.int64) & 0xF
             print("  cfg %d  %d workgroups (%d stamped)  event %.2f us%s  span %.2f us  shader clock %.2f GHz  wg per XCC %s" % (
-                cfg, tiles, int(ok.sum()), us, " (cold)" if cold else "", t[:, 6].max(), float(np.median(clk)),
+                cfg, tiles, int(ok.sum()), us, " (cold)" if cold else "", t[:, -1].max(), float(np.median(clk)),
                 np.bincount(xcc, minlength=8).tolist()))
             for i, nm in enumerate(NAMES):
                 col = t[:, i]
-                print("    %-7s min %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f   | own duration since entry p50 %6.2f max %6.2f" % (
-                    nm, col.min(), np.median(col), np.percentile(col, 90), col.max(), np.median(col - t[:, 0]), (col - t[:, 0]).max()))
+                prev = t[:, i - 1] if i else t[:, 0]
+                print("    %-7s min %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f   | since entry p50 %6.2f max %6.2f   | step p50 %5.2f" % (
+                    nm, col.min(), np.median(col), np.percentile(col, 90), col.max(), np.median(col - t[:, 0]), (col - t[:, 0]).max(),
+                    np.median(col - prev)))
         sys.stdout.flush()
 
 
