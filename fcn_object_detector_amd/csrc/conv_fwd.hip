@@ -91,7 +91,7 @@ struct ConvP {
     unsigned ow_magic, oh_magic;          // ceil(2^32 / OW), ceil(2^32 / OH): exact for every m < M (validate()); 0: OW / OH == 1
     const float* zero_page;               // 16 zero bytes in HBM: what out-of-image / out-of-tile lanes load
     unsigned tiles_n_magic;               // ceil(2^32 / tiles_n): tile / tiles_n without a division (tiles * tiles_n < 2^32), 0: tiles_n == 1
-    unsigned cin_magic;                   // ceil(2^32 / Cin): k / Cin for every k < K + 128 (validate(): (K + 128) * Cin < 2^32)
+    unsigned cin_magic24;                 // ceil(2^24 / Cin): k / Cin for k < 256 (Cin <= 16384)
                                           // (160 bytes: the group kernel fetches a problem with three wide scalar loads)
 };
 static_assert(sizeof(ConvP) == 160, "conv_fwd_group loads a ConvP as 16 + 16 + 8 dwords");
@@ -99,8 +99,6 @@ static_assert(sizeof(ConvP) == 160, "conv_fwd_group loads a ConvP as 16 + 16 + 8
 // A group launch carries its problems in the kernel arguments: a workgroup finds its problem with scalar
 // compares on the prefix table and ONE scalar load, instead of chasing a table in global memory (three or four
 // dependent L2 round trips in front of the first LDS-DMA of a kernel that only runs for ~10 us).
-// internal flag (not part of the ABI: set by the launcher): rotate the K loop of every tile
-constexpr int kFlagRotate = 1 << 20;
 constexpr int kMaxGroup = 8;
 constexpr int kMaxPool = 2;
 struct PoolP {
@@ -268,22 +266,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // ---- loader state: this lane stages slot (lane % SEGS) of rows STEP*i + RPI*wid + lane / SEGS ------------
     const int lrow = RPI * wid + lane / SEGS;                  // row of instruction 0
     const int lseg = (lane % SEGS) ^ swz<SEGS>(lrow);          // k-segment this lane fetches (same for all its rows)
-    // K rotation: tile t starts its K loop at chunk rot(t) and wraps around.  Tiles that share an operand (the same
-    // activation rows or the same filter rows) then read DIFFERENT parts of it at any moment: the first one to need a line
-    // pulls it into the XCD's L2 and the others find it there - a true hit at L2 latency.  In lockstep they all miss on the
-    // same line together and every one of them waits the whole Infinity-Cache latency, and a CU with ~64 lines in flight
-    // moves only 8 KB per such latency (36 GB/s; 70 GB/s at L2 latency).  The sum runs over the same chunks in a rotated
-    // order - deterministic per tile.
-    const int nchunks = (p.K + BKE - 1) / BKE;
-    const int rot = (p.flags & kFlagRotate) ? (int)(((((unsigned)tile * 40503u) & 0xFFFFu) * (unsigned)nchunks) >> 16) : 0;
-    int left = nchunks - rot;           // chunks to issue before the sequence wraps to chunk 0
-    // k position of this lane's segment, kept as (tap, channel) and advanced by BK per chunk without branches
-    const int kc0w = lseg * EPS;                                        // chunk 0 (where the sequence wraps to)
-    const int kt0 = fast_div(kc0w, p.cin_magic), kc0 = kc0w - kt0 * p.Cin;
-    int kb = rot * BKE + lseg * EPS;                                     // this segment's k index (weights are zero past K)
-    int kt = fast_div(kb, p.cin_magic);
-    int kc = kb - kt * p.Cin;
-    const int bk_taps = fast_div(BKE, p.cin_magic), bk_rem = BKE - bk_taps * p.Cin;      // BKE / Cin
+    // k position of that segment, kept as (tap, channel) and advanced by BK per chunk without branches
+    int kc = lseg * EPS;
+    int kt = (int)(((unsigned)kc * p.cin_magic24) >> 24);      // kc / Cin (kc < 256)
+    kc -= kt * p.Cin;
+    const int bk_taps = (int)(((unsigned)BKE * p.cin_magic24) >> 24), bk_rem = BKE - bk_taps * p.Cin;      // BKE / Cin
     int a_iy0[IA], a_ix0[IA], a_off[IA];   // window origin and its element offset (32-bit: validated on the host)
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
@@ -302,8 +289,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
         const int n = n0 + STEP * i + lrow;
-        b_off[i] = n < p.Cout ? n * p.K + kb : -1;
+        b_off[i] = n < p.Cout ? n * p.K + lseg * EPS : -1;
     }
+    int kb = lseg * EPS;   // this segment's k index (weights are zero past K)
     const int taps = p.kh * p.kw;
     // the zero page pointer is laundered into VGPRs so that "in bounds ? source : zero page" stays a plain select
     // (one LDS-DMA instruction per row group) instead of two exec-masked instructions
@@ -319,9 +307,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         is_kr = (kt * p.kw_magic) >> 16;            // kt / kw (magic = ceil(65536 / kw), exact for kt < 8192)
         is_kq = kt - is_kr * p.kw;
         is_koff = (is_kr * p.W + is_kq) * p.x_cstride + kc;
-        const bool live = left > -rot;      // chunks issued past the end of the (rotated) sequence are all-zero
-        is_kok = (int)(kt < taps) & (int)live;
-        is_kbok = (int)(kb < p.K) & (int)live;
+        is_kok = kt < taps;
+        is_kbok = kb < p.K;
         is_dst = smem + buf * BUF_FLOATS + lds_wave_base;
     };
     auto issue_a = [&](const int i) {
@@ -339,18 +326,13 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         b_off[i] += b_off[i] >= 0 ? BKE : 0;
     };
     auto issue_post = [&]() {
-        const bool wrap = --left == 0;      // uniform: the next chunk of the (rotated) sequence is chunk 0
+        kb += BKE;
         // advance by one chunk: BKE = bk_taps * Cin + bk_rem
-        kb += wrap ? BKE - nchunks * BKE : BKE;
         kc += bk_rem;
         kt += bk_taps;
-        const bool carry = kc >= p.Cin;
-        kc -= carry ? p.Cin : 0;
-        kt += carry ? 1 : 0;
-        kc = wrap ? kc0 : kc;
-        kt = wrap ? kt0 : kt;
-#pragma unroll
-        for (int i = 0; i < IB; ++i) b_off[i] -= (wrap && b_off[i] >= 0) ? nchunks * BKE : 0;      // (issue_b has added BKE already)
+        const bool wrap = kc >= p.Cin;
+        kc -= wrap ? p.Cin : 0;
+        kt += wrap ? 1 : 0;
     };
     // Issue the LDS-DMA of one chunk (INST x global_load_lds_dwordx4 per wave) into ring slot `buf`.  Every lane
     // always loads: lanes outside the image / tile / K read the zero page, so padding arrives as zeros and the
@@ -372,6 +354,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int nchunks = (p.K + BKE - 1) / BKE;
     // Fragment reads are inline asm: hipcc cannot tell an LDS-DMA in flight from the ds_read of a slot that landed
     // long ago and would drain vmcnt to 0 in front of every compiler-generated LDS read of this array.
     // Addressing: row (lane & 31) of a 32-row tile, k-segment 2*step + (lane >> 5), de-swizzled per lane.
@@ -468,12 +451,16 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 
     FCN_STAMP(7);      // addresses set up
     // ---- prologue: chunks 0 .. D-1 in flight (chunks past K are all-zero, so the counts below never change) ----
-    // (Skipping the issue in the last D iterations and draining there instead was tried in round 2: the uniform branches
-    // around every piece of the interleaved schedule cost the main loop 15-20 % on the K >= 864 launches.)
+    // Tried and dropped in round 2, all measured on one box against this version (gpurun_out/r2/sweep_ab.log, sweep_xr.log;
+    // profiles/experiments/r02_*.json): skipping the issue of the chunks past K (uniform branches around the pieces of the
+    // interleaved schedule: +15-20 % on the K >= 864 launches); rotating each tile's K loop and an XCD-aware tile order so
+    // that tiles sharing an operand hit in L2 instead of missing together (no gain; the bookkeeping of the rotation alone,
+    // a dozen VALU instructions per chunk, cost 4-6 %: with one wave per SIMD the loader's VALU work does NOT hide behind the
+    // MFMAs - 4a_A runs 8.4 us with and 6.8 us without its MFMAs, sweep_nomfma.log).
     int buf_issue = 0;                 // ring slot of the next chunk to issue
     auto next = [](int b) { return b + 1 == NBUF ? 0 : b + 1; };
 #pragma unroll 1
-    for (int c = 0; c < D; ++c) {      // rolled: this runs once
+    for (int c = 0; c < D; ++c) {      // rolled: straight-line code costs instruction fetches, and this runs once
         issue_chunk(buf_issue);
         buf_issue = next(buf_issue);
     }
@@ -531,7 +518,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 }
                 buf_cur = next(buf_cur);
 #ifdef FCN_CONV_STAMPS
-                if (c0 + u < 4) FCN_STAMP(8 + c0 + u);      // iterations 0..3 done
+                if (c0 + u < 4) FCN_STAMP(8 + c0 + u);      // iterations 0..3 done (each stamp costs the loop ~0.3 us: read the first three rows only)
 #endif
             }
         }
@@ -591,7 +578,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                      ((unsigned)(size_t)p.y & 15) == 0 && ((unsigned)(size_t)p.y2 & 15) == 0;
     const int wn_t = (4 * c4) / (32 * WTN), jt = ((4 * c4) / 32) % WTN, lc = (4 * c4) & 31;
     const float* lds_col = smem + (size_t)(wn_t * WAVES_K * WTM * WTN + jt) * 1024 + lc;
-    auto reduced = [&](const int it) {      // K-split partials of one item in the fixed order wk = 0, 1, .. , plus the bias
+#pragma unroll 1
+    for (int it = tid / C4; it < BM; it += C::NT / C4) {
+        const int m = m0 + it;
+        if (m >= p.M) break;
         const int wm_t = it / (32 * WTM), i_t = (it / 32) % WTM;
         const float* src = lds_col + (size_t)(wm_t * WAVES_N * WAVES_K * WTM * WTN + i_t * WTN) * 1024 + (it & 31) * 32;
         v4f v = *(const v4f*)src;
@@ -599,29 +589,6 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         for (int s = 1; s < WAVES_K; ++s) v += *(const v4f*)(src + (size_t)s * WTM * WTN * 1024);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += bias_v[e];
-        return v;
-    };
-    // the common case first and on its own - float32 out, bias (+ ReLU), whole aligned groups: code that runs once per
-    // launch costs what its instruction fetches cost, so the path every forward layer takes is kept short and branch-free
-    const bool plain = vec && !half_out && (p.flags & (FCN_CONV_ACCUM | FCN_CONV_MASK | FCN_CONV_SIGMOID2)) == 0;
-    if (__builtin_expect(plain, 1)) {
-#pragma unroll 1
-        for (int it = tid / C4; it < BM; it += C::NT / C4) {
-            const int m = m0 + it;
-            if (m >= p.M) break;
-            v4f v = reduced(it);
-            if (do_relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            *(v4f*)(p.y + ((size_t)m * p.y_cstride + p.y_coffset + n)) = v;
-        }
-    } else {
-#pragma unroll 1
-    for (int it = tid / C4; it < BM; it += C::NT / C4) {
-        const int m = m0 + it;
-        if (m >= p.M) break;
-        v4f v = reduced(it);
         const size_t o = (size_t)m * p.y_cstride + p.y_coffset + n;
         const size_t o2 = (size_t)m * p.y2_cstride + p.y2_coffset + n;
         if (half_out) {      // f16 activations: rounded once, after bias and ReLU
@@ -665,7 +632,6 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 }
         }
     }
-    }
 #ifdef FCN_CONV_STAMPS
     FCN_STAMP(5);      // stores issued
     wait_vmcnt<0>();
@@ -683,62 +649,41 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const int nprob, const int te0, const int te1, const int te2,
                                                                                   const int te3, const int te4, const int te5, const int te6,
-                                                                                  const int te7, const int xcd_per, const int xcd_total,
-                                                                                  const unsigned xcd_wmagic, const GroupArgs a) {
+                                                                                  const int te7, const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
     // The launch's fixed cost is what counts at M = 784 (9 us launches, 1.5 us of MFMA work).  The problem table (nprob and
-    // the exclusive tile prefix of every problem) travels as the kernel's first SCALAR arguments: the build preloads
+    // the exclusive tile prefix of every problem) travels as the kernel's first nine SCALAR arguments: the build preloads
     // them into SGPRs at wave launch (-amdgpu-kernarg-preload-count, Makefile), so a workgroup knows its problem without
     // a memory round trip, and the problem itself is ONE round trip to the kernarg segment - written as inline asm because
     // the compiler sinks each field's load to its first use and pays four or five dependent round trips instead.
     typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
     typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
-    // the GroupArgs copy sits behind the twelve scalars in the kernarg segment, at its natural alignment
-    constexpr size_t kArgsOffset = (12 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
+    // the GroupArgs copy sits behind the nine ints in the kernarg segment, at its natural alignment
+    constexpr size_t kArgsOffset = (9 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
     karg_ptr ka = (karg_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kArgsOffset);
     const int head[1 + kMaxGroup] = {nprob, te0, te1, te2, te3, te4, te5, te6, te7};
     static_assert(kMaxGroup == 8, "the tile prefix travels as eight scalar kernel arguments");
-    int tile = blockIdx.x;
-    // xcd_per == 0: head[1..] = exclusive prefix of the problems' TILES, workgroup b runs tile b.
-    // xcd_per > 0 (all problems share M and the tile height): XCD-aware order.  Workgroups are dealt round-robin to the 8
-    // XCDs (b % 8 says which workgroups share an L2 - speed only, nothing below depends on it for correctness), so XCD x
-    // takes the contiguous logical range [x * per, (x + 1) * per) of an order that walks tile ROWS: (tile_m, problem,
-    // tile_n).  One XCD then reads a few rows of activations plus the filters instead of everything, and tiles that share
-    // operands sit behind the same L2.  head[1..] = exclusive prefix of the problems' tile COLUMNS in that case.
-    const int conv_tiles = xcd_per > 0 ? 8 * xcd_per : head[kMaxGroup];      // (the host repeats the last prefix in the unused entries)
+    const int tile = blockIdx.x;
+    const int conv_tiles = head[kMaxGroup];      // the host repeats the last prefix in the unused entries
     if (tile >= conv_tiles) {      // workgroups behind the convolution tiles: the poolings fused into this launch
         const int w = tile - conv_tiles;
         if (w < a.pool[0].wg_end) pool_body<T, 64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[0], w);
         else pool_body<T, 64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[1], w - a.pool[0].wg_end);
         return;
     }
-    int row = 0;
-    if (xcd_per > 0) {
-        const int logical = (tile & 7) * xcd_per + (tile >> 3);
-        if (logical >= xcd_total) return;
-        row = fast_div(logical, xcd_wmagic);
-        tile = logical - row * head[kMaxGroup];      // column in the row of all problems' tiles
-    }
-    int pi = 0, begin = 0, end = head[kMaxGroup];
+    int pi = 0, begin = 0;
 #pragma unroll
-    for (int i = kMaxGroup - 2; i >= 0; --i) {      // the prefix is increasing: find the problem this tile / column falls into
-        const int end_i = head[1 + i];
-        const bool in_or_before = i + 1 >= nprob || tile < end_i;      // the tile lies in problem <= i
-        end = in_or_before ? end_i : end;
-    }
-#pragma unroll
-    for (int i = 0; i < kMaxGroup - 1; ++i) {
+    for (int i = 0; i < kMaxGroup - 1; ++i) {      // tile_end is increasing: count the problems that end at or before this tile
         const int end_i = head[1 + i];
         const bool past = i + 1 < nprob && tile >= end_i;
         pi += past ? 1 : 0;
         begin = past ? end_i : begin;
     }
-    int tile_local = tile - begin + row * (end - begin);      // xcd order: tile_m * tiles_n + tile_n (tiles_n = this problem's columns)
-    pi = __builtin_amdgcn_readfirstlane(pi);      // (uniform already; keeps the address arithmetic below on the scalar unit)
-    tile_local = __builtin_amdgcn_readfirstlane(tile_local);
     u32x16 ra, rb;
     u32x8 rc;
+    pi = __builtin_amdgcn_readfirstlane(pi);      // (uniform already; keeps the address arithmetic below on the scalar unit)
+    begin = __builtin_amdgcn_readfirstlane(begin);
     const ConvP __attribute__((address_space(4)))* pbase = &ka->p[pi];
     asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx8 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(ra), "=&s"(rb), "=&s"(rc)
@@ -748,7 +693,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_gro
     __builtin_memcpy((char*)&prob, &ra, 64);
     __builtin_memcpy((char*)&prob + 64, &rb, 64);
     __builtin_memcpy((char*)&prob + 128, &rc, 32);
-    conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(prob, tile_local, smem);
+    conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(prob, tile - begin, smem);
 }
 
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
@@ -832,9 +777,8 @@ int validate(const fcn_conv_desc& d) {
     FCN_REQUIRE(!((d.flags & FCN_CONV_MASK) && (d.flags & FCN_CONV_F16)), FCN_E_UNSUPPORTED, "conv: FCN_CONV_MASK is a float32 (training) feature");
     FCN_REQUIRE((long long)d.N * d.OH * d.OW < (1ll << 31), FCN_E_UNSUPPORTED, "conv: problem too large for int32 indexing");
     // the kernel decodes pixel and tile indices with multiply-high by host-computed reciprocals (no division code on the device)
-    FCN_REQUIRE((long long)d.N * d.OH * d.OW * (d.OW > d.OH ? d.OW : d.OH) < (1ll << 32) &&
-                    ((long long)d.kh * d.kw * d.Cin + 128) * d.Cin < (1ll << 32), FCN_E_UNSUPPORTED,
-                "conv: N*OH*OW*max(OH,OW) and (K+128)*Cin must stay below 2^32 (split the batch)");
+    FCN_REQUIRE((long long)d.N * d.OH * d.OW * (d.OW > d.OH ? d.OW : d.OH) < (1ll << 32) && d.Cin <= 16384, FCN_E_UNSUPPORTED,
+                "conv: N*OH*OW*max(OH,OW) must stay below 2^32 and Cin at most 16384 (split the batch)");
     return 0;
 }
 
@@ -843,7 +787,7 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.x_cstride = d.x_cstride;
     p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw; p.pad = d.pad; p.stride = d.stride; p.OH = d.OH; p.OW = d.OW;
     p.y_cstride = d.y_cstride; p.y_coffset = d.y_coffset; p.y2_cstride = d.y2_cstride; p.y2_coffset = d.y2_coffset;
-    p.flags = d.flags & 0xFFFF; p.in_shift = 0.f;      // (the high bits are the launcher's own: kFlagRotate)
+    p.flags = d.flags; p.in_shift = 0.f;
     p.M = d.N * d.OH * d.OW;
     p.K = d.kh * d.kw * d.Cin;
     p.tiles_m = p.tiles_n = p.tile_end = 0;
@@ -853,7 +797,7 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
     p.oh_magic = d.OH > 1 ? (unsigned)(((1ull << 32) + d.OH - 1) / d.OH) : 0u;
     p.zero_page = zero_page;
     p.tiles_n_magic = 0;      // plan_tiles_cfg
-    p.cin_magic = d.Cin > 1 ? (unsigned)(((1ull << 32) + d.Cin - 1) / d.Cin) : 0u;
+    p.cin_magic24 = (unsigned)(((1u << 24) + d.Cin - 1) / d.Cin);
 }
 
 // Heuristic used when the caller does not autotune (cfg_request = -1).  Fitted to tools/conv_sweep.py on
@@ -914,16 +858,14 @@ void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
     }
 }
 
-struct XcdOrder { int per, total; unsigned wmagic; };
-
 template <typename T>
-void launch_group_cfg(int cfg, const GroupArgs& ga, const XcdOrder& xo, int total, hipStream_t st) {
+void launch_group_cfg(int cfg, const GroupArgs& ga, int total, hipStream_t st) {
     switch (cfg) {
 #define X(I, A, B, C_, D, E, F, G, H)                                                                                                     \
     case I:                                                                                                                               \
         hipLaunchKernelGGL((conv_fwd_group<T, A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, ga.nprob,      \
                            ga.tile_end[0], ga.tile_end[1], ga.tile_end[2], ga.tile_end[3], ga.tile_end[4], ga.tile_end[5], ga.tile_end[6],          \
-                           ga.tile_end[7], xo.per, xo.total, xo.wmagic, ga);                                                                       \
+                           ga.tile_end[7], ga);                                                                                                    \
         break;
         FCN_CONV_CONFIGS(X)
 #undef X
@@ -1056,30 +998,6 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
             ga.tile_end[i] = src.tile_end - base;
         }
         int grid = ga.tile_end[ga.nprob - 1];
-        // XCD-aware tile order + rotated K loops (see conv_fwd_group / conv_body), possible when every problem of the launch
-        // has the same number of tile rows.  Both are OFF unless $FCN_CONV_XCD=1 / $FCN_CONV_ROTATE=1: measured in round 2
-        // (profiles/experiments/r02_xcd_order_k_rotation.json) the rotation changes nothing and the XCD order costs the
-        // multi-problem 3x3 / 5x5 groups 2-5 us - the per-CU staging rate is not set by where the bytes come from.
-        XcdOrder xo = {0, 0, 0u};
-        static const bool want_xcd = getenv("FCN_CONV_XCD") && atoi(getenv("FCN_CONV_XCD")) != 0;
-        static const bool want_rot = getenv("FCN_CONV_ROTATE") && atoi(getenv("FCN_CONV_ROTATE")) != 0;
-        bool same_rows = true;
-        for (int i = 1; i < ga.nprob; ++i) same_rows = same_rows && ga.p[i].tiles_m == ga.p[0].tiles_m;
-        int cols_all = 0;
-        for (int i = 0; i < ga.nprob; ++i) cols_all += ga.p[i].tiles_n;
-        if (want_xcd && same_rows && grid >= 16 && (long long)grid * cols_all < (1ll << 32)) {
-            int cols = 0;
-            for (int i = 0; i < kMaxGroup; ++i) {
-                if (i < ga.nprob) cols += ga.p[i].tiles_n;
-                ga.tile_end[i] = cols;      // exclusive prefix of tile COLUMNS (the last one repeated in the unused entries)
-            }
-            xo.total = ga.p[0].tiles_m * cols;      // == grid
-            xo.per = (xo.total + 7) / 8;
-            xo.wmagic = cols > 1 ? (unsigned)(((1ull << 32) + cols - 1) / cols) : 0u;      // total * cols < 2^32 (plan_tiles_cfg)
-            grid = 8 * xo.per;
-        }
-        if (want_rot)
-            for (int i = 0; i < kMaxGroup; ++i) ga.p[i].flags |= kFlagRotate;
         if (hg.npool > 0) {      // only with n <= kMaxGroup: a single launch
             const int per_wg = kCfgThreads[g->cfg] * kPoolItemsPerThread;
             int end = 0;
@@ -1091,8 +1009,8 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
             }
             grid += end;
         }
-        if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, xo, grid, as_stream(s));
-        else launch_group_cfg<float>(g->cfg, ga, xo, grid, as_stream(s));
+        if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, grid, as_stream(s));
+        else launch_group_cfg<float>(g->cfg, ga, grid, as_stream(s));
         FCN_LAUNCH_CHECK("conv_fwd_group");
     }
     return 0;

@@ -305,31 +305,43 @@ struct WgShape { int bn, bk, nw; double eff; };   // eff: sustained fraction of 
 constexpr int kNumWgCfg = 4;
 constexpr WgShape kWgShapes[kNumWgCfg] = {{64, 64, 4, 0.55}, {64, 128, 4, 0.50}, {128, 64, 4, 0.60}, {64, 64, 4, 0.50}};
 
-// out[i] = sum_s parts[s][i] in a FIXED order (bit-reproducible), but not a serial one: 16 lanes per output each
-// sum every 16th slab, then the 16 lane sums are added in lane order.  A serial loop over up to 256 slabs is a chain of
-// dependent-latency loads on a handful of workgroups (100+ us for the small layers); this tree keeps the loads in flight.
-constexpr int RED_LANES = 16;
-__global__ __launch_bounds__(64 * RED_LANES) void reduce_partials_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t count,
-                                                                         int splits, size_t stride) {
-    __shared__ float part[RED_LANES][64];
-    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    for (size_t base = (size_t)blockIdx.x * 64; base < count; base += (size_t)gridDim.x * 64) {
-        const size_t i = base + o;
-        float s = 0.f;
-        if (i < count) {
-#pragma unroll 4
-            for (int k = sl; k < splits; k += RED_LANES) s += parts[(size_t)k * stride + i];
-        }
-        part[sl][o] = s;
-        __syncthreads();
-        if (sl == 0 && i < count) {
-            float t = part[0][o];
+// out[i] = sum_s parts[s][i] in a FIXED order (slab 0, 1, 2, ..: bit-reproducible).  One lane owns four consecutive outputs
+// and walks the slabs with 16-byte loads, eight of them in flight at a time (the adds stay in slab order): every access is
+// a full 1 KiB wave-instruction.  Round 1 gave each output 16 lanes that read 4 bytes per slab - 256 B per wave-instruction,
+// 64 outputs per 1024-thread block, two barriers - and the pass cost 10 % of the training step (profiles/r01_train_*).
+constexpr int RED_THREADS = 256, RED_PER_BLOCK = RED_THREADS * 4;
+__device__ __forceinline__ void reduce_slabs(const float* __restrict__ parts, float* __restrict__ out, size_t count, int splits, size_t stride,
+                                             size_t i4) {
+    if (i4 >= count) return;
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const bool vec = i4 + 3 < count && (stride & 3) == 0 && (((size_t)parts | (size_t)out) & 15) == 0;
+    if (vec) {
+        const v4* src = reinterpret_cast<const v4*>(parts + i4);
+        const size_t st4 = stride / 4;
+        v4 acc = src[0];
+        int k = 1;
+        for (; k + 7 < splits; k += 8) {
+            v4 v[8];
 #pragma unroll
-            for (int l = 1; l < RED_LANES; ++l) t += part[l][o];
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + j) * st4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; k < splits; ++k) acc += src[(size_t)k * st4];
+        *reinterpret_cast<v4*>(out + i4) = acc;
+    } else {
+        for (size_t i = i4; i < count && i < i4 + 4; ++i) {
+            float t = parts[i];
+            for (int k = 1; k < splits; ++k) t += parts[(size_t)k * stride + i];
             out[i] = t;
         }
-        __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(RED_THREADS) void reduce_partials_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t count,
+                                                                      int splits, size_t stride) {
+    for (size_t base = (size_t)blockIdx.x * RED_PER_BLOCK; base < count; base += (size_t)gridDim.x * RED_PER_BLOCK)
+        reduce_slabs(parts, out, count, splits, stride, base + (size_t)threadIdx.x * 4);
 }
 
 struct ReduceGroupArgs {
@@ -341,9 +353,8 @@ struct ReduceGroupArgs {
     int splits[kMaxWgGroup];
 };
 
-// the same fixed-order tree for up to kMaxWgGroup problems in one launch (one problem per block range)
-__global__ __launch_bounds__(64 * RED_LANES) void reduce_partials_group_kernel(const ReduceGroupArgs a) {
-    __shared__ float part[RED_LANES][64];
+// the same for up to kMaxWgGroup problems in one launch (one problem per block range)
+__global__ __launch_bounds__(RED_THREADS) void reduce_partials_group_kernel(const ReduceGroupArgs a) {
     int pi = 0, begin = 0;
 #pragma unroll
     for (int i = 0; i < kMaxWgGroup - 1; ++i) {
@@ -358,21 +369,7 @@ __global__ __launch_bounds__(64 * RED_LANES) void reduce_partials_group_kernel(c
 #pragma unroll
     for (int i = 1; i < kMaxWgGroup; ++i)
         if (pi == i) { parts = a.parts[i]; out = a.out[i]; count = a.count[i]; stride = a.stride[i]; splits = a.splits[i]; }
-    const int o = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const size_t i = (size_t)((int)blockIdx.x - begin) * 64 + o;
-    float s = 0.f;
-    if (i < count) {
-#pragma unroll 4
-        for (int k = sl; k < splits; k += RED_LANES) s += parts[(size_t)k * stride + i];
-    }
-    part[sl][o] = s;
-    __syncthreads();
-    if (sl == 0 && i < count) {
-        float t = part[0][o];
-#pragma unroll
-        for (int l = 1; l < RED_LANES; ++l) t += part[l][o];
-        out[i] = t;
-    }
+    reduce_slabs(parts, out, count, splits, stride, ((size_t)((int)blockIdx.x - begin) * RED_THREADS + threadIdx.x) * 4);
 }
 
 // wt[c][kh-1-r][kw-1-q][k] = w[k][r][q][c]   (w: [Cout][kh][kw][Cin4], wt: [Cin][kh][kw][Cout4], pads of wt zero)
@@ -789,7 +786,7 @@ size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* d, int* h_splits) 
     int cfg = 0, splits = 1;
     plan_wgrad(d, &cfg, &splits);
     if (h_splits) *h_splits = splits;
-    return (size_t)splits * ((size_t)d->Cout * K + d->Cout);
+    return (size_t)splits * (((size_t)d->Cout * K + d->Cout + 3) / 4 * 4);
 }
 
 static int wgrad_validate(const fcn_conv_desc* d) {
@@ -823,7 +820,7 @@ static void wgrad_fill(WgradP& p, const fcn_conv_desc* d, int cfg, int splits, f
     p.ohw_magic = magic32((unsigned)(p.OH * p.OW));
     p.kw_magic = (65536 + p.kw - 1) / p.kw;
     p.dw_part = slabs;
-    p.slab_floats = p.Cout * p.K + p.Cout;
+    p.slab_floats = (p.Cout * p.K + p.Cout + 3) / 4 * 4;      // slabs stay 16-byte aligned for the reduction's float4 loads
     p.db_part = with_bias ? slabs + (size_t)p.Cout * p.K : nullptr;
 }
 
@@ -853,10 +850,10 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     // the solver keeps a layer's bias gradient right behind its weight gradient: one reduction then covers both
     const bool together = db && db == dw + cnt;
     const size_t cnt1 = together ? cnt + p.Cout : cnt;
-    const int red_blocks = (int)((cnt1 + 63) / 64 < 4096 ? (cnt1 + 63) / 64 : 4096);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(red_blocks), dim3(64 * RED_LANES), 0, st, p.dw_part, dw, cnt1, splits, stride);
+    const int red_blocks = (int)((cnt1 + RED_PER_BLOCK - 1) / RED_PER_BLOCK < 4096 ? (cnt1 + RED_PER_BLOCK - 1) / RED_PER_BLOCK : 4096);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(red_blocks), dim3(RED_THREADS), 0, st, p.dw_part, dw, cnt1, splits, stride);
     if (db && !together)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.Cout, 64)), dim3(64 * RED_LANES), 0, st, p.db_part, db, (size_t)p.Cout, splits, stride);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.Cout, RED_PER_BLOCK)), dim3(RED_THREADS), 0, st, p.db_part, db, (size_t)p.Cout, splits, stride);
     FCN_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }
@@ -899,7 +896,7 @@ size_t fcn_conv2d_wgrad_group_workspace_floats(const fcn_conv_desc* ds, int n) {
     int cfg = 0, splits[kMaxWgGroup];
     plan_wgrad_group(ds, n, &cfg, splits);
     size_t total = 0;
-    for (int i = 0; i < n; ++i) total += (size_t)splits[i] * ((size_t)ds[i].Cout * ds[i].kh * ds[i].kw * ds[i].Cin + ds[i].Cout) + 4;
+    for (int i = 0; i < n; ++i) total += (size_t)splits[i] * (((size_t)ds[i].Cout * ds[i].kh * ds[i].kw * ds[i].Cin + ds[i].Cout + 3) / 4 * 4) + 4;
     return total;
 }
 
@@ -936,7 +933,7 @@ int fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* ds, float* const* dws, float
             ra.count[i] = together ? cnt + p.Cout : cnt;
             ra.stride[i] = (unsigned long long)p.slab_floats;
             ra.splits[i] = p.splits;
-            blks += (int)((ra.count[i] + 63) / 64);
+            blks += (int)((ra.count[i] + RED_PER_BLOCK - 1) / RED_PER_BLOCK);
             if (dbs[i] && !together) extras[extra++] = Extra{p.db_part, dbs[i], (size_t)p.Cout, (size_t)p.slab_floats, p.splits};
             slabs += ((size_t)p.splits * p.slab_floats + 3) / 4 * 4;
         } else {
@@ -955,9 +952,9 @@ int fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* ds, float* const* dws, float
         FCN_WGRAD_CONFIGS(X)
 #undef X
     }
-    hipLaunchKernelGGL(reduce_partials_group_kernel, dim3(blks), dim3(64 * RED_LANES), 0, st, ra);
+    hipLaunchKernelGGL(reduce_partials_group_kernel, dim3(blks), dim3(RED_THREADS), 0, st, ra);
     for (int e = 0; e < extra; ++e)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((long long)extras[e].count, 64)), dim3(64 * RED_LANES), 0, st, extras[e].parts,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((long long)extras[e].count, RED_PER_BLOCK)), dim3(RED_THREADS), 0, st, extras[e].parts,
                            extras[e].out, extras[e].count, extras[e].splits, extras[e].stride);
     FCN_LAUNCH_CHECK("conv_wgrad_group");
     return 0;
