@@ -171,12 +171,19 @@ __device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
 __device__ __forceinline__ int fast_div(int m, unsigned magic) { return magic ? (int)__umulhi((unsigned)m, magic) : m; }
 
 
-template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
+// Ring slots >= 16 select SPLIT ROLES (the value minus 16 is the ring depth): the workgroup has twice the waves, the first
+// half multiplies (fragment reads + MFMAs, no vector-memory work), the second half loads (address arithmetic + LDS-DMA, no
+// MFMAs).  With one wave per SIMD the loader's ~45 VALU instructions per chunk do not hide behind the wave's own MFMAs (the
+// launch costs MFMA time PLUS loader time: 4a_A 8.4 us with, 6.8 us without its MFMAs); with a loader wave beside a
+// multiplier wave on every SIMD the vector pipe and the matrix pipe really run side by side.
+template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF_, bool PF>
 struct Cfg {
+    static constexpr bool ROLES = NBUF_ >= 16;
+    static constexpr int NBUF = ROLES ? NBUF_ - 16 : NBUF_;
     static constexpr int BM = 32 * WTM * WAVES_M;
     static constexpr int BN = 32 * WTN * WAVES_N;
-    static constexpr int NW = WAVES_M * WAVES_N * WAVES_K;   // waves per workgroup
-    static constexpr int NT = 64 * NW;
+    static constexpr int NW = WAVES_M * WAVES_N * WAVES_K;   // multiplying waves (= loading waves) per workgroup
+    static constexpr int NT = 64 * NW * (ROLES ? 2 : 1);
     static constexpr int SEGS = BK / 4;                 // 16-byte slots per staged row
     static constexpr int RPI = 256 / BK;                // rows one LDS-DMA wave-instruction (1 KiB) fills
     static constexpr int STEP = RPI * NW;               // rows between two consecutive instructions of one wave
@@ -236,9 +243,11 @@ __device__ int g_conv_stamps_cap = 0;
 // weights, f32 accumulation, BASELINE configs[4]): v_mfma_f32_32x32x16_f16, 8 elements per segment - the staging, the LDS
 // image, the swizzle and the pipeline are byte-for-byte the same (BK counts 4-byte words), a chunk just covers twice the
 // k range and one MFMA consumes what four f32 MFMAs do.
-template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
+template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF_, bool PF>
 __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem) {
-    using C = Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>;
+    using C = Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF_, PF>;
+    constexpr int NBUF = C::NBUF;
+    constexpr bool ROLES = C::ROLES;
     constexpr int BM = C::BM, SEGS = C::SEGS, RPI = C::RPI, STEP = C::STEP, IA = C::IA, IB = C::IB, INST = C::INST;
     constexpr int D = C::D, KS = C::KS, BUF_FLOATS = C::BUF_FLOATS;
     constexpr bool F16 = sizeof(T) == 2;
@@ -251,7 +260,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     FCN_STAMP(0);      // kernel entry (after the kernarg loads of the group prologue)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base goes through M0)
+    const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base goes through M0)
+    // split roles: waves 0 .. NW-1 multiply, waves NW .. 2NW-1 load; otherwise every wave does both
+    const bool is_loader = !ROLES || wid_all >= C::NW, is_mult = !ROLES || wid_all < C::NW;
+    const int wid = ROLES && wid_all >= C::NW ? wid_all - C::NW : wid_all;      // index within the role
     const int wk = wid % WAVES_K;
     const int wn = (wid / WAVES_K) % WAVES_N;
     const int wm = wid / (WAVES_K * WAVES_N);
@@ -459,12 +471,69 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // MFMAs - 4a_A runs 8.4 us with and 6.8 us without its MFMAs, sweep_nomfma.log).
     int buf_issue = 0;                 // ring slot of the next chunk to issue
     auto next = [](int b) { return b + 1 == NBUF ? 0 : b + 1; };
+    int buf_cur = 0;                   // ring slot of chunk c
+    if constexpr (ROLES) {
+        // ---- split roles: the same ring, the same one barrier per chunk, but the two halves of the workgroup run different
+        // loops.  Every barrier below is executed by BOTH loops (1 + nchunks + 1).
+        static_assert(PF, "split roles use the prefetching multiplier loop");
+        if (is_loader) {
+#pragma unroll 1
+            for (int c = 0; c < D; ++c) {
+                issue_chunk(buf_issue);
+                buf_issue = next(buf_issue);
+            }
+            wait_vmcnt<INST*(D - 1)>();        // chunk 0 landed (this wave's pieces) ...
+            __builtin_amdgcn_s_barrier();      // ... and everybody else's
+#pragma unroll 1
+            for (int c = 0; c < nchunks; ++c) {
+                wait_vmcnt<INST*(D - 2)>();    // chunk c + 1 landed
+                __builtin_amdgcn_s_barrier();  // the multipliers are done with chunk c - 1: its slot takes chunk c + D
+                asm volatile("" ::: "memory");
+                issue_chunk(buf_issue);
+                buf_issue = next(buf_issue);
+            }
+            wait_vmcnt<0>();                   // the all-zero chunks issued past K must land before the ring is reused
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            FCN_STAMP(2);      // first chunk usable
+            read_frags(0, 0);
+            for (int c0 = 0; c0 < nchunks; c0 += 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {      // unrolled by 2: the fragment parity is a compile-time constant
+                    if (c0 + u < nchunks) {
+                        __builtin_amdgcn_s_barrier();      // chunk c + 1 is in LDS
+                        asm volatile("" ::: "memory");
+                        frags_landed(u & 1, 0, KS);
+                        const unsigned nslot = (unsigned)next(buf_cur) * (BUF_FLOATS * 4);
+                        constexpr int NG = KS * MPS;
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            mfma_group(u & 1, g / MPS, g % MPS);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (g < KS) read_step((u + 1) & 1, g, g, nslot);      // the fragments of chunk c + 1, in the MFMAs' shadow
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        static_assert(KS <= KS * MPS, "one fragment read per MFMA group");
+                        buf_cur = next(buf_cur);
+                    }
+                }
+            }
+            FCN_STAMP(3);      // main loop done
+            frags_landed(0, 0, KS);      // (the reads of the chunk that does not exist: see the comment in the other branch)
+            frags_landed(1, 0, KS);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
 #pragma unroll 1
     for (int c = 0; c < D; ++c) {      // rolled: straight-line code costs instruction fetches, and this runs once
         issue_chunk(buf_issue);
         buf_issue = next(buf_issue);
     }
-    int buf_cur = 0;                   // ring slot of chunk c
     FCN_STAMP(1);      // prologue issued
     if (PF) {
         wait_vmcnt<INST*(D - 1)>();   // chunk 0 landed (this wave's pieces) ...
@@ -544,13 +613,15 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
+    }
+
     // ---- epilogue: every wave parks its accumulators in LDS, then ALL threads of the workgroup reduce the K-split
     // partials (fixed order wk = 0, 1, ..), add the bias, apply ReLU / accumulate / mask / sigmoid and store 4 consecutive
     // channels per lane (one 16-byte store).  The former epilogue - wave wk = 0 alone, one 4-byte store per accumulator
     // register behind a ladder of per-element branches - was 1700 instructions of straight-line code executed once:
     // 2.0 us of a 9 us launch at M = 784 (tools/conv_timeline.py), most of it instruction fetch.
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-    {
+    if (is_mult) {
         float* slab = smem + (size_t)(((wm * WAVES_N + wn) * WAVES_K + wk) * WTM * WTN) * 1024 + (lane >> 5) * 128 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
@@ -647,7 +718,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 }
 
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_group(const int nprob, const int te0, const int te1, const int te2,
+__global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT)) void conv_fwd_group(const int nprob, const int te0, const int te1, const int te2,
                                                                                   const int te3, const int te4, const int te5, const int te6,
                                                                                   const int te7, const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
@@ -668,8 +739,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_gro
     const int conv_tiles = head[kMaxGroup];      // the host repeats the last prefix in the unused entries
     if (tile >= conv_tiles) {      // workgroups behind the convolution tiles: the poolings fused into this launch
         const int w = tile - conv_tiles;
-        if (w < a.pool[0].wg_end) pool_body<T, 64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[0], w);
-        else pool_body<T, 64 * WAVES_M * WAVES_N * WAVES_K>(a.pool[1], w - a.pool[0].wg_end);
+        if (w < a.pool[0].wg_end) pool_body<T, Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT>(a.pool[0], w);
+        else pool_body<T, Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT>(a.pool[1], w - a.pool[0].wg_end);
         return;
     }
     int pi = 0, begin = 0;
@@ -697,7 +768,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_gro
 }
 
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_one(ConvP p) {
+__global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT)) void conv_fwd_one(ConvP p) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
     conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(p, blockIdx.x, smem);
 }
@@ -728,7 +799,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * WAVES_K) void conv_fwd_one
     X(19, 1, 1, 2, 1, 2, 32, 4, true)  \
     X(20, 1, 1, 2, 1, 2, 32, 3, false) \
     X(21, 1, 1, 1, 1, 4, 32, 3, false) \
-    X(22, 1, 1, 4, 1, 1, 32, 3, false)
+    X(22, 1, 1, 4, 1, 1, 32, 3, false) \
+    X(23, 1, 1, 1, 1, 4, 32, 16 + 4, true)  \
+    X(24, 1, 1, 1, 1, 4, 64, 16 + 4, true)  \
+    X(25, 1, 1, 2, 1, 2, 32, 16 + 4, true)  \
+    X(26, 1, 1, 2, 2, 1, 32, 16 + 4, true)  \
+    X(27, 1, 1, 1, 1, 4, 32, 16 + 6, true)  \
+    X(28, 1, 1, 2, 2, 1, 64, 16 + 4, true)  \
+    X(29, 2, 1, 2, 2, 1, 32, 16 + 4, true)
 
 struct TileCfg { int bm, bn, bk; bool prefetch; };
 constexpr int kCfgThreads[] = {
@@ -746,7 +824,7 @@ constexpr int kCfgWavesK[] = {
     FCN_CONV_CONFIGS(X)
 #undef X
 };
-constexpr int kNumCfg = 23;
+constexpr int kNumCfg = 30;
 constexpr TileCfg kCfgs[kNumCfg] = {
 #define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
     FCN_CONV_CONFIGS(X)

@@ -51,7 +51,7 @@ def f16_conv(x, wt, b, pad, stride, flags, out_f32, y_cstride=None, y_coffset=0)
     return y
 
 
-@pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15"])
+@pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15", "23", "24", "26", "29"])
 @pytest.mark.parametrize("case", CASES)
 def test_f16_conv_matches_oracle_on_the_same_rounded_inputs(gpu, monkeypatch, case, cfg):
     if cfg is None:

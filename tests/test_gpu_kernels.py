@@ -53,7 +53,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [str(i) for i in range(23)] + [None])
+@pytest.mark.parametrize("cfg", [str(i) for i in range(30)] + [None])      # every tile configuration, the split-role ones (23..29) included
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_matches_oracle(gpu, monkeypatch, case, cfg):
     cin, cout, k, s, p, h, w, n = case
@@ -267,7 +267,7 @@ def test_depthwise_deconv_matches_oracle(gpu, c, k, s, p, h):
     assert rel_err(y, R.deconv2d(x, w, None, p, s, group=c)) < 1e-5
 
 
-@pytest.mark.parametrize("cfg", [2, 5, 8, 13])
+@pytest.mark.parametrize("cfg", [2, 5, 8, 13, 23, 26])
 @pytest.mark.parametrize("with_idx", [False, True])
 def test_maxpool_fused_into_conv_group(gpu, cfg, with_idx):
     """Two MAX poolings ride in a grouped convolution launch (fcn_conv2d_group_prepare_fused): conv outputs unchanged,
