@@ -28,6 +28,44 @@ FWD_GFLOP = 15.608          # 2*MAC over the 59 convolutions at 448
 ALGO_BYTES_MB = 277.7       # fused algorithmic HBM bytes per forward frame (f32)
 F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
+F16_ACT_MB = 253.7 / 2      # the f32 path's algorithmic activation bytes per frame, stored as halves
+F16_WEIGHT_MB = 24.0 / 2    # weights once per batch
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources: profiles/*.json carry the hash of the sources they were measured on, so a traffic figure
+    read back from a committed profile shows when the kernels have changed since (tools/profile_bench.sh stamps it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "fcn_object_detector_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "fcn_object_detector_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_traffic(tag: str, key: str = "conv_fwd_hbm"):
+    """HBM bytes per launch of a kernel family from the committed PMC passes profiles/<tag>_pmc_{fetch,write}.json (separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    try:
+        pf = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_fetch.json")))
+        pw = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_write.json")))
+        return {"bytes_per_launch": round(pf[key]["read_bytes_per_launch"] + pw[key]["write_bytes_per_launch"]),
+                "profile": "profiles/%s_pmc_{fetch,write}.json" % tag, "profile_kernel_sources": pf.get("kernel_source_hash"),
+                "stale": pf.get("kernel_source_hash") != kernel_source_hash()}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def infer32_traffic(fwd_ms: float):
+    """HBM bytes per batch-32 f16 forward from the committed PMC passes (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE around tools/fwd_resident.py 32 f16 N, totals divided by the N forwards)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_infer32_f16_hbm.json")))
+        return {"bytes_per_forward": d["bytes_per_forward"], "measured_GBps": round(d["bytes_per_forward"] / fwd_ms / 1e6, 1),
+                "profile": "profiles/r02_infer32_f16_hbm.json", "stale": d.get("kernel_source_hash") != kernel_source_hash()}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(msg, params, x, budget_s: float = 20.0):
@@ -139,6 +177,16 @@ def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
            "workload": "configs[%d]: DetectNet GoogLeNet train step (device target generation + fwd + bwd + %s + SGD), batch %d/GPU, 448x448, f32"
                        % (2 if world == 1 else 3, "RCCL all-reduce of 23.9 MB grads" if world > 1 else "no collective", n)}
     res["achieved_tflops"] = round(45.9e-3 * res["imgs_per_s"], 2)
+    # roofline of the step's dominant kernel family: the MFMA weight gradient (conv_wgrad_group_kernel + its fixed-order
+    # reduction of the pixel-split partials), HIP events per launch on the engine's stream
+    wg = [r for r in eng.time_ops(reps=3, ops=eng.bwd_ops) if r[0] == "wgrad"]
+    wg_ms, wg_fl = sum(r[2] for r in wg), sum(r[3] for r in wg)
+    if wg_ms > 0:
+        res["roofline"] = {"bound": "mfma", "kernel": "conv_wgrad_group_kernel (f32 MFMA, reduction over pixels) + reduce_partials_group_kernel; %d launches" % len(wg),
+                           "achieved": round(wg_fl / wg_ms / 1e9, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(wg_fl / wg_ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "ms_per_step": round(wg_ms, 3), "whole_step_frac": round(res["achieved_tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                           "note": "achieved = 2*Cout*K*M per layer / HIP-event time of its launch; whole_step_frac = 45.9 GFLOP/img over the whole step"}
     if comm is not None:
         # the collective by itself, and how much of it the backward pass hides.  "dry" = the same step
         # with every bucket's hand-off (events, stream waits) but no ncclAllReduce behind it.
@@ -284,6 +332,12 @@ def bench_infer32(local: int, dtype: str, reps: int = 10):
     return {"frames_per_s": round(n / dt2, 1), "ms_per_batch": round(dt2 * 1e3, 3), "batches_in_flight": 2,
             "one_batch_at_a_time": {"frames_per_s": round(n / dt, 1), "ms_per_batch": round(dt * 1e3, 3)}, "forward_ms": round(fwd_ms, 3),
             "forward_tflops": round(FWD_GFLOP * n / fwd_ms, 1), "dtype": dtype, "batch": n,
+            "roofline": ({"bound": "hbm", "kernel": "conv_fwd (f16 storage, v_mfma_f32_32x32x16_f16): the whole forward, 27 launches",
+                          "achieved": round((n * F16_ACT_MB + F16_WEIGHT_MB) / fwd_ms, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round((n * F16_ACT_MB + F16_WEIGHT_MB) / fwd_ms / HBM_PEAK_GBS, 4), "traffic": infer32_traffic(fwd_ms),
+                          "note": "algorithmic bytes per batch = %d x %.1f MB of half activations (read + written once by every conv / pool / LRN) "
+                                  "+ %.1f MB of half weights, over the forward's device time; SURVEY 8(d): this path is bytes-bound (ridge 400 flop/B vs 112)"
+                                  % (n, F16_ACT_MB, F16_WEIGHT_MB)} if dtype == "f16" else None),
             "detections_last_batch": int(sum(len(r[0]) for r in res)),
             "candidates_per_image_class": {"mean": round(float((heads["coverage"] >= 0.5).sum(axis=(2, 3)).mean()), 1),
                                            "max": int((heads["coverage"] >= 0.5).sum(axis=(2, 3)).max())}}, heads
@@ -485,18 +539,15 @@ def main() -> None:
                 sys.stderr.write("%-10s %-60s %8.2f us %7.2f TF/s %7.1f GB/s\n" % (k, n[:60], ms * 1e3, fl / ms / 1e9 if ms else 0,
                                                                                   by / ms / 1e6 if ms else 0))
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
-        traffic = None      # HBM bytes per conv launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)
-        try:
-            pf = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_fetch.json")))["conv_fwd_hbm"]
-            pw = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_pmc_write.json")))["conv_fwd_hbm"]
-            traffic = round(pf["read_bytes_per_launch"] + pw["write_bytes_per_launch"])
-        except (OSError, KeyError, ValueError):
-            pass
+        tr = profile_traffic("r02_bench")      # HBM bytes per conv launch from the committed PMC passes (stamped with the sources' hash)
+        traffic = tr["bytes_per_launch"] if tr else None
         roofline = {"bound": "mfma", "kernel": "conv_fwd (f32 MFMA implicit GEMM; %d launches covering the 59 convolutions)" % len(conv),
                     "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_note": "HBM bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE (profiles/r01_bench_pmc_*.json); "
-                                    "algorithmic bytes per launch = %.0f" % (sum(o[4] for o in conv) / max(len(conv), 1)),
+                    "traffic_source": tr, "algorithmic_bytes_per_launch": round(sum(o[4] for o in conv) / max(len(conv), 1)),
+                    "traffic_note": "HBM bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this "
+                                    "command; 'stale' = the kernel sources changed since that profile",
+                    "frames_in_flight": 1,
                     "avg_launch_us": round(conv_ms * 1e3 / max(len(conv), 1), 2), "launches_per_step": len(ops),
                     "sum_kernel_ms_per_step": round(all_ms, 4),
                     "measured_on": "one stream, launches serial (kernel durations are not comparable once frames overlap)",
@@ -512,7 +563,15 @@ def main() -> None:
                                  "latency_ms_per_frame": round(serial_s * 1e3 / args.steps, 4),
                                  "device_ms_per_step": round(dev_ms / args.steps, 4)},
                "pcie_inclusive_fps": round(pcie_fps, 2),
-               "roofline": roofline}
+               "config2_timed_region": {"frames_per_s": round(pcie_fps, 2), "ms_per_frame": round(1e3 / pcie_fps, 4),
+                                        "includes": "SURVEY 8(d) config 2: H2D of the (3,448,448) f32 frame + layout change + all kernels + D2H of the "
+                                                    "two head blobs, one frame at a time (never `value`: inputs resident in HBM there)"},
+               "roofline": roofline,
+               "roofline_in_flight": {"bound": "mfma", "frames_in_flight": depth, "achieved": round(FWD_GFLOP * value / 1e3, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": round(FWD_GFLOP * value / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
+                                      "note": "the mode `value` is measured in: conv FLOPs of a frame x frames/s over the wall clock of the K steps (kernels "
+                                              "of different frames overlap, so per-kernel durations are not comparable; profiles/r02_bench_inflight_kernel_stats.csv "
+                                              "holds the kernel trace of this mode: GPU-busy time / wall time there)"}}
         if world == 1 and not args.no_cpu_baseline:
             base, ref_blobs = cpu_baseline(msg, params, x)
             out["cpu_baseline"] = base

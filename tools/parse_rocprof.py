@@ -48,6 +48,23 @@ def main():
             e.update({c: v for c, v in d.items()})
     if steps:
         res["steps_profiled"] = steps
+    try:      # which kernel sources this profile was measured on (bench.py reports `stale` when they have changed since)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import kernel_source_hash
+        res["kernel_source_hash"] = kernel_source_hash()
+    except Exception:
+        pass
+    if res["counters"]:
+        calls = sum(v["calls"] for v in res["counters"].values())
+        fetch_kib = sum(v.get("FETCH_SIZE", 0.0) for v in res["counters"].values())
+        write_kib = sum(v.get("WRITE_SIZE", 0.0) for v in res["counters"].values())
+        res["all_kernels_hbm"] = {"launches": calls, "read_bytes_total": 2.0 * fetch_kib * 1024, "write_bytes_total": write_kib * 1024,
+                                  "read_bytes_per_launch": 2.0 * fetch_kib * 1024 / max(calls, 1), "write_bytes_per_launch": write_kib * 1024 / max(calls, 1),
+                                  "note": "every kernel of the run; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB"}
+        # matrix-core utilisation where the MFMA counters were collected: busy cycles of the matrix pipes / busy cycles of the SQs
+        for k, v in res["counters"].items():
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("SQ_BUSY_CYCLES"):
+                v["mfma_busy_over_sq_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CYCLES"], 4)
     conv = {k: v for k, v in res["counters"].items() if k.startswith("conv_fwd")}
     if conv:
         calls = sum(v["calls"] for v in conv.values())

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Round profile of `bench.py` on the GPU box: kernel-trace statistics and the two HBM counter passes (separate runs, as
-# MI355X_MICROARCH.md prescribes), summarised into gpurun_out/*.json.  usage: tools/profile_bench.sh <tag> [bench args]
+# Round profile of `bench.py` on the GPU box: kernel-trace statistics, the two HBM counter passes and the matrix-core counter
+# pass (separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes), summarised into gpurun_out/<tag>_*.json / .csv;
+# copy the summaries into profiles/ afterwards.  usage: tools/profile_bench.sh <tag> [bench args]
 set -e -o pipefail
-TAG=${1:-r01}; shift || true
+TAG=${1:-r02}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -10,24 +11,59 @@ export FCN_TUNE_CACHE=$OUT/${TAG}_tune.json
 ARGS="--steps 50 --warmup 5 --no-cpu-baseline --no-secondary $*"
 cd "$ROOT"
 python3 bench.py $ARGS > "$OUT/${TAG}_bench_plain.json"            # fills the tune cache: profiled runs replay the plan
-# the profiled runs keep ONE frame in flight: per-kernel durations (what `roofline` is computed from) are only meaningful
-# when launches do not overlap
-ARGS="$ARGS --in-flight 1"
 export TMPDIR=/tmp
-# rocprofv3 (ROCm 7.2) segfaults inside hipGraphLaunch when the plan is replayed from the tune cache; the profiled runs
-# therefore issue the same kernels as ordinary launches (identical kernels, arguments and order)
+# The profiled runs issue the forward as ordinary launches (FCN_NO_GRAPH=1): under rocprofv3 (ROCm 7.2) a hipGraphLaunch of the
+# plan replayed from the tune cache crashed in round 1 (no trace was kept; not retried - DESIGN.md section 5).  Kernels,
+# arguments and order are those of the graph.
 export FCN_NO_GRAPH=1
-rm -rf "$OUT/${TAG}_stats" "$OUT/${TAG}_tstats" "$OUT/${TAG}_fetch" "$OUT/${TAG}_write"
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_stats" -o run -- python3 "$ROOT/bench.py" $ARGS --no-train > "$OUT/${TAG}_bench_under_rocprof.json" )
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_tstats" -o run -- python3 "$ROOT/bench.py" $ARGS > "$OUT/${TAG}_train_under_rocprof.json" )
-( cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/${TAG}_fetch" -o run -- python3 "$ROOT/bench.py" $ARGS --no-train > /dev/null )
-( cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/${TAG}_write" -o run -- python3 "$ROOT/bench.py" $ARGS --no-train > /dev/null )
-python3 tools/parse_rocprof.py "$OUT/${TAG}_stats" "$OUT/${TAG}_bench_kernel_stats.json"
-python3 tools/parse_rocprof.py "$OUT/${TAG}_tstats" "$OUT/${TAG}_train_kernel_stats.json"
-cp "$(find "$OUT/${TAG}_tstats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_train_kernel_stats.csv"
-python3 tools/parse_rocprof.py "$OUT/${TAG}_fetch" "$OUT/${TAG}_bench_pmc_fetch.json"
-python3 tools/parse_rocprof.py "$OUT/${TAG}_write" "$OUT/${TAG}_bench_pmc_write.json"
-cp "$(find "$OUT/${TAG}_stats" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_bench_kernel_stats.csv"
+prof() {      # prof <dir> <rocprofv3 options...> -- <program...>   (the program itself follows `--`: never a wrapper)
+    local d=$1; shift
+    rm -rf "$OUT/$d"
+    ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/$d" -o run "$@" )
+}
+# (1) ONE frame in flight: per-kernel durations (what `roofline` is computed from) only mean something when launches do not overlap
+ONE="$ARGS --in-flight 1"
+prof ${TAG}_stats --stats -- python3 "$ROOT/bench.py" $ONE --no-train > "$OUT/${TAG}_bench_under_rocprof.json"
+prof ${TAG}_tstats --stats -- python3 "$ROOT/bench.py" $ONE > "$OUT/${TAG}_train_under_rocprof.json"
+prof ${TAG}_fetch --pmc FETCH_SIZE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
+prof ${TAG}_write --pmc WRITE_SIZE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
+# (2) matrix-core counters (SQ block, own pass): busy cycles of the MFMA pipes against the SQ's busy cycles, MFMA op counts
+prof ${TAG}_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null || echo "MFMA counter pass failed (counter names: rocprofv3 -L)"
+prof ${TAG}_tmfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES -- python3 "$ROOT/bench.py" $ONE > /dev/null || echo "MFMA counter pass (train) failed"
+# (3) the mode `value` is measured in: four frames in flight
+prof ${TAG}_inflight --stats -- python3 "$ROOT/bench.py" $ARGS --no-train > "$OUT/${TAG}_bench_inflight_under_rocprof.json"
+# (4) BASELINE configs[4]: batch-32 half-float forward, HBM bytes per forward
+N32=20
+python3 tools/fwd_resident.py 32 f16 2 > /dev/null      # fills the tune cache for the batch-32 f16 plan
+prof ${TAG}_f16_fetch --pmc FETCH_SIZE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > "$OUT/${TAG}_infer32_f16_run.json"
+prof ${TAG}_f16_write --pmc WRITE_SIZE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > /dev/null
+prof ${TAG}_f16_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > /dev/null || echo "MFMA counter pass (f16) failed"
+for pair in stats:bench_kernel_stats tstats:train_kernel_stats fetch:bench_pmc_fetch write:bench_pmc_write mfma:bench_pmc_mfma tmfma:train_pmc_mfma \
+            inflight:bench_inflight_kernel_stats f16_fetch:infer32_f16_pmc_fetch f16_write:infer32_f16_pmc_write f16_mfma:infer32_f16_pmc_mfma; do
+    d=${pair%%:*}; o=${pair##*:}
+    [ -d "$OUT/${TAG}_$d" ] && python3 tools/parse_rocprof.py "$OUT/${TAG}_$d" "$OUT/${TAG}_$o.json" || true
+done
+for pair in stats:bench_kernel_stats tstats:train_kernel_stats inflight:bench_inflight_kernel_stats; do
+    d=${pair%%:*}; o=${pair##*:}
+    f=$(find "$OUT/${TAG}_$d" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_$o.csv"
+done
+python3 - "$OUT" "$TAG" $N32 <<'PY'
+import json, sys
+out, tag, n = sys.argv[1], sys.argv[2], int(sys.argv[3])
+try:
+    f = json.load(open("%s/%s_infer32_f16_pmc_fetch.json" % (out, tag))); w = json.load(open("%s/%s_infer32_f16_pmc_write.json" % (out, tag)))
+    run = json.loads(open("%s/%s_infer32_f16_run.json" % (out, tag)).read().strip().splitlines()[-1])
+    total = run["forwards_total"]
+    # every kernel of the run (layout converters of the one upload included: < 0.1 %), divided by the forwards it ran
+    b = (f["all_kernels_hbm"]["read_bytes_total"] + w["all_kernels_hbm"]["write_bytes_total"]) / total
+    json.dump({"bytes_per_forward": round(b), "read_bytes_per_forward": round(f["all_kernels_hbm"]["read_bytes_total"] / total),
+               "write_bytes_per_forward": round(w["all_kernels_hbm"]["write_bytes_total"] / total), "forwards": total, "run": run,
+               "kernel_source_hash": f.get("kernel_source_hash"),
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around tools/fwd_resident.py 32 f16 %d; read = 2 x FETCH_SIZE" % n},
+              open("%s/%s_infer32_f16_hbm.json" % (out, tag), "w"), indent=1)
+except Exception as e:
+    print("infer32 summary failed:", e)
+PY
 # the raw traces are large: keep the summaries only
-rm -rf "$OUT/${TAG}_stats" "$OUT/${TAG}_tstats" "$OUT/${TAG}_fetch" "$OUT/${TAG}_write"
+for d in stats tstats fetch write mfma tmfma inflight f16_fetch f16_write f16_mfma; do rm -rf "$OUT/${TAG}_$d"; done
 ls -la "$OUT" | grep "${TAG}_"
