@@ -1053,6 +1053,12 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
     return 0;
 }
 
+int fcn_conv2d_group_release(void* d_workspace) {
+    std::lock_guard<std::mutex> lock(g_groups_mu);
+    g_groups.erase(d_workspace);
+    return 0;
+}
+
 int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
     FCN_REQUIRE(g && g->d_probs && g->n > 0 && g->total_tiles > 0, FCN_E_ARG, "fcn_conv2d_fwd_group_f32: unprepared group");
     FCN_REQUIRE(g->cfg >= 0 && g->cfg < kNumCfg, FCN_E_ARG, "fcn_conv2d_fwd_group_f32: bad cfg %d", g->cfg);

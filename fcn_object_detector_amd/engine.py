@@ -186,6 +186,7 @@ class Engine:
         self._staging: Dict[str, DeviceBuffer] = {}
         self._keep: List[object] = []
         self._conv_layer_meta: Dict[str, dict] = {}
+        self._group_workspaces: List[DeviceBuffer] = []      # workspaces of prepared launch groups (released on close)
         self.aux_dev: Dict[str, DeviceBuffer] = {}      # TRAIN: pooling argmax / LRN scale kept for backward
         self.loss_blobs: Dict[str, float] = {}          # loss top -> loss_weight
         self.device_fed: set = set()             # input blobs a producer writes straight into HBM (device scene renderer): never uploaded
@@ -537,6 +538,7 @@ class Engine:
                 byts = sum(it["bytes"] for it in chunk)
                 arr = (L.ConvDesc * len(chunk))(*[it["desc"] for it in chunk])
                 ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(chunk))), zero=False)
+                self._group_workspaces.append(ws)
                 grp = L.ConvGroup()
                 fused = pools[:2] if base == 0 and len(chunk) <= 8 else []
                 parr = (L.PoolDesc * max(len(fused), 1))(*[pt["pool_desc"] for pt in fused])
@@ -1076,6 +1078,14 @@ class Engine:
                 lib.fcn_stream_sync(self.stream)
                 lib.fcn_stream_destroy(self.stream)
                 self.stream = 0
+            # the library's host copies of this engine's prepared groups are keyed by their workspace address: drop them before
+            # the addresses can be handed out again
+            for ws in getattr(self, "_group_workspaces", []):
+                if ws.ptr:
+                    lib.fcn_conv2d_group_release(ws.ptr)
+                    ws.free()
+            self._group_workspaces = []
+            self.ops = []
 
     def __del__(self):
         try:

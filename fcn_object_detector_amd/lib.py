@@ -121,6 +121,7 @@ PROTOTYPES = {
     "fcn_conv2d_group_prepare": (_i, [C.POINTER(ConvDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),
     "fcn_conv2d_group_prepare_fused": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(PoolDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),
     "fcn_conv2d_fwd_group_f32": (_i, [C.POINTER(ConvGroup), _vp]),
+    "fcn_conv2d_group_release": (_i, [_vp]),
     "fcn_maxpool_fwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "fcn_avepool_fwd_f32": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
     "fcn_lrn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
@@ -174,6 +175,7 @@ PROTOTYPES = {
     "fcn_adam_update_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i, _f, _vp]),
 }
 
+HW_QUEUES: dict = {}      # what load() found / did about GPU_MAX_HW_QUEUES
 _lib: Optional[C.CDLL] = None
 _lock = threading.Lock()
 
@@ -196,7 +198,20 @@ def load() -> C.CDLL:
         # (3460 vs 4300 frames/s), the two-stream training step runs 6.60 vs 6.37 ms; with 8 the node pipeline lost a third
         # of its rate as soon as another pipeline's four idle streams existed (2590 vs 3600 frames/s).  16 covers the
         # engines a process of this package keeps alive at once; no measured cost against 8.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        # An embedding process should export GPU_MAX_HW_QUEUES itself; the variable is only filled in
+        # here when nobody has set it and $FCN_SET_HW_QUEUES is not 0 - and that is said once, not done silently.
+        global HW_QUEUES
+        if "GPU_MAX_HW_QUEUES" in os.environ:
+            HW_QUEUES = {"value": os.environ["GPU_MAX_HW_QUEUES"], "set_by": "environment"}
+        elif os.environ.get("FCN_SET_HW_QUEUES", "1") != "0":
+            os.environ["GPU_MAX_HW_QUEUES"] = "16"
+            HW_QUEUES = {"value": "16", "set_by": "fcn_object_detector_amd.lib.load"}
+            if os.environ.get("FCN_QUIET", "0") in ("", "0"):
+                import sys
+                sys.stderr.write("fcn_object_detector_amd: GPU_MAX_HW_QUEUES was unset; set to 16 for this process (export it yourself or "
+                                 "FCN_SET_HW_QUEUES=0 to keep the runtime's default; FCN_QUIET=1 silences this line)\n")
+        else:
+            HW_QUEUES = {"value": None, "set_by": "nobody (FCN_SET_HW_QUEUES=0): the HIP runtime's default of 4 applies"}
         try:
             lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
         except OSError as e:  # pragma: no cover - depends on the box

@@ -270,6 +270,7 @@ class TrainEngine(Engine):
                 cfg = self._tuned_cfg("dgrad:" + rec["name"], arr, n_, gws) if self.autotune else -1
                 L.call("fcn_conv2d_group_prepare", arr, n_, gws.ptr, cfg, C.byref(rec["grp"]))
                 self._keep.extend([arr, gws, rec["grp"]])
+                self._group_workspaces.append(gws)
                 rec["op"].name = "%s [cfg%d %dwg]" % (rec["name"], rec["grp"].cfg, rec["grp"].total_tiles)
 
         def wgrad_item(l: Layer, gtop: Blob):

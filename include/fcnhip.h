@@ -144,6 +144,10 @@ typedef struct fcn_pool_desc {
 } fcn_pool_desc;
 int  fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fcn_pool_desc* h_pools, int npools, void* d_workspace,
                                     int cfg_request, fcn_conv_group* h_out);
+/* The library keeps a host copy of every prepared group, keyed by its d_workspace.  Call this before freeing (or reusing for
+ * something else) a workspace that was handed to a prepare call: the entry is erased, so that a later allocation that happens
+ * to get the same device address can never pick up a stale plan.  Unknown pointers are ignored (returns 0). */
+int  fcn_conv2d_group_release(void* d_workspace);
 
 /* ---- Pooling / LRN / pointwise: Caffe PoolingLayer, LRNLayer, EltwiseLayer ---- */
 /* MAX pool, ceil-mode output size computed by the caller (OH, OW), window clipped to the

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("FCN_QUIET", "1")      # (lib.load() announces on stderr when it fills in GPU_MAX_HW_QUEUES)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 PYCAFFE = os.path.join(ROOT, "fcn_object_detector_amd", "python")

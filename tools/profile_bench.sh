@@ -28,8 +28,8 @@ prof ${TAG}_tstats --stats -- python3 "$ROOT/bench.py" $ONE > "$OUT/${TAG}_train
 prof ${TAG}_fetch --pmc FETCH_SIZE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
 prof ${TAG}_write --pmc WRITE_SIZE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
 # (2) matrix-core counters (SQ block, own pass): busy cycles of the MFMA pipes against the SQ's busy cycles, MFMA op counts
-prof ${TAG}_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null || echo "MFMA counter pass failed (counter names: rocprofv3 -L)"
-prof ${TAG}_tmfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES -- python3 "$ROOT/bench.py" $ONE > /dev/null || echo "MFMA counter pass (train) failed"
+prof ${TAG}_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null || echo "MFMA counter pass failed (counter names: rocprofv3 -L)"
+prof ${TAG}_tmfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/bench.py" $ONE > /dev/null || echo "MFMA counter pass (train) failed"
 # (3) the mode `value` is measured in: four frames in flight
 prof ${TAG}_inflight --stats -- python3 "$ROOT/bench.py" $ARGS --no-train > "$OUT/${TAG}_bench_inflight_under_rocprof.json"
 # (4) BASELINE configs[4]: batch-32 half-float forward, HBM bytes per forward
@@ -37,7 +37,7 @@ N32=20
 python3 tools/fwd_resident.py 32 f16 2 > /dev/null      # fills the tune cache for the batch-32 f16 plan
 prof ${TAG}_f16_fetch --pmc FETCH_SIZE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > "$OUT/${TAG}_infer32_f16_run.json"
 prof ${TAG}_f16_write --pmc WRITE_SIZE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > /dev/null
-prof ${TAG}_f16_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > /dev/null || echo "MFMA counter pass (f16) failed"
+prof ${TAG}_f16_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > /dev/null || echo "MFMA counter pass (f16) failed"
 for pair in stats:bench_kernel_stats tstats:train_kernel_stats fetch:bench_pmc_fetch write:bench_pmc_write mfma:bench_pmc_mfma tmfma:train_pmc_mfma \
             inflight:bench_inflight_kernel_stats f16_fetch:infer32_f16_pmc_fetch f16_write:infer32_f16_pmc_write f16_mfma:infer32_f16_pmc_mfma; do
     d=${pair%%:*}; o=${pair##*:}
