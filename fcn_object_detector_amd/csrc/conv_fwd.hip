@@ -85,7 +85,7 @@ struct ConvP {
     int Cout, kh, kw, pad, stride, OH, OW;
     int y_cstride, y_coffset, y2_cstride, y2_coffset;
     int flags;
-    float in_shift;   // unused by the kernel (kept so the struct mirrors fcn_conv_desc)
+    int lean_chunks;  // > 0: the scalar-addressed loader runs this many chunks (plan_tiles_cfg); 0: the per-lane loader
     int kw_magic;
     int M, K, tiles_m, tiles_n, tile_end;  // tile_end: exclusive prefix end of this problem's tiles in a group launch
     unsigned ow_magic, oh_magic;          // ceil(2^32 / OW), ceil(2^32 / OH): exact for every m < M (validate()); 0: OW / OH == 1
@@ -278,11 +278,6 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // ---- loader state: this lane stages slot (lane % SEGS) of rows STEP*i + RPI*wid + lane / SEGS ------------
     const int lrow = RPI * wid + lane / SEGS;                  // row of instruction 0
     const int lseg = (lane % SEGS) ^ swz<SEGS>(lrow);          // k-segment this lane fetches (same for all its rows)
-    // k position of that segment, kept as (tap, channel) and advanced by BK per chunk without branches
-    int kc = lseg * EPS;
-    int kt = (int)(((unsigned)kc * p.cin_magic24) >> 24);      // kc / Cin (kc < 256)
-    kc -= kt * p.Cin;
-    const int bk_taps = (int)(((unsigned)BKE * p.cin_magic24) >> 24), bk_rem = BKE - bk_taps * p.Cin;      // BKE / Cin
     int a_iy0[IA], a_ix0[IA], a_off[IA];   // window origin and its element offset (32-bit: validated on the host)
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
@@ -297,66 +292,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         a_ix0[i] = ox * p.stride - p.pad;
         a_off[i] = ((img * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.x_cstride;
     }
-    int b_off[IB];   // element offset of this lane's segment in weight row n; negative = row past Cout
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-        const int n = n0 + STEP * i + lrow;
-        b_off[i] = n < p.Cout ? n * p.K + lseg * EPS : -1;
-    }
-    int kb = lseg * EPS;   // this segment's k index (weights are zero past K)
     const int taps = p.kh * p.kw;
-    // the zero page pointer is laundered into VGPRs so that "in bounds ? source : zero page" stays a plain select
-    // (one LDS-DMA instruction per row group) instead of two exec-masked instructions
-    unsigned long long zp_bits = reinterpret_cast<unsigned long long>(p.zero_page);
-    asm volatile("" : "+v"(zp_bits));
-    const float* zero_page = reinterpret_cast<const float*>(zp_bits);
     const int lds_wave_base = RPI * wid * BK;   // float offset of instruction 0's 1 KiB piece inside a ring slot
-
-    int is_kr = 0, is_kq = 0, is_koff = 0;   // state shared by the pieces of one chunk's issue
-    bool is_kok = false, is_kbok = false;
-    float* is_dst = smem;
-    auto issue_pre = [&](const int buf) {
-        is_kr = (kt * p.kw_magic) >> 16;            // kt / kw (magic = ceil(65536 / kw), exact for kt < 8192)
-        is_kq = kt - is_kr * p.kw;
-        is_koff = (is_kr * p.W + is_kq) * p.x_cstride + kc;
-        is_kok = kt < taps;
-        is_kbok = kb < p.K;
-        is_dst = smem + buf * BUF_FLOATS + lds_wave_base;
-    };
-    auto issue_a = [&](const int i) {
-        // bitwise & on purpose: && becomes a divergent branch around the address arithmetic
-        const bool ok = (int)is_kok & (int)((unsigned)(a_iy0[i] + is_kr) < (unsigned)p.H) & (int)((unsigned)(a_ix0[i] + is_kq) < (unsigned)p.W);
-        unsigned long long src = ok ? reinterpret_cast<unsigned long long>(px + (a_off[i] + is_koff)) : reinterpret_cast<unsigned long long>(zero_page);
-        asm volatile("" : "+v"(src));    // one select, one DMA (keeps hipcc from forking the load into two exec-masked copies)
-        __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + STEP * i * BK), 16, 0, 0);
-    };
-    auto issue_b = [&](const int i) {
-        unsigned long long src = ((int)is_kbok & (int)(b_off[i] >= 0)) ? reinterpret_cast<unsigned long long>(pw + b_off[i])
-                                                                       : reinterpret_cast<unsigned long long>(zero_page);
-        asm volatile("" : "+v"(src));
-        __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + (BM + STEP * i) * BK), 16, 0, 0);
-        b_off[i] += b_off[i] >= 0 ? BKE : 0;
-    };
-    auto issue_post = [&]() {
-        kb += BKE;
-        // advance by one chunk: BKE = bk_taps * Cin + bk_rem
-        kc += bk_rem;
-        kt += bk_taps;
-        const bool wrap = kc >= p.Cin;
-        kc -= wrap ? p.Cin : 0;
-        kt += wrap ? 1 : 0;
-    };
-    // Issue the LDS-DMA of one chunk (INST x global_load_lds_dwordx4 per wave) into ring slot `buf`.  Every lane
-    // always loads: lanes outside the image / tile / K read the zero page, so padding arrives as zeros and the
-    // number of outstanding instructions per chunk is a constant the vmcnt waits can count on.
-    auto issue_chunk = [&](const int buf) {
-        issue_pre(buf);
-#pragma unroll
-        for (int i = 0; i < IA; ++i) issue_a(i);
-#pragma unroll
-        for (int i = 0; i < IB; ++i) issue_b(i);
-        issue_post();
-    };
+    const bool lean = p.lean_chunks > 0;        // uniform: which of the two loaders below feeds this problem
+    const int nchunks = lean ? p.lean_chunks : (p.K + BKE - 1) / BKE;
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -366,7 +305,6 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (p.K + BKE - 1) / BKE;
     // Fragment reads are inline asm: hipcc cannot tell an LDS-DMA in flight from the ds_read of a slot that landed
     // long ago and would drain vmcnt to 0 in front of every compiler-generated LDS read of this array.
     // Addressing: row (lane & 31) of a 32-row tile, k-segment 2*step + (lane >> 5), de-swizzled per lane.
@@ -469,6 +407,20 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // that tiles sharing an operand hit in L2 instead of missing together (no gain; the bookkeeping of the rotation alone,
     // a dozen VALU instructions per chunk, cost 4-6 %: with one wave per SIMD the loader's VALU work does NOT hide behind the
     // MFMAs - 4a_A runs 8.4 us with and 6.8 us without its MFMAs, sweep_nomfma.log).
+    // The ring pipeline, parameterised by the loader that feeds it (its four pieces): prologue issue, one counted wait + one
+    // barrier per chunk, MFMAs with the next chunk's fragment reads and the refill's pieces in their shadow.
+    auto pipeline = [&](auto& issue_pre, auto& issue_a, auto& issue_b, auto& issue_post) {
+    // Issue the LDS-DMA of one chunk (INST x 1 KiB wave-instructions) into ring slot `buf`.  Every lane always loads - lanes
+    // outside the image / tile / K get zeros - so the number of outstanding instructions per chunk is a constant the vmcnt
+    // waits can count on.
+    auto issue_chunk = [&](const int buf) {
+        issue_pre(buf);
+#pragma unroll
+        for (int i = 0; i < IA; ++i) issue_a(i);
+#pragma unroll
+        for (int i = 0; i < IB; ++i) issue_b(i);
+        issue_post();
+    };
     int buf_issue = 0;                 // ring slot of the next chunk to issue
     auto next = [](int b) { return b + 1 == NBUF ? 0 : b + 1; };
     int buf_cur = 0;                   // ring slot of chunk c
@@ -613,6 +565,122 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 
+    }
+
+    };      // pipeline
+
+    if (lean) {
+        // ---- scalar-addressed loader -----------------------------------------------------------------------------------
+        // v_mfma_f32_32x32x2_f32 runs on the vector ALUs (64 FLOP/clk/SIMD IS the f32 vector rate): the loader's address
+        // arithmetic does not hide behind a wave's own MFMAs, it ADDS to them - with 32x32 K-split tiles (4 MFMAs = 256 cycles
+        // per wave and chunk) the ~45 VALU instructions of the per-lane loader below cost as much again, which is why a launch
+        // without its MFMAs is barely faster than with them (sweep_nomfma.log) and why two waves per SIMD do not help.  Here a
+        // chunk never straddles a filter tap (1x1 filters, or Cin padded to whole chunks per tap: the pad lanes load zeros), so
+        // the chunk's tap, channel origin and both operand offsets are WAVE-UNIFORM: they live in SGPRs and advance on the
+        // scalar unit.  Per lane there remain one select per piece (+ the halo test of padded convolutions).  Lanes outside
+        // the image / tile / K carry an out-of-range buffer offset: `buffer_load ... lds` writes zeros for them
+        // (tools/probes/bufload_lds_probe.hip), so no zero page and no 64-bit address select either.
+        constexpr int ESZ = (int)sizeof(T);
+        constexpr int OOB = (int)0x80000000u;      // >= num_records of every buffer (validate(): operands stay below 2 GiB)
+        const int lane_c = lseg * EPS;             // channel of this lane's segment inside a chunk
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<T*>(px), 0, (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * ESZ), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pw), 0, p.Cout * p.K * ESZ, 0x00020000);
+        int a_vo[IA], b_vo[IB];
+#pragma unroll
+        for (int i = 0; i < IA; ++i) a_vo[i] = (a_off[i] + lane_c) * ESZ;
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int n = n0 + STEP * i + lrow;
+            b_vo[i] = n < p.Cout ? (n * p.K + lane_c) * ESZ : OOB;
+        }
+        int s_kr = 0, s_kq = 0, s_kc = 0, s_koff = 0, s_kb = 0, s_left = nchunks;      // wave-uniform K position of the next chunk
+        bool cvalid = false;
+        float* dst = smem;
+        auto lpre = [&](const int buf) {
+            const int thr = s_left > 0 ? p.Cin - s_kc : 0;      // channels of this tap the chunk still covers (0: past the end)
+            cvalid = lane_c < thr;
+            dst = smem + buf * BUF_FLOATS + lds_wave_base;
+        };
+        auto la = [&](const int i) {
+            // (rows past M carry a hugely negative origin and fail the first test; for unpadded convolutions both tests hold
+            // for every real row - selecting a cheaper test per problem cost more select instructions than the test itself)
+            const bool ok = (int)cvalid & (int)((unsigned)(a_iy0[i] + s_kr) < (unsigned)p.H) & (int)((unsigned)(a_ix0[i] + s_kq) < (unsigned)p.W);
+            int vo = ok ? a_vo[i] + s_koff : OOB;
+            asm volatile("" : "+v"(vo));      // one select, one DMA
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dst + STEP * i * BK), 16, vo, 0, 0, 0);
+        };
+        auto lb = [&](const int i) {
+            int vo = cvalid ? b_vo[i] + s_kb : OOB;      // (OOB + a row offset stays out of range: both below 2^31)
+            asm volatile("" : "+v"(vo));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + (BM + STEP * i) * BK), 16, vo, 0, 0, 0);
+        };
+        auto lpost = [&]() {      // scalar unit only
+            --s_left;
+            const bool nt = s_kc + BKE >= p.Cin;                  // the next chunk starts the next tap
+            s_kb += (nt ? p.Cin - s_kc : BKE) * ESZ;              // weights are [tap][Cin]: the tap's end, or one chunk on
+            const int kq1 = s_kq + (nt ? 1 : 0);
+            const bool wq = kq1 == p.kw;
+            s_kq = wq ? 0 : kq1;
+            s_kr += wq ? 1 : 0;
+            s_kc = nt ? 0 : s_kc + BKE;
+            s_koff = nt ? (s_kr * p.W + s_kq) * p.x_cstride * ESZ : s_koff + BKE * ESZ;
+        };
+        pipeline(lpre, la, lb, lpost);
+    } else {
+        // ---- per-lane loader: any geometry (chunks may straddle taps: Cin = 3 + 1 pad of conv1, 16, ...) -----------------
+        // k position of this lane's segment, kept as (tap, channel) and advanced by BK per chunk without branches
+        int kc = lseg * EPS;
+        int kt = (int)(((unsigned)kc * p.cin_magic24) >> 24);      // kc / Cin (kc < 256)
+        kc -= kt * p.Cin;
+        const int bk_taps = (int)(((unsigned)BKE * p.cin_magic24) >> 24), bk_rem = BKE - bk_taps * p.Cin;      // BKE / Cin
+        int b_off[IB];   // element offset of this lane's segment in weight row n; negative = row past Cout
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int n = n0 + STEP * i + lrow;
+            b_off[i] = n < p.Cout ? n * p.K + lseg * EPS : -1;
+        }
+        int kb = lseg * EPS;   // this segment's k index (weights are zero past K)
+        // the zero page pointer is laundered into VGPRs so that "in bounds ? source : zero page" stays a plain select
+        // (one LDS-DMA instruction per row group) instead of two exec-masked instructions
+        unsigned long long zp_bits = reinterpret_cast<unsigned long long>(p.zero_page);
+        asm volatile("" : "+v"(zp_bits));
+        const float* zero_page = reinterpret_cast<const float*>(zp_bits);
+        int is_kr = 0, is_kq = 0, is_koff = 0;   // state shared by the pieces of one chunk's issue
+        bool is_kok = false, is_kbok = false;
+        float* is_dst = smem;
+        auto issue_pre = [&](const int buf) {
+            is_kr = (kt * p.kw_magic) >> 16;            // kt / kw (magic = ceil(65536 / kw), exact for kt < 8192)
+            is_kq = kt - is_kr * p.kw;
+            is_koff = (is_kr * p.W + is_kq) * p.x_cstride + kc;
+            is_kok = kt < taps;
+            is_kbok = kb < p.K;
+            is_dst = smem + buf * BUF_FLOATS + lds_wave_base;
+        };
+        auto issue_a = [&](const int i) {
+            // bitwise & on purpose: && becomes a divergent branch around the address arithmetic
+            const bool ok = (int)is_kok & (int)((unsigned)(a_iy0[i] + is_kr) < (unsigned)p.H) & (int)((unsigned)(a_ix0[i] + is_kq) < (unsigned)p.W);
+            unsigned long long src = ok ? reinterpret_cast<unsigned long long>(px + (a_off[i] + is_koff)) : reinterpret_cast<unsigned long long>(zero_page);
+            asm volatile("" : "+v"(src));    // one select, one DMA (keeps hipcc from forking the load into two exec-masked copies)
+            __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + STEP * i * BK), 16, 0, 0);
+        };
+        auto issue_b = [&](const int i) {
+            unsigned long long src = ((int)is_kbok & (int)(b_off[i] >= 0)) ? reinterpret_cast<unsigned long long>(pw + b_off[i])
+                                                                           : reinterpret_cast<unsigned long long>(zero_page);
+            asm volatile("" : "+v"(src));
+            __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + (BM + STEP * i) * BK), 16, 0, 0);
+            b_off[i] += b_off[i] >= 0 ? BKE : 0;
+        };
+        auto issue_post = [&]() {
+            kb += BKE;
+            // advance by one chunk: BKE = bk_taps * Cin + bk_rem
+            kc += bk_rem;
+            kt += bk_taps;
+            const bool wrap = kc >= p.Cin;
+            kc -= wrap ? p.Cin : 0;
+            kt += wrap ? 1 : 0;
+        };
+        pipeline(issue_pre, issue_a, issue_b, issue_post);
     }
 
     // ---- epilogue: every wave parks its accumulators in LDS, then ALL threads of the workgroup reduce the K-split
@@ -865,7 +933,7 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.x_cstride = d.x_cstride;
     p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw; p.pad = d.pad; p.stride = d.stride; p.OH = d.OH; p.OW = d.OW;
     p.y_cstride = d.y_cstride; p.y_coffset = d.y_coffset; p.y2_cstride = d.y2_cstride; p.y2_coffset = d.y2_coffset;
-    p.flags = d.flags; p.in_shift = 0.f;
+    p.flags = d.flags; p.lean_chunks = 0;
     p.M = d.N * d.OH * d.OW;
     p.K = d.kh * d.kw * d.Cin;
     p.tiles_m = p.tiles_n = p.tile_end = 0;
@@ -911,6 +979,7 @@ int choose_cfg(const ConvP* ps, int n) {
 
 int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
     const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+    static const bool lean_ok = !(getenv("FCN_CONV_LEAN") && atoi(getenv("FCN_CONV_LEAN")) == 0);      // (experiments: per-lane loader only)
     int total = 0;
     for (int i = 0; i < n; ++i) {
         ps[i].tiles_m = cdiv(ps[i].M, bm);
@@ -920,6 +989,16 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
         ps[i].tiles_n_magic = ps[i].tiles_n > 1 ? (unsigned)(((1ull << 32) + ps[i].tiles_n - 1) / ps[i].tiles_n) : 0u;
         total += ps[i].tiles_m * ps[i].tiles_n;
         ps[i].tile_end = total;
+        // Which loader feeds this problem under this configuration (conv_body): the scalar-addressed one needs chunks that
+        // do not straddle filter taps - 1x1 filters, or every tap's Cin padded to whole chunks (the pad lanes load zeros and
+        // cost MFMA work: accepted up to 1.5x) - and operands below 2 GiB (32-bit buffer offsets).
+        const int esz = (ps[i].flags & FCN_CONV_F16) ? 2 : 4;
+        const int bke = kCfgs[cfg].bk * 4 / esz;
+        const int taps = ps[i].kh * ps[i].kw, cpt = cdiv(ps[i].Cin, bke);
+        const long long xb = (((long long)ps[i].N * ps[i].H * ps[i].W - 1) * ps[i].x_cstride + ps[i].Cin) * esz;
+        const long long wb = (long long)ps[i].Cout * ps[i].K * esz;
+        const bool lean = lean_ok && xb < (1ll << 31) && wb < (1ll << 31) && (taps == 1 || 2ll * cpt * bke <= 3ll * ps[i].Cin);
+        ps[i].lean_chunks = lean ? taps * cpt : 0;
     }
     return total;
 }

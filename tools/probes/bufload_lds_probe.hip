@@ -1,0 +1,40 @@
+// GPU diagnostic: does an out-of-range lane of `buffer_load_dwordx4 ... lds` (raw buffer, stride 0) WRITE ZEROS into LDS, or
+// leave the old LDS bytes?  (the convolution loader wants zero-fill for halo / tail lanes without a per-lane address select)
+//   hipcc --offload-arch=gfx950 -O3 tools/probes/bufload_lds_probe.hip -o tools/probes/bufload_lds_probe.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef void __attribute__((address_space(3))) * lds_ptr;
+
+__global__ __launch_bounds__(64) void probe(const float* src, int src_bytes, float* out) {
+    __shared__ __attribute__((aligned(16))) float smem[256];
+    for (int i = threadIdx.x; i < 256; i += 64) smem[i] = -7.0f;      // stale pattern
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0 /* stride */, src_bytes /* num_records */, 0x00020000);
+    // lanes 0..31 in range (16 B each), lanes 32..63 far out of range
+    const int voff = threadIdx.x < 32 ? threadIdx.x * 16 : 0x40000000 + threadIdx.x * 16;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)smem, 16, voff, 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 64) out[i] = smem[i];
+}
+
+int main() {
+    std::vector<float> h(128);
+    for (int i = 0; i < 128; ++i) h[i] = 1.0f + i;
+    float *d, *o;
+    hipMalloc(&d, 512);
+    hipMalloc(&o, 1024);
+    hipMemcpy(d, h.data(), 512, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, d, 512, o);
+    std::vector<float> r(256);
+    hipMemcpy(r.data(), o, 1024, hipMemcpyDeviceToHost);
+    int ok_in = 0, zero_out = 0, stale_out = 0;
+    for (int i = 0; i < 128; ++i) ok_in += r[i] == 1.0f + i;
+    for (int i = 128; i < 256; ++i) { zero_out += r[i] == 0.0f; stale_out += r[i] == -7.0f; }
+    printf("in-range floats correct: %d / 128;  out-of-range lanes: %d zeros, %d stale (of 128)\n", ok_in, zero_out, stale_out);
+    printf("first out-of-range values: %g %g %g %g\n", r[128], r[129], r[130], r[131]);
+    return 0;
+}
