@@ -580,6 +580,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         // scalar unit.  Per lane there remain one select per piece (+ the halo test of padded convolutions).  Lanes outside
         // the image / tile / K carry an out-of-range buffer offset: `buffer_load ... lds` writes zeros for them
         // (tools/probes/bufload_lds_probe.hip), so no zero page and no 64-bit address select either.
+        // (Tried on top of this in round 2: treating a whole filter ROW of kw taps as one contiguous run when the input's pixels
+        // are packed - conv1 as 7 x 28 floats, a 5x5 on 16 channels as 5 x 80 - so that small-Cin layers take this loader too.
+        // The two extra VALU instructions per chunk it needs cost every launch 3-6 % and conv1 gained nothing:
+        // gpurun_out/r2/sweep_merged_ab.log, same box, alternating builds.)
         constexpr int ESZ = (int)sizeof(T);
         constexpr int OOB = (int)0x80000000u;      // >= num_records of every buffer (validate(): operands stay below 2 GiB)
         const int lane_c = lseg * EPS;             // channel of this lane's segment inside a chunk
