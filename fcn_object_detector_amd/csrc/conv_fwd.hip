@@ -583,7 +583,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         // (Tried on top of this in round 2: treating a whole filter ROW of kw taps as one contiguous run when the input's pixels
         // are packed - conv1 as 7 x 28 floats, a 5x5 on 16 channels as 5 x 80 - so that small-Cin layers take this loader too.
         // The two extra VALU instructions per chunk it needs cost every launch 3-6 % and conv1 gained nothing:
-        // gpurun_out/r2/sweep_merged_ab.log, same box, alternating builds.)
+        // gpurun_out/r2/sweep_merged_ab.log, same box, alternating builds.  Also tried: the chunk offsets in the instruction's
+        // scalar-offset field instead of a per-lane add (neutral, sweep_lean3_ab.log); plus a per-row bit mask of the taps
+        // inside the image and a scalar-selected tail predicate - 7 instead of 11 VALU instructions per chunk in the steady
+        // state, but the mask's set-up loops and the ballot lengthen the prologue: 4a_A 6.2 -> 7.1 us, sweep_lean2_ab.log.)
         constexpr int ESZ = (int)sizeof(T);
         constexpr int OOB = (int)0x80000000u;      // >= num_records of every buffer (validate(): operands stay below 2 GiB)
         const int lane_c = lseg * EPS;             // channel of this lane's segment inside a chunk
