@@ -18,6 +18,8 @@
 //   * everything else is HBM-bound NHWC pointwise work, 16 bytes per lane where the shapes allow.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 using namespace fcn;
@@ -104,9 +106,6 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* sm
     const int kr = (ktap * p.kw_magic) >> 16;
     const int kq = ktap - kr * p.kw;
     const bool k_ok = kidx < p.K;
-    unsigned long long zp_bits = reinterpret_cast<unsigned long long>(p.zero_page);
-    asm volatile("" : "+v"(zp_bits));
-    const float* zero_page = reinterpret_cast<const float*>(zp_bits);
 
     const int chunk0 = split * p.chunks_per_split;
     const int total_chunks = (p.M + WG_BP - 1) / WG_BP;
@@ -116,16 +115,29 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* sm
     const int chunk_end = chunk0 + nchunks;
     const int ohw = p.OH * p.OW;
 
+    // Both operands are fetched with `buffer_load ... lds`: 32-bit offsets, and lanes that must read zeros (rows past M,
+    // columns past Cout, taps outside the image, chunks past this split's range) simply carry an out-of-range offset - the
+    // hardware writes zeros for them (tools/probes/bufload_lds_probe.hip: the scalar offset is part of the range check).
+    // That removes the zero page, the 64-bit address arithmetic and two selects from every piece: v_mfma_f32_32x32x2_f32
+    // shares the vector ALU with this arithmetic, so it does not hide behind the MFMAs, it adds to them.
+    constexpr int OOB = (int)0x80000000u;      // >= num_records (wgrad_validate: both operands stay below 2 GiB)
+#if defined(__HIP_DEVICE_COMPILE__)      // (hipcc's host pass instantiates this body too and has no buffer-resource type: the loader is device-pass text only)
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.dy), 0, (int)((((long long)p.M - 1) * p.dy_cstride + (p.Cout + 3) / 4 * 4) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.x), 0, (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * 4), 0x00020000);
+    int n_vo[IN_];      // dY: byte offset of (row of chunk 0, column) - the chunk's row offset travels in the scalar offset
+#pragma unroll
+    for (int i = 0; i < IN_; ++i) n_vo[i] = dy_col_ok ? ((RN * (NW * i + wid) + n_row) * p.dy_cstride + dy_col) * 4 : OOB;
     int issue_chunk_idx = chunk0;
+    int s_dy = 0;       // scalar offset of the chunk's first row in dY (out of range for chunks past this split's end)
     float* is_dst = smem;
-    auto issue_pre = [&](const int buf) { is_dst = smem + buf * BUF_FLOATS; };
+    auto issue_pre = [&](const int buf) {
+        is_dst = smem + buf * BUF_FLOATS;
+        s_dy = issue_chunk_idx < chunk_end ? issue_chunk_idx * WG_BP * p.dy_cstride * 4 : 0x7F000000;      // rows >= M are past num_records by themselves
+    };
     auto issue_n = [&](const int i) {          // dY[m][n0 + 4*slot ..]
-        const int row = RN * (NW * i + wid) + n_row;
-        const int m = issue_chunk_idx * WG_BP + row;
-        const bool ok = (int)(m < p.M) & (int)(issue_chunk_idx < chunk_end) & (int)dy_col_ok;
-        unsigned long long src = reinterpret_cast<unsigned long long>(ok ? p.dy + (size_t)m * p.dy_cstride + dy_col : zero_page);
-        asm volatile("" : "+v"(src));
-        __builtin_amdgcn_global_load_lds((gvoid_cptr)src, (lds_ptr)(is_dst + RN * (NW * i + wid) * BN), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_ptr)(is_dst + RN * (NW * i + wid) * BN), 16, n_vo[i], s_dy, 0, 0);
     };
     auto issue_k = [&](const int i) {          // im2col row m, k segment
         const int row = RK * (NW * i + wid) + k_row;
@@ -139,11 +151,18 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* sm
         const int iy = oy * p.stride - p.pad + kr;
         const int ix = ox * p.stride - p.pad + kq;
         const bool ok = (int)m_ok & (int)k_ok & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
-        unsigned long long srcx = reinterpret_cast<unsigned long long>(
-            ok ? p.x + ((size_t)(img * p.H + iy) * p.W + ix) * p.x_cstride + kch : zero_page);
-        asm volatile("" : "+v"(srcx));
-        __builtin_amdgcn_global_load_lds((gvoid_cptr)srcx, (lds_ptr)(is_dst + WG_BP * BN + RK * (NW * i + wid) * BK), 16, 0, 0);
+        int vo = ok ? (((img * p.H + iy) * p.W + ix) * p.x_cstride + kch) * 4 : OOB;
+        asm volatile("" : "+v"(vo));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rxx, (lds_ptr)(is_dst + WG_BP * BN + RK * (NW * i + wid) * BK), 16, vo, 0, 0, 0);
     };
+#else
+    int issue_chunk_idx = chunk0;
+    auto issue_pre = [&](const int) {};
+    auto issue_n = [&](const int) {};
+    auto issue_k = [&](const int) {};
+    (void)OOB; (void)dy_col_ok; (void)k_ok; (void)kr; (void)kq; (void)kch; (void)ohw; (void)chunk_end; (void)n_row; (void)k_row;
+    (void)NW; (void)RN; (void)RK; (void)issue_chunk_idx;
+#endif
     auto issue_chunk = [&](const int buf) {
         issue_pre(buf);
 #pragma unroll
@@ -180,24 +199,49 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* sm
     // fragments of a whole chunk (16 MFMA steps of 2 pixels), read with inline asm: hipcc cannot tell an LDS-DMA in
     // flight from a slot that landed long ago and would drain vmcnt in front of compiler-generated LDS reads
     float av[1][16][TN], bv[1][16][TK];
-    auto read_step = [&](const int par, const int st, const unsigned slot) {
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-            asm volatile("ds_read_b32 %0, %1" : "=v"(av[par][st][i]) : "v"(a_addr + slot + 4u * (2 * st * BN + 32 * i)));
-#pragma unroll
-        for (int j = 0; j < TK; ++j)
-            asm volatile("ds_read_b32 %0, %1" : "=v"(bv[par][st][j]) : "v"(b_addr + slot + 4u * (2 * st * BK + 32 * j)));
+    // (the per-step displacement goes into the instruction's offset field: as a computed address every one of the chunk's 32
+    // reads cost a v_add, and v_mfma_f32_32x32x2_f32 shares the vector ALU with them - they do not hide behind the MFMAs)
+    auto ds_read32 = [](float& dst, unsigned addr, auto off) {
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value));
     };
-    auto landed = [&](const int par) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    auto read_all = [&](const unsigned slot) {
+        const unsigned a0 = a_addr + slot, b0 = b_addr + slot;
+        auto step = [&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;
+            if constexpr (TN >= 1) ds_read32(av[0][st][0], a0, std::integral_constant<int, 4 * (2 * st * BN)>{});
+            if constexpr (TN >= 2) ds_read32(av[0][st][TN >= 2 ? 1 : 0], a0, std::integral_constant<int, 4 * (2 * st * BN + 32)>{});
+            if constexpr (TK >= 1) ds_read32(bv[0][st][0], b0, std::integral_constant<int, 4 * (2 * st * BK)>{});
+            if constexpr (TK >= 2) ds_read32(bv[0][st][TK >= 2 ? 1 : 0], b0, std::integral_constant<int, 4 * (2 * st * BK + 32)>{});
+        };
+        step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{}); step(std::integral_constant<int, 8>{});
+        step(std::integral_constant<int, 9>{}); step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+        step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{}); step(std::integral_constant<int, 14>{});
+        step(std::integral_constant<int, 15>{});
+    };
+    static_assert(TN <= 2 && TK <= 2 && 4 * (30 * (BN > BK ? BN : BK) + 32) < 65536, "fragment reads are written out for at most 2x2 MFMA tiles per wave");
+    // wait until at most `left` of the reads issued so far are outstanding (LDS operations return in order), then pin the
+    // fragment registers of steps [s0, s1) so that nothing is scheduled across the wait
+    auto landed = [&](auto left_c, const int s0, const int s1) {
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(left_c)::value) : "memory");
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
+        for (int st = s0; st < s1; ++st) {
 #pragma unroll
-            for (int i = 0; i < TN; ++i) asm volatile("" : "+v"(av[par][st][i]));
+            for (int i = 0; i < TN; ++i) asm volatile("" : "+v"(av[0][st][i]));
 #pragma unroll
-            for (int j = 0; j < TK; ++j) asm volatile("" : "+v"(bv[par][st][j]));
+            for (int j = 0; j < TK; ++j) asm volatile("" : "+v"(bv[0][st][j]));
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_steps = [&](const int s0, const int s1) {
+#pragma unroll
+        for (int st = s0; st < s1; ++st)
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][st][i], bv[0][st][j], acc[i][j], 0, 0, 0);
     };
 
     {
@@ -210,16 +254,15 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* sm
             issue_chunk(buf_issue);
             buf_issue = next(buf_issue);
             const unsigned slot = (unsigned)buf_cur * (BUF_FLOATS * 4);
-#pragma unroll
-            for (int st = 0; st < 16; ++st) read_step(0, st, slot);
-            landed(0);
-#pragma unroll
-            for (int st = 0; st < 16; ++st)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TK; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][st][i], bv[0][st][j], acc[i][j], 0, 0, 0);
+            // all 16 steps' fragments are requested at once; the MFMAs of the first half start as soon as ITS reads are back
+            // (lgkmcnt counts down in order), the second half's latency hides behind them
+            read_all(slot);
+            // (lgkmcnt is a 4-bit counter: the tail that may stay outstanding is the largest whole number of steps within 15 reads)
+            constexpr int kTailSteps = 15 / (TN + TK), kSplit = 16 - kTailSteps, kTailReads = kTailSteps * (TN + TK);
+            landed(std::integral_constant<int, kTailReads>{}, 0, kSplit);
+            mfma_steps(0, kSplit);
+            landed(std::integral_constant<int, 0>{}, kSplit, 16);
+            mfma_steps(kSplit, 16);
             if (do_bias) {
                 float t = 0.f;
 #pragma unroll
@@ -800,6 +843,8 @@ static int wgrad_validate(const fcn_conv_desc* d) {
     FCN_REQUIRE((long long)d->N * d->OH * d->OW < (1ll << 31) && (long long)d->N * d->H * d->W * d->x_cstride < (1ll << 31), FCN_E_UNSUPPORTED,
                 "wgrad: tensor too large");
     FCN_REQUIRE(d->y_cstride >= d->y_coffset + d->Cout, FCN_E_ARG, "wgrad: gradient slice exceeds its channel stride");
+    FCN_REQUIRE((long long)d->N * d->OH * d->OW * d->y_cstride * 4 < (1ll << 31) && (long long)d->N * d->H * d->W * d->x_cstride * 4 < (1ll << 31),
+                FCN_E_UNSUPPORTED, "wgrad: x and dY must each stay below 2 GiB (32-bit buffer offsets): split the batch");
     return 0;
 }
 

@@ -8,6 +8,19 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef void __attribute__((address_space(3))) * lds_ptr;
 
+// second question: is the instruction's SCALAR offset part of the range check?  (lanes whose voffset is in range but whose
+// voffset + soffset is not: zeros = yes, data from beyond num_records = no)
+__global__ __launch_bounds__(64) void probe_soffset(const float* src, int src_bytes, int soff, float* out) {
+    __shared__ __attribute__((aligned(16))) float smem[256];
+    for (int i = threadIdx.x; i < 256; i += 64) smem[i] = -7.0f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)smem, 16, (int)threadIdx.x * 16, soff, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 64) out[i] = smem[i];
+}
+
 __global__ __launch_bounds__(64) void probe(const float* src, int src_bytes, float* out) {
     __shared__ __attribute__((aligned(16))) float smem[256];
     for (int i = threadIdx.x; i < 256; i += 64) smem[i] = -7.0f;      // stale pattern
@@ -36,5 +49,18 @@ int main() {
     for (int i = 128; i < 256; ++i) { zero_out += r[i] == 0.0f; stale_out += r[i] == -7.0f; }
     printf("in-range floats correct: %d / 128;  out-of-range lanes: %d zeros, %d stale (of 128)\n", ok_in, zero_out, stale_out);
     printf("first out-of-range values: %g %g %g %g\n", r[128], r[129], r[130], r[131]);
+    // buffer of 2048 bytes allocated, descriptor says 1024 bytes; voffset = lane * 16 (0..1008, all in range), soffset = 512:
+    // lanes 32..63 address bytes 1024..1535 (inside the allocation, beyond num_records)
+    std::vector<float> h2(512);
+    for (int i = 0; i < 512; ++i) h2[i] = 100.0f + i;
+    float* d2;
+    hipMalloc(&d2, 2048);
+    hipMemcpy(d2, h2.data(), 2048, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(probe_soffset, dim3(1), dim3(64), 0, 0, d2, 1024, 512, o);
+    hipMemcpy(r.data(), o, 1024, hipMemcpyDeviceToHost);
+    int in_ok = 0, z = 0, beyond = 0;
+    for (int i = 0; i < 128; ++i) in_ok += r[i] == 100.0f + 128 + i;
+    for (int i = 128; i < 256; ++i) { z += r[i] == 0.0f; beyond += r[i] == 100.0f + 128 + i; }
+    printf("soffset test: lanes whose sum stays in range correct: %d / 128; lanes pushed out of range by soffset: %d zeros, %d read beyond num_records (of 128)\n", in_ok, z, beyond);
     return 0;
 }
