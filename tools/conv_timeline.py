@@ -104,9 +104,14 @@ def main():
             print("  cfg %d  %d workgroups (%d stamped)  event %.2f us%s  span %.2f us  shader clock %.2f GHz  wg per XCC %s" % (
                 cfg, tiles, int(ok.sum()), us, " (cold)" if cold else "", t[:, -1].max(), float(np.median(clk)),
                 np.bincount(xcc, minlength=8).tolist()))
+            have = [i for i in range(len(NAMES)) if (real[ok, i] > 0).all()]      # (split-role configs: thread 0 is a multiplier wave and never
+            prev_i = 0                                                              #  executes the loader's stamps; short K loops lack iter1..3)
             for i, nm in enumerate(NAMES):
+                if i not in have:
+                    continue
                 col = t[:, i]
-                prev = t[:, i - 1] if i else t[:, 0]
+                prev = t[:, prev_i]
+                prev_i = i
                 print("    %-7s min %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f   | since entry p50 %6.2f max %6.2f   | step p50 %5.2f" % (
                     nm, col.min(), np.median(col), np.percentile(col, 90), col.max(), np.median(col - t[:, 0]), (col - t[:, 0]).max(),
                     np.median(col - prev)))
