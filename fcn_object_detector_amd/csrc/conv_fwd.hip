@@ -348,6 +348,21 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             if (j == 1) ds_read(bf[par][fst][WTN > 1 ? 1 : 0], fb[st] + slot_bytes, std::integral_constant<int, 32 * BK * 4>{});
         }
     };
+    // the same with the ring slot as a compile-time constant: slot and tile displacement ride in the instruction's 16-bit
+    // offset field, no address arithmetic at all (the f32 MFMA shares the vector ALU with every v_add a wave issues)
+    auto read_step_c = [&](const int par, const int fst, const int st, auto slot_c) {
+        constexpr int SB = decltype(slot_c)::value * BUF_FLOATS * 4;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) {
+            if (i == 0) ds_read(af[par][fst][0], fa[st], std::integral_constant<int, SB>{});
+            if (i == 1) ds_read(af[par][fst][WTM > 1 ? 1 : 0], fa[st], std::integral_constant<int, SB + 32 * BK * 4>{});
+        }
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+            if (j == 0) ds_read(bf[par][fst][0], fb[st], std::integral_constant<int, SB>{});
+            if (j == 1) ds_read(bf[par][fst][WTN > 1 ? 1 : 0], fb[st], std::integral_constant<int, SB + 32 * BK * 4>{});
+        }
+    };
     auto read_frags = [&](const int par, const int buf) {
         const unsigned slot_bytes = (unsigned)buf * (BUF_FLOATS * 4);
 #pragma unroll
@@ -452,26 +467,47 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             asm volatile("" ::: "memory");
             FCN_STAMP(2);      // first chunk usable
             read_frags(0, 0);
-            for (int c0 = 0; c0 < nchunks; c0 += 2) {
+            // unrolled so that both the fragment parity and the ring slot are compile-time constants (when the ring fits the
+            // 16-bit offset field of ds_read; otherwise by 2 and the slot offset is added at run time)
+            constexpr bool IMM = (NBUF + 1) * BUF_FLOATS * 4 < 65536;
+            constexpr int U = !IMM ? 2 : (NBUF % 2 == 0 ? NBUF : 2 * NBUF);
+            auto iteration = [&](auto u_c) {
+                constexpr int u = decltype(u_c)::value;
+                __builtin_amdgcn_s_barrier();      // chunk c + 1 is in LDS
+                asm volatile("" ::: "memory");
+                frags_landed(u & 1, 0, KS);
+                const unsigned nslot = (unsigned)next(buf_cur) * (BUF_FLOATS * 4);
+                constexpr int NG = KS * MPS;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {      // unrolled by 2: the fragment parity is a compile-time constant
-                    if (c0 + u < nchunks) {
-                        __builtin_amdgcn_s_barrier();      // chunk c + 1 is in LDS
-                        asm volatile("" ::: "memory");
-                        frags_landed(u & 1, 0, KS);
-                        const unsigned nslot = (unsigned)next(buf_cur) * (BUF_FLOATS * 4);
-                        constexpr int NG = KS * MPS;
-#pragma unroll
-                        for (int g = 0; g < NG; ++g) {
-                            mfma_group(u & 1, g / MPS, g % MPS);
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (g < KS) read_step((u + 1) & 1, g, g, nslot);      // the fragments of chunk c + 1, in the MFMAs' shadow
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        static_assert(KS <= KS * MPS, "one fragment read per MFMA group");
-                        buf_cur = next(buf_cur);
+                for (int g = 0; g < NG; ++g) {
+                    mfma_group(u & 1, g / MPS, g % MPS);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g < KS) {      // the fragments of chunk c + 1, in the MFMAs' shadow
+                        if constexpr (IMM) read_step_c((u + 1) & 1, g, g, std::integral_constant<int, (u + 1) % NBUF>{});
+                        else read_step((u + 1) & 1, g, g, nslot);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                buf_cur = next(buf_cur);
+            };
+            for (int c0 = 0; c0 < nchunks; c0 += U) {      // (c0 is a multiple of the ring depth: chunk c0 + u sits in slot u % NBUF)
+                if (c0 + 0 < nchunks) iteration(std::integral_constant<int, 0>{});
+                if (c0 + 1 < nchunks) iteration(std::integral_constant<int, 1>{});
+                if constexpr (U > 2) {
+                    if (c0 + 2 < nchunks) iteration(std::integral_constant<int, 2>{});
+                    if (c0 + 3 < nchunks) iteration(std::integral_constant<int, 3>{});
+                }
+                if constexpr (U > 4) {
+                    if (c0 + 4 < nchunks) iteration(std::integral_constant<int, 4>{});
+                    if (c0 + 5 < nchunks) iteration(std::integral_constant<int, 5>{});
+                }
+                if constexpr (U > 6) {
+                    if (c0 + 6 < nchunks) iteration(std::integral_constant<int, 6>{});
+                    if (c0 + 7 < nchunks) iteration(std::integral_constant<int, 7>{});
+                    if (c0 + 8 < nchunks) iteration(std::integral_constant<int, 8>{});
+                    if (c0 + 9 < nchunks) iteration(std::integral_constant<int, 9>{});
+                }
+                static_assert(U <= 10, "ring depths up to 5 (odd) or 10 (even)");
             }
             FCN_STAMP(3);      // main loop done
             frags_landed(0, 0, KS);      // (the reads of the chunk that does not exist: see the comment in the other branch)
@@ -795,7 +831,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT)) void conv_fwd_group(const int nprob, const int te0, const int te1, const int te2,
                                                                                   const int te3, const int te4, const int te5, const int te6,
-                                                                                  const int te7, const GroupArgs a) {
+                                                                                  const int te7, const int pool_wgs, const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
     // The launch's fixed cost is what counts at M = 784 (9 us launches, 1.5 us of MFMA work).  The problem table (nprob and
     // the exclusive tile prefix of every problem) travels as the kernel's first nine SCALAR arguments: the build preloads
@@ -806,18 +842,20 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
     typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
     // the GroupArgs copy sits behind the nine ints in the kernarg segment, at its natural alignment
-    constexpr size_t kArgsOffset = (9 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
+    constexpr size_t kArgsOffset = (10 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
     karg_ptr ka = (karg_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kArgsOffset);
     const int head[1 + kMaxGroup] = {nprob, te0, te1, te2, te3, te4, te5, te6, te7};
     static_assert(kMaxGroup == 8, "the tile prefix travels as eight scalar kernel arguments");
-    const int tile = blockIdx.x;
-    const int conv_tiles = head[kMaxGroup];      // the host repeats the last prefix in the unused entries
-    if (tile >= conv_tiles) {      // workgroups behind the convolution tiles: the poolings fused into this launch
-        const int w = tile - conv_tiles;
+    // The poolings fused into this launch take the FIRST pool_wgs workgroups: they are short (a microsecond or two) and start
+    // at once, beside the convolution tiles' set-up and first memory latency - queued behind the tiles, as in round 1, they
+    // were the launch's tail (inception_4a's 1x1 group: 6.1 us alone, 7.3 us with the module's pool behind it).
+    if ((int)blockIdx.x < pool_wgs) {
+        const int w = blockIdx.x;
         if (w < a.pool[0].wg_end) pool_body<T, Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT>(a.pool[0], w);
         else pool_body<T, Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT>(a.pool[1], w - a.pool[0].wg_end);
         return;
     }
+    const int tile = (int)blockIdx.x - pool_wgs;
     int pi = 0, begin = 0;
 #pragma unroll
     for (int i = 0; i < kMaxGroup - 1; ++i) {      // tile_end is increasing: count the problems that end at or before this tile
@@ -1023,13 +1061,13 @@ void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
 }
 
 template <typename T>
-void launch_group_cfg(int cfg, const GroupArgs& ga, int total, hipStream_t st) {
+void launch_group_cfg(int cfg, const GroupArgs& ga, int pool_wgs, int total, hipStream_t st) {
     switch (cfg) {
 #define X(I, A, B, C_, D, E, F, G, H)                                                                                                     \
     case I:                                                                                                                               \
         hipLaunchKernelGGL((conv_fwd_group<T, A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, ga.nprob,      \
                            ga.tile_end[0], ga.tile_end[1], ga.tile_end[2], ga.tile_end[3], ga.tile_end[4], ga.tile_end[5], ga.tile_end[6],          \
-                           ga.tile_end[7], ga);                                                                                                    \
+                           ga.tile_end[7], pool_wgs, ga);                                                                                          \
         break;
         FCN_CONV_CONFIGS(X)
 #undef X
@@ -1168,6 +1206,7 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
             ga.tile_end[i] = src.tile_end - base;
         }
         int grid = ga.tile_end[ga.nprob - 1];
+        int pool_wgs = 0;
         if (hg.npool > 0) {      // only with n <= kMaxGroup: a single launch
             const int per_wg = kCfgThreads[g->cfg] * kPoolItemsPerThread;
             int end = 0;
@@ -1178,9 +1217,10 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
                 ga.pool[i].wg_end = end;
             }
             grid += end;
+            pool_wgs = end;
         }
-        if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, grid, as_stream(s));
-        else launch_group_cfg<float>(g->cfg, ga, grid, as_stream(s));
+        if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, pool_wgs, grid, as_stream(s));
+        else launch_group_cfg<float>(g->cfg, ga, pool_wgs, grid, as_stream(s));
         FCN_LAUNCH_CHECK("conv_fwd_group");
     }
     return 0;
