@@ -22,6 +22,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# CPU baseline leg only (the GPU path never touches BLAS): OpenBLAS workers spin for ~2^26 cycles after every sgemm and
+# libgomp's spin too; with both pools alive (oracle/caffe_cpu.c uses OpenMP) they steal each other's cores.  Both read these
+# when their library loads, i.e. before numpy is imported.
+os.environ.setdefault("OPENBLAS_THREAD_TIMEOUT", "4")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 import numpy as np  # noqa: E402
 
 FWD_GFLOP = 15.608          # 2*MAC over the 59 convolutions at 448x448

@@ -164,6 +164,22 @@ __device__ __forceinline__ float pow_neg_beta_fast(float s, float beta) {
     return powf(s, -beta);
 }
 
+// LRN of the 4 channels in `c` given their left / right neighbour groups (zeros outside the blob): scale -> s, returns x * s^-beta
+__device__ __forceinline__ float4 lrn5_apply(const float4 l, const float4 c, const float4 r, float alpha_over_n, float beta, float kk, float4& s) {
+    const float q[12] = {l.x * l.x, l.y * l.y, l.z * l.z, l.w * l.w, c.x * c.x, c.y * c.y,
+                         c.z * c.z, c.w * c.w, r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w};
+    s.x = kk + alpha_over_n * (q[2] + q[3] + q[4] + q[5] + q[6]);
+    s.y = kk + alpha_over_n * (q[3] + q[4] + q[5] + q[6] + q[7]);
+    s.z = kk + alpha_over_n * (q[4] + q[5] + q[6] + q[7] + q[8]);
+    s.w = kk + alpha_over_n * (q[5] + q[6] + q[7] + q[8] + q[9]);
+    float4 o;
+    o.x = c.x * pow_neg_beta(s.x, beta);
+    o.y = c.y * pow_neg_beta(s.y, beta);
+    o.z = c.z * pow_neg_beta(s.z, beta);
+    o.w = c.w * pow_neg_beta(s.w, beta);
+    return o;
+}
+
 __global__ __launch_bounds__(256) void lrn5_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ scale,
                                                    long long pixels, int C, int x_cstride, int y_cstride, float alpha_over_n,
                                                    float beta, float kk) {
@@ -176,21 +192,54 @@ __global__ __launch_bounds__(256) void lrn5_kernel(const float* __restrict__ x, 
         const float4 c = ld4(xp);
         const float4 l = g > 0 ? ld4(xp - 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 r = g + 1 < cg ? ld4(xp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float q[12] = {l.x * l.x, l.y * l.y, l.z * l.z, l.w * l.w, c.x * c.x, c.y * c.y,
-                             c.z * c.z, c.w * c.w, r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w};
         float4 s;
-        s.x = kk + alpha_over_n * (q[2] + q[3] + q[4] + q[5] + q[6]);
-        s.y = kk + alpha_over_n * (q[3] + q[4] + q[5] + q[6] + q[7]);
-        s.z = kk + alpha_over_n * (q[4] + q[5] + q[6] + q[7] + q[8]);
-        s.w = kk + alpha_over_n * (q[5] + q[6] + q[7] + q[8] + q[9]);
-        float4 o;
-        o.x = c.x * pow_neg_beta(s.x, beta);
-        o.y = c.y * pow_neg_beta(s.y, beta);
-        o.z = c.z * pow_neg_beta(s.z, beta);
-        o.w = c.w * pow_neg_beta(s.w, beta);
+        const float4 o = lrn5_apply(l, c, r, alpha_over_n, beta, kk, s);
         st4(y + (size_t)pix * y_cstride + g * 4, o);
         if (scale) st4(scale + (size_t)pix * C + g * 4, s);
     }
+}
+
+// MAX pooling and LRN (local_size 5) of the same blob in one pass, inference only (nothing kept for backward):
+// LRN_FIRST false: y = LRN(maxpool(x))  (pool1 -> norm1);  true: y = maxpool(LRN(x))  (norm2 -> pool2).
+// The workgroup covers an 8 x 8 patch of output pixels x 32 channels (lane = 4 channels): the overlapping windows and the
+// neighbour channel groups the LRN window needs are re-read from the CU's L1, and the blob in the middle never exists.
+__device__ __forceinline__ float4 max4(const float4 a, const float4 b) {      // strict '>' like maxpool_kernel (first maximum stays)
+    return make_float4(b.x > a.x ? b.x : a.x, b.y > a.y ? b.y : a.y, b.z > a.z ? b.z : a.z, b.w > a.w ? b.w : a.w);
+}
+
+template <bool LRN_FIRST>
+__global__ __launch_bounds__(512) void maxpool_lrn5_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int x_cstride,
+                                                           int k, int stride, int pad, int OH, int OW, int y_cstride, int cgroups,
+                                                           float alpha_over_n, float beta, float kk) {
+    const int cg32 = (int)blockIdx.x % cgroups, tx = (int)blockIdx.x / cgroups;
+    const int g = cg32 * 8 + ((int)threadIdx.x & 7), cg = C / 4;
+    const int pp = (int)threadIdx.x >> 3;
+    const int oy = (int)blockIdx.y * 8 + (pp >> 3), ox = tx * 8 + (pp & 7), n = (int)blockIdx.z;
+    if (g >= cg || oy >= OH || ox >= OW) return;
+    int hs = oy * stride - pad, ws = ox * stride - pad;
+    const int he = min(hs + k, H), we = min(ws + k, W);
+    hs = max(hs, 0);
+    ws = max(ws, 0);
+    const float* xb = x + (size_t)n * H * W * x_cstride + g * 4;
+    const bool hl = g > 0, hr = g + 1 < cg;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f), low = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    float4 m = low, ml = hl ? low : zero, mr = hr ? low : zero, s;
+    for (int iy = hs; iy < he; ++iy)
+        for (int ix = ws; ix < we; ++ix) {
+            const float* xp = xb + ((size_t)iy * W + ix) * x_cstride;
+            const float4 c = ld4(xp);
+            const float4 l = hl ? ld4(xp - 4) : zero;
+            const float4 r = hr ? ld4(xp + 4) : zero;
+            if (LRN_FIRST) {
+                m = max4(m, lrn5_apply(l, c, r, alpha_over_n, beta, kk, s));
+            } else {
+                m = max4(m, c);
+                if (hl) ml = max4(ml, l);
+                if (hr) mr = max4(mr, r);
+            }
+        }
+    if (!LRN_FIRST) m = lrn5_apply(ml, m, mr, alpha_over_n, beta, kk, s);
+    st4(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + g * 4, m);
 }
 
 // generic window (any odd/even local_size, any C)
@@ -504,6 +553,29 @@ int fcn_lrn_fwd_f32(const float* x, float* y, float* scale, int pixels, int C, i
                            (long long)pixels, C, x_cstride, y_cstride, local_size, aon, beta, k);
     }
     FCN_LAUNCH_CHECK("lrn");
+    return 0;
+}
+
+int fcn_maxpool_lrn5_fwd_f32(const float* x, float* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad, int OH, int OW,
+                             int y_cstride, int lrn_first, float alpha, float beta, float lrn_k, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && OH > 0 && OW > 0, FCN_E_ARG,
+                "maxpool_lrn5: bad args");
+    FCN_REQUIRE(pad < k && (OH - 1) * stride - pad < H && (OW - 1) * stride - pad < W, FCN_E_ARG, "maxpool_lrn5: OH/OW too large or pad >= kernel");
+    FCN_REQUIRE(x_cstride >= C && y_cstride >= C, FCN_E_ARG, "maxpool_lrn5: channel stride smaller than C");
+    FCN_REQUIRE(C % 4 == 0 && x_cstride % 4 == 0 && y_cstride % 4 == 0 && aligned16(x) && aligned16(y), FCN_E_UNSUPPORTED,
+                "maxpool_lrn5: needs 16-byte channel groups (run the two layers separately)");
+    const int cgroups = cdiv(C, 32);
+    const long long gx = (long long)cgroups * cdiv(OW, 8);
+    FCN_REQUIRE(gx < (1ll << 31) && cdiv(OH, 8) <= 65535 && N <= 65535, FCN_E_UNSUPPORTED, "maxpool_lrn5: grid too large");
+    const dim3 grid((unsigned)gx, cdiv(OH, 8), N);
+    const float aon = alpha / 5.f;
+    if (lrn_first)
+        hipLaunchKernelGGL(maxpool_lrn5_kernel<true>, grid, dim3(512), 0, as_stream(s), x, y, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
+                           cgroups, aon, beta, lrn_k);
+    else
+        hipLaunchKernelGGL(maxpool_lrn5_kernel<false>, grid, dim3(512), 0, as_stream(s), x, y, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
+                           cgroups, aon, beta, lrn_k);
+    FCN_LAUNCH_CHECK("maxpool_lrn5");
     return 0;
 }
 

@@ -544,6 +544,43 @@ __global__ __launch_bounds__(256) void maxpool_bwd_v4_kernel(const float* __rest
     }
 }
 
+// same again with the lanes of a workgroup laid over an 8 x 8 patch of input pixels x 32 channels: the windows of neighbouring
+// inputs overlap (each output is read by up to k*k inputs), and with one patch per workgroup that re-reading is served by the
+// CU's own L1 instead of nine trips to L2 (grid-stride order put neighbours on different CUs)
+__global__ __launch_bounds__(512) void maxpool_bwd_patch_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx, float* __restrict__ dx,
+                                                                int H, int W, int C, int dx_cstride, int dx_coffset, int k, int stride, int pad,
+                                                                int OH, int OW, int dy_cstride, int dy_coffset, int accumulate,
+                                                                const float* __restrict__ relu_y, int ry_cstride, int ry_coffset, int cgroups) {
+    const int cg = (int)blockIdx.x % cgroups, tx = (int)blockIdx.x / cgroups;
+    const int c = cg * 32 + ((int)threadIdx.x & 7) * 4;
+    const int pp = (int)threadIdx.x >> 3;
+    const int iy = (int)blockIdx.y * 8 + (pp >> 3), ix = tx * 8 + (pp & 7), n = (int)blockIdx.z;
+    if (c >= C || iy >= H || ix >= W) return;
+    const int oy_lo = max(0, (iy + pad - k + stride) / stride), oy_hi = min(OH - 1, (iy + pad) / stride);
+    const int ox_lo = max(0, (ix + pad - k + stride) / stride), ox_hi = min(OW - 1, (ix + pad) / stride);
+    const int me = iy * W + ix;
+    v4f g = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            const size_t o = ((size_t)(n * OH + oy) * OW + ox);
+            const int4 id = *reinterpret_cast<const int4*>(idx + o * C + c);
+            const v4f d = *reinterpret_cast<const v4f*>(dy + o * dy_cstride + dy_coffset + c);
+            g[0] += id.x == me ? d[0] : 0.f;
+            g[1] += id.y == me ? d[1] : 0.f;
+            g[2] += id.z == me ? d[2] : 0.f;
+            g[3] += id.w == me ? d[3] : 0.f;
+        }
+    const size_t pix = (size_t)(n * H + iy) * W + ix;
+    v4f* dst = reinterpret_cast<v4f*>(dx + pix * dx_cstride + dx_coffset + c);
+    if (accumulate) g += *dst;
+    if (relu_y) {
+        const v4f y = *reinterpret_cast<const v4f*>(relu_y + pix * ry_cstride + ry_coffset + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = y[e] > 0.f ? g[e] : 0.f;
+    }
+    *dst = g;
+}
+
 // LRN backward: dX = dY*scale^-beta - (2 alpha beta / n) * X * sum_{window} (dY * Y / scale)
 __global__ __launch_bounds__(256) void lrn_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ scale,
                                                       const float* __restrict__ dy, float* __restrict__ dx, long long pixels, int C,
@@ -1049,7 +1086,12 @@ int fcn_maxpool_bwd_mask_f32(const float* dy, const int32_t* idx, float* dx, int
     const bool v4 = C % 4 == 0 && dx_cstride % 4 == 0 && dx_coffset % 4 == 0 && dy_cstride % 4 == 0 && dy_coffset % 4 == 0 &&
                     (long long)N * H * W * (C / 4) < (1ll << 31) && (((uintptr_t)dy | (uintptr_t)idx | (uintptr_t)dx) & 15) == 0 &&
                     (!relu_y || (relu_y_cstride % 4 == 0 && relu_y_coffset % 4 == 0 && ((uintptr_t)relu_y & 15) == 0));
-    if (v4)
+    const int cgroups = (C + 31) / 32;
+    const long long gx = (long long)cgroups * ((W + 7) / 8);
+    if (v4 && gx < (1ll << 31) && (H + 7) / 8 <= 65535 && N <= 65535)
+        hipLaunchKernelGGL(maxpool_bwd_patch_kernel, dim3((unsigned)gx, (H + 7) / 8, N), dim3(512), 0, as_stream(s), dy, idx, dx, H, W, C, dx_cstride,
+                           dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate, relu_y, relu_y_cstride, relu_y_coffset, cgroups);
+    else if (v4)
         hipLaunchKernelGGL(maxpool_bwd_v4_kernel, dim3(stream_grid((long long)N * H * W * (C / 4), 256)), dim3(256), 0, as_stream(s), dy, idx, dx, N, H,
                            W, C, dx_cstride, dx_coffset, k, stride, pad, OH, OW, dy_cstride, dy_coffset, accumulate, relu_y, relu_y_cstride,
                            relu_y_coffset);

@@ -188,6 +188,7 @@ class Engine:
         self._conv_layer_meta: Dict[str, dict] = {}
         self._group_workspaces: List[DeviceBuffer] = []      # workspaces of prepared launch groups (released on close)
         self.aux_dev: Dict[str, DeviceBuffer] = {}      # TRAIN: pooling argmax / LRN scale kept for backward
+        self._lazy_blob_ops: Dict[str, List[Op]] = {}   # blobs that fused launches do not write -> the launches that do
         self.loss_blobs: Dict[str, float] = {}          # loss top -> loss_weight
         self.device_fed: set = set()             # input blobs a producer writes straight into HBM (device scene renderer): never uploaded
         self.dropout_seed = 0
@@ -513,6 +514,9 @@ class Engine:
             tasks.append(dict(kind="op", layer=l, ops=ops, reads=[self._range(b) for b in l.bottoms],
                               writes=[self._range(tp) for tp in l.tops], pool_desc=self._fusable_pool_desc(l)))
 
+        if self.fuse and spec.phase == "TEST" and not self.f16 and os.environ.get("FCN_FUSE_POOL_LRN", "1") != "0":
+            tasks = self._fuse_pool_lrn(tasks)
+
         def hit(a, b) -> bool:
             return any(x[0] == y[0] and x[1] < y[2] and y[1] < x[2] for x in a for y in b)
 
@@ -572,6 +576,55 @@ class Engine:
                 self.ops.extend(tasks[i]["ops"])
         emit_convs(pending, pending_pools)
         self.levels = max(levels) + 1 if levels else 0
+
+    def _fuse_pool_lrn(self, tasks: List[dict]) -> List[dict]:
+        """MAX pooling directly followed by LRN (pool1 -> norm1) or LRN directly followed by MAX pooling (norm2 -> pool2)
+        become ONE launch that never writes the blob between them (inference engines; fcn_maxpool_lrn5_fwd_f32).  The
+        blob in the middle stays readable: read_blob() runs the first layer on its own when somebody asks for it."""
+        B, lib = self.blobs, L.load()
+        out: List[dict] = []
+        i = 0
+        while i < len(tasks):
+            a = tasks[i]
+            b = tasks[i + 1] if i + 1 < len(tasks) else None
+            op = None
+            if b is not None and a["kind"] == "op" and b["kind"] == "op":
+                la, lb = a["layer"], b["layer"]
+                if {la.type, lb.type} == {"Pooling", "LRN"} and len(la.tops) == 1 and lb.bottoms == [la.tops[0]] and la.tops[0] != la.bottoms[0]:
+                    op = self._pool_lrn_op(la, lb)
+            if op is None:
+                out.append(a)
+                i += 1
+                continue
+            self._lazy_blob_ops[a["layer"].tops[0]] = list(a["ops"])
+            out.append(dict(kind="op", layer=b["layer"], ops=[op], reads=a["reads"], writes=b["writes"], pool_desc=None))
+            i += 2
+        return out
+
+    def _pool_lrn_op(self, la: Layer, lb: Layer) -> Optional[Op]:
+        B, lib = self.blobs, L.load()
+        pool, lrn = (la, lb) if la.type == "Pooling" else (lb, la)
+        mid = la.tops[0]
+        if [q.name for q in self.consumers.get(mid, [])] != [lb.name] or len(self.producers.get(mid, [])) != 1 or mid in self.outputs:
+            return None
+        pp, lp = pool.sub("pooling_param"), lrn.sub("lrn_param")
+        if str(pp.get("pool", "MAX")) != "MAX" or bool(pp.get("global_pooling", False)):
+            return None
+        if str(lp.get("norm_region", "ACROSS_CHANNELS")) != "ACROSS_CHANNELS" or int(lp.get("local_size", 5)) != 5:
+            return None
+        xb, mb, yb = B[la.bottoms[0]], B[mid], B[lb.tops[0]]
+        if any(t.esize != 4 or t.coffset or t.cstride % 4 for t in (xb, mb, yb)) or xb.channels % 4 or mid in self.alias or lb.tops[0] in self.alias:
+            return None
+        n, c, h, w = xb.shape
+        _, _, oh, ow = yb.shape
+        k, s, pad = kernel_stride_pad(pp)
+        if pad >= k or max((h + 7) // 8, n) > 65535:
+            return None
+        al, be, kk = float(lp.get("alpha", 1.0)), float(lp.get("beta", 0.75)), float(lp.get("k", 1.0))
+        first = 1 if la.type == "LRN" else 0
+        return Op("pool_lrn", "%s+%s" % (la.name, lb.name), lambda st: L.check(lib.fcn_maxpool_lrn5_fwd_f32(
+            xb.ptr, yb.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, yb.cstride, first, al, be, kk, st)),
+            0.0, 4.0 * (xb.pixels * c + yb.pixels * c))
 
     def _fusable_pool_desc(self, l: Layer) -> Optional[L.PoolDesc]:
         if os.environ.get("FCN_FUSE_POOLS", "1") == "0":      # (experiments: pools as launches of their own)
@@ -894,6 +947,8 @@ class Engine:
             b = self.blobs[name]
             host = self.host_array(name)
             if not b.host_valid:
+                for op in self._lazy_blob_ops.get(name, ()):      # a blob a fused launch skipped: its own layer, on demand
+                    op.run(self.stream)
                 self._enqueue_download(name, self.stream)
                 L.call("fcn_stream_sync", self.stream)
                 if b.lazy_shift:

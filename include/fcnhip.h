@@ -161,6 +161,12 @@ int  fcn_avepool_fwd_f32(const float* x, float* y, int N, int H, int W, int C, i
 /* LRN ACROSS_CHANNELS: y = x * (k + alpha/n * sum x^2)^-beta ; scale (may be NULL) keeps the base */
 int  fcn_lrn_fwd_f32(const float* x, float* y, float* scale, int pixels, int C, int x_cstride,
                      int y_cstride, int local_size, float alpha, float beta, float k, fcn_stream_t s);
+/* MAX pooling and LRN (ACROSS_CHANNELS, local_size 5) of one blob in a single pass, inference only: lrn_first 0 computes
+ * LRN(maxpool(x)) (deploy.prototxt pool1/3x3_s2 -> pool1/norm1), 1 computes maxpool(LRN(x)) (conv2/norm2 -> pool2/3x3_s2);
+ * the blob between the two layers is never written.  C, the strides and the pointers must allow 16-byte channel groups
+ * (FCN_E_UNSUPPORTED otherwise: run fcn_maxpool_fwd_f32 and fcn_lrn_fwd_f32). */
+int  fcn_maxpool_lrn5_fwd_f32(const float* x, float* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
+                              int OH, int OW, int y_cstride, int lrn_first, float alpha, float beta, float lrn_k, fcn_stream_t s);
 int  fcn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, fcn_stream_t s);
 int  fcn_sigmoid_fwd_f32(const float* x, float* y, size_t count, fcn_stream_t s);
 int  fcn_power_fwd_f32(const float* x, float* y, size_t count, float power, float scale, float shift, fcn_stream_t s);

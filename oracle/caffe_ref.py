@@ -21,9 +21,37 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import ctypes
+import os
+
 import numpy as np
 
 F32 = np.float32
+
+
+def _load_c():
+    """oracle/libcaffe_cpu.so (oracle/Makefile, built by __graft_entry__.build()): compiled loops for im2col, MAX pooling
+    and LRN.  Absent or ORACLE_NUMPY=1: the numpy statements below run instead (tests/test_oracle.py holds the two equal)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcaffe_cpu.so")
+    if os.environ.get("ORACLE_NUMPY") or not os.path.isfile(path):
+        return None
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")      # read when libgomp loads: idle OpenMP threads sleep instead of spinning
+    lib = ctypes.CDLL(path)
+    i, f, p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+    lib.oracle_im2col_f32.argtypes = [p] + [i] * 11 + [p]
+    lib.oracle_maxpool_f32.argtypes = [p] + [i] * 8 + [p, p]
+    lib.oracle_lrn_f32.argtypes = [p] + [i] * 5 + [f, f, f, p, p]
+    for fn in (lib.oracle_im2col_f32, lib.oracle_maxpool_f32, lib.oracle_lrn_f32):
+        fn.restype = None
+    return lib
+
+
+_C = _load_c()
+
+
+def _ptr(a: np.ndarray) -> int:
+    assert a.flags.c_contiguous
+    return a.ctypes.data
 
 
 # --------------------------------------------------------------------------
@@ -57,6 +85,11 @@ def im2col(x: np.ndarray, kh: int, kw: int, ph: int, pw: int, sh: int, sw: int) 
     """(C,H,W) -> (C*kh*kw, OH*OW), zero padding, row order (c, r, q) as Caffe's im2col_cpu."""
     c, h, w = x.shape
     oh, ow = conv_out(h, kh, ph, sh), conv_out(w, kw, pw, sw)
+    if _C is not None and x.dtype == F32:
+        x = np.ascontiguousarray(x)
+        col = np.empty((c * kh * kw, oh * ow), dtype=F32)
+        _C.oracle_im2col_f32(_ptr(x), c, h, w, kh, kw, ph, pw, sh, sw, oh, ow, _ptr(col))
+        return col
     xp = np.zeros((c, h + 2 * ph, w + 2 * pw), dtype=x.dtype)
     xp[:, ph:ph + h, pw:pw + w] = x
     s0, s1, s2 = xp.strides
@@ -130,6 +163,12 @@ def max_pool(x: np.ndarray, k: int, s: int, p: int, return_index: bool = False):
     input and output (no gathers: this runs inside the CPU baseline bench.py times)."""
     n, c, h, w = x.shape
     oh, ow = pool_out(h, k, p, s), pool_out(w, k, p, s)
+    if _C is not None and x.dtype == F32:
+        x = np.ascontiguousarray(x)
+        y = np.empty((n, c, oh, ow), dtype=F32)
+        idx = np.empty((n, c, oh, ow), dtype=np.int64) if return_index else None
+        _C.oracle_maxpool_f32(_ptr(x), n * c, h, w, k, s, p, oh, ow, _ptr(y), _ptr(idx) if return_index else None)
+        return (y, idx) if return_index else y
     # channels innermost while pooling: the window strides then sit on outer dimensions and every compare / masked copy
     # runs over contiguous channel runs
     xt = np.ascontiguousarray(x.transpose(0, 2, 3, 1))
@@ -193,6 +232,11 @@ def lrn_across(x: np.ndarray, local_size: int, alpha: float, beta: float, k: flo
     """Caffe LRNLayer ACROSS_CHANNELS: scale = k + alpha/n * sum_{c' in window} x^2 (zero padded),
     y = x * scale^-beta."""
     n, c, h, w = x.shape
+    if _C is not None and x.dtype == F32:
+        x = np.ascontiguousarray(x)
+        y, scale = np.empty_like(x), np.empty_like(x)
+        _C.oracle_lrn_f32(_ptr(x), n, c, h, w, local_size, F32(alpha / local_size), beta, k, _ptr(y), _ptr(scale))
+        return (y, scale) if return_scale else y
     pre = (local_size - 1) // 2
     sq = np.zeros((n, c + local_size - 1, h, w), dtype=F32)
     sq[:, pre:pre + c] = x * x

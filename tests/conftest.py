@@ -1,8 +1,13 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+# the oracle runs OpenBLAS (numpy) and OpenMP (oracle/caffe_cpu.c) side by side: keep their idle workers from spinning on each
+# other's cores (both settings are read when the libraries load, so before numpy is imported)
+os.environ.setdefault("OPENBLAS_THREAD_TIMEOUT", "4")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("FCN_QUIET", "1")      # (lib.load() announces on stderr when it fills in GPU_MAX_HW_QUEUES)

@@ -214,6 +214,33 @@ def test_lrn_matches_oracle(gpu, c, ls):
     assert rel_err(nchw(dev_to(sd, (2, 5, 7, c)), c), scale) < 1e-6
 
 
+@pytest.mark.parametrize("lrn_first", [0, 1])
+@pytest.mark.parametrize("k,s,p,h,w,c,cs", [(3, 2, 0, 28, 28, 64, 64), (3, 2, 0, 15, 21, 8, 12), (3, 1, 1, 9, 7, 12, 12), (3, 2, 1, 10, 11, 40, 40),
+                                            (3, 2, 0, 17, 9, 192, 192)])
+def test_maxpool_lrn_single_pass_matches_oracle(gpu, lrn_first, k, s, p, h, w, c, cs):
+    """fcn_maxpool_lrn5_fwd_f32 (pool1 -> norm1 and norm2 -> pool2 of deploy.prototxt as one launch) against the oracle's
+    two layers, and bit for bit against the library's own two launches."""
+    rng = np.random.default_rng(13)
+    x = (rng.standard_normal((2, c, h, w)) * 30).astype(np.float32)
+    oh, ow = R.pool_out(h, k, p, s), R.pool_out(w, k, p, s)
+    xd = dev_from(nhwc(x, cs))
+    yd = dev_from(np.zeros((2, oh, ow, cs), np.float32))
+    L.call("fcn_maxpool_lrn5_fwd_f32", xd.ptr, yd.ptr, 2, h, w, c, cs, k, s, p, oh, ow, cs, lrn_first, 1e-4, 0.75, 1.0, None)
+    y = nchw(dev_to(yd, (2, oh, ow, cs)), c)
+    ref = R.max_pool(R.lrn_across(x, 5, 1e-4, 0.75, 1.0), k, s, p) if lrn_first else R.lrn_across(R.max_pool(x, k, s, p), 5, 1e-4, 0.75, 1.0)
+    assert rel_err(y, ref) < 1e-5
+    mh, mw = (h, w) if lrn_first else (oh, ow)
+    md = dev_from(np.zeros((2, mh, mw, cs), np.float32))
+    zd = dev_from(np.zeros((2, oh, ow, cs), np.float32))
+    if lrn_first:
+        L.call("fcn_lrn_fwd_f32", xd.ptr, md.ptr, None, 2 * h * w, c, cs, cs, 5, 1e-4, 0.75, 1.0, None)
+        L.call("fcn_maxpool_fwd_f32", md.ptr, zd.ptr, None, 2, h, w, c, cs, k, s, p, oh, ow, cs, 0, None)
+    else:
+        L.call("fcn_maxpool_fwd_f32", xd.ptr, md.ptr, None, 2, h, w, c, cs, k, s, p, oh, ow, cs, 0, None)
+        L.call("fcn_lrn_fwd_f32", md.ptr, zd.ptr, None, 2 * oh * ow, c, cs, cs, 5, 1e-4, 0.75, 1.0, None)
+    assert np.array_equal(y, nchw(dev_to(zd, (2, oh, ow, cs)), c))
+
+
 def test_layout_roundtrip(gpu):
     rng = np.random.default_rng(12)
     x = rng.standard_normal((3, 37, 9, 13)).astype(np.float32)

@@ -239,3 +239,42 @@ def test_scene_image_helpers():
     assert np.array_equal(S.resize_nearest(m, 8, 6), m.repeat(2, 0).repeat(2, 1))
 
 
+
+
+# ---- oracle/caffe_cpu.c (compiled loops of the memory-bound layers) against the numpy statement of the same layers ----
+
+def _numpy_twin(monkeypatch):
+    monkeypatch.setattr(R, "_C", None)
+
+
+@pytest.mark.skipif(R._C is None, reason="oracle/libcaffe_cpu.so not built (make -C oracle)")
+@pytest.mark.parametrize("c,h,w,k,s,p", [(3, 23, 31, 7, 2, 3), (16, 14, 9, 3, 1, 1), (8, 11, 11, 5, 1, 2), (4, 6, 8, 2, 2, 0)])
+def test_c_im2col_equals_numpy(monkeypatch, c, h, w, k, s, p):
+    x = np.random.default_rng(3).standard_normal((c, h, w)).astype(np.float32)
+    got = R.im2col(x, k, k, p, p, s, s)
+    _numpy_twin(monkeypatch)
+    assert np.array_equal(got, R.im2col(x, k, k, p, p, s, s))
+
+
+@pytest.mark.skipif(R._C is None, reason="oracle/libcaffe_cpu.so not built (make -C oracle)")
+@pytest.mark.parametrize("k,s,p,h,w", [(3, 2, 0, 28, 28), (3, 2, 0, 15, 14), (3, 1, 1, 9, 7), (2, 2, 0, 8, 6), (3, 2, 1, 10, 11), (3, 1, 1, 1, 1)])
+def test_c_maxpool_equals_numpy(monkeypatch, k, s, p, h, w):
+    x = np.random.default_rng(4).standard_normal((2, 5, h, w)).astype(np.float32)
+    x[0, 0, : h // 2] = 0.25      # ties: the first maximum in raster order wins
+    y0 = R.max_pool(x, k, s, p)
+    y1, i1 = R.max_pool(x, k, s, p, return_index=True)
+    _numpy_twin(monkeypatch)
+    r0 = R.max_pool(x, k, s, p)
+    r1, j1 = R.max_pool(x, k, s, p, return_index=True)
+    assert np.array_equal(y0, r0) and np.array_equal(y1, r1) and np.array_equal(i1, j1) and np.array_equal(y0, y1)
+
+
+@pytest.mark.skipif(R._C is None, reason="oracle/libcaffe_cpu.so not built (make -C oracle)")
+@pytest.mark.parametrize("c,n,alpha,beta", [(7, 5, 1e-4, 0.75), (16, 3, 2e-2, 0.5), (3, 5, 1.0, 0.75)])
+def test_c_lrn_equals_numpy(monkeypatch, c, n, alpha, beta):
+    x = (np.random.default_rng(5).standard_normal((2, c, 6, 5)) * 3).astype(np.float32)
+    y, sc = R.lrn_across(x, n, alpha, beta, 1.0, return_scale=True)
+    _numpy_twin(monkeypatch)
+    ry, rsc = R.lrn_across(x, n, alpha, beta, 1.0, return_scale=True)
+    assert np.array_equal(sc, rsc)                          # same additions in the same order, no fused multiply-add
+    assert np.allclose(y, ry, rtol=3e-7, atol=0)            # powf against numpy's float32 power: a last-bit difference at most
