@@ -219,7 +219,7 @@ def test_lrn_matches_oracle(gpu, c, ls):
                                             (3, 2, 0, 17, 9, 192, 192)])
 def test_maxpool_lrn_single_pass_matches_oracle(gpu, lrn_first, k, s, p, h, w, c, cs):
     """fcn_maxpool_lrn5_fwd_f32 (pool1 -> norm1 and norm2 -> pool2 of deploy.prototxt as one launch) against the oracle's
-    two layers, and bit for bit against the library's own two launches."""
+    two layers, and against the library's own two launches (bit for bit when the pooling comes first)."""
     rng = np.random.default_rng(13)
     x = (rng.standard_normal((2, c, h, w)) * 30).astype(np.float32)
     oh, ow = R.pool_out(h, k, p, s), R.pool_out(w, k, p, s)
@@ -238,7 +238,11 @@ def test_maxpool_lrn_single_pass_matches_oracle(gpu, lrn_first, k, s, p, h, w, c
     else:
         L.call("fcn_maxpool_fwd_f32", xd.ptr, md.ptr, None, 2, h, w, c, cs, k, s, p, oh, ow, cs, 0, None)
         L.call("fcn_lrn_fwd_f32", md.ptr, zd.ptr, None, 2 * oh * ow, c, cs, cs, 5, 1e-4, 0.75, 1.0, None)
-    assert np.array_equal(y, nchw(dev_to(zd, (2, oh, ow, cs)), c))
+    two = nchw(dev_to(zd, (2, oh, ow, cs)), c)
+    if lrn_first:      # the single pass normalises with the hardware rsq / sqrt (1 ulp each)
+        assert np.allclose(y, two, rtol=1e-6, atol=0)
+    else:
+        assert np.array_equal(y, two)
 
 
 def test_layout_roundtrip(gpu):
