@@ -886,6 +886,165 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
     conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(p, blockIdx.x, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// First-layer kernel: 7x7, stride 2, pad 3 on 4-channel pixels (conv1/7x7_s2 of models/deploy.prototxt: 3 image channels +
+// 1 pad), up to 64 output channels.  The implicit-GEMM kernel above stages im2col rows; with 16 bytes per pixel every staged
+// 16-byte segment is a different filter tap, so its loader decodes a tap per lane and chunk and every workgroup's 32 x 32
+// tile lives for seven chunks only (22.8 us at batch 1, a quarter of the matrix-core rate).  Here a workgroup owns an
+// 8 x 32 patch of OUTPUT pixels and all output channels:
+//   * the 21 x 70 input pixels under the patch and the whole filter bank go to LDS once, through registers (ordinary 16-byte
+//     loads return at L1 rate; `buffer_load ... lds` moves one lane per clock and took 2.7 us for the same bytes), and are
+//     PACKED on the way: 3 floats per pixel / tap, the pad channel is dropped;
+//   * one filter row of the packed image is then 21 consecutive floats for the patch (7 taps x 3 channels, the next output
+//     pixel 6 floats further) and for the bank, so K runs over 7 rows x 22 = 154 (147 real + 1 zero weight per row) instead
+//     of 7 x 8 x 4 = 224 with 16-byte pixels: an MFMA's two k-values are floats 2j and 2j + 1 of the row;
+//   * lane (pixel ox, half h) reads patch[2 oy + r][6 ox + 2 j + h] and bank[n][r][2 j + h] with ds_read_b32 whose address is
+//     a per-lane base plus an instruction immediate - no address arithmetic inside the 77 steps x 4 MFMAs, and both reads
+//     are bank-conflict free (strides of 6 and 154 floats: 32 distinct even banks, the h = 1 lanes on the odd ones);
+//   * each of the 4 waves keeps 2 output rows x 64 channels (four 32 x 32 accumulators) and leaves through LDS so that the
+//     stores are 16 bytes per lane, 256 contiguous bytes per pixel.
+constexpr int kD7Th = 8, kD7Tw = 32;                         // output rows x columns of a workgroup
+constexpr int kD7Ph = 2 * kD7Th + 5, kD7Pw = 2 * kD7Tw + 6;  // input rows x columns under them (+1 column: the zero-weight tap)
+constexpr int kD7RowF = kD7Pw * 3;                           // floats per packed patch row
+constexpr int kD7PatchF = kD7Ph * kD7RowF;                   // 4410
+constexpr int kD7WRowF = 22, kD7WPitchF = 7 * kD7WRowF;      // bank: [64 channels][7 rows][21 + 1 floats]
+constexpr int kD7WOff = (kD7PatchF + 3) / 4 * 4;             // float offset of the bank
+constexpr int kD7EpiPitch = 68;                              // floats per pixel in the epilogue image (64 channels + bank spread)
+constexpr int kD7StageF = kD7WOff + 64 * kD7WPitchF;
+constexpr int kD7EpiF = 4 * 2 * 32 * kD7EpiPitch;
+constexpr int kD7LdsBytes = (kD7StageF > kD7EpiF ? kD7StageF : kD7EpiF) * 4;
+constexpr int kD7Threads = 256;
+static_assert(kD7LdsBytes <= 80 * 1024, "first-layer kernel: two workgroups per CU");
+
+__global__ __launch_bounds__(kD7Threads) void conv_first7_kernel(const ConvP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float smem[kD7LdsBytes / 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    FCN_STAMP(0);
+    const int tiles_x = (p.OW + kD7Tw - 1) / kD7Tw, tiles_y = (p.OH + kD7Th - 1) / kD7Th;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y, n = t / tiles_y;
+    const int oy0 = ty * kD7Th, ox0 = tx * kD7Tw;
+    const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    // ---- stage: the patch (6 pixels per thread) and the bank (13 taps per thread), all loads in flight before the first write
+    constexpr int PI = (kD7Ph * kD7Pw + kD7Threads - 1) / kD7Threads, WI = (64 * 49 + kD7Threads - 1) / kD7Threads;
+    v4f px[PI], wv[WI];
+    const float* xn = p.x + (size_t)n * p.H * p.W * 4;
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int s = tid + kD7Threads * i;
+        const int pr = s / kD7Pw, pc = s - pr * kD7Pw;
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        const bool ok = s < kD7Ph * kD7Pw && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        px[i] = ok ? *reinterpret_cast<const v4f*>(xn + ((size_t)iy * p.W + ix) * 4) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int tp = tid + kD7Threads * i;
+        wv[i] = tp < p.Cout * 49 ? *reinterpret_cast<const v4f*>(p.w + (size_t)tp * 4) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < PI; ++i) {
+        const int s = tid + kD7Threads * i;
+        if (s < kD7Ph * kD7Pw) {
+            float* d = smem + s * 3;      // (row pitch = 70 pixels x 3: the packed image is contiguous)
+            d[0] = px[i][0]; d[1] = px[i][1]; d[2] = px[i][2];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int tp = tid + kD7Threads * i;
+        if (tp < 64 * 49) {
+            const int co = tp / 49, rq = tp - co * 49;
+            const int r = rq / 7, q = rq - r * 7;
+            float* d = smem + kD7WOff + co * kD7WPitchF + r * kD7WRowF + q * 3;
+            d[0] = wv[i][0]; d[1] = wv[i][1]; d[2] = wv[i][2];
+        }
+    }
+    for (int i = tid; i < 64 * 7; i += kD7Threads) smem[kD7WOff + i * kD7WRowF + 21] = 0.f;      // the zero weight that pairs with float 20
+    // bias of the 4 channels this lane stores in the epilogue
+    const int c4 = (lane & 15) * 4;
+    const v4f bias_v = (p.bias && c4 < p.Cout) ? *reinterpret_cast<const v4f*>(p.bias + c4) : zero4;
+    FCN_STAMP(1);
+    // ---- per-lane fragment bases (floats): A = patch[2 (2 wave + mt) + r][6 ox + 2 j + h], B = bank[nl + 32 nt][r][2 j + h]
+    const int nl = lane & 31, h = lane >> 5;
+    const float* a_base = smem + (4 * wave) * kD7RowF + 6 * nl + h;
+    const float* b_base = smem + kD7WOff + nl * kD7WPitchF + h;
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    __syncthreads();
+    FCN_STAMP(2);
+    auto frag = [&](const int step, float (&a)[2], float (&b)[2]) {      // step = 11 r + j
+        const int r = step / 11, j = step - 11 * r;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[mt] = a_base[(2 * mt + r) * kD7RowF + 2 * j];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b[nt] = b_base[nt * 32 * kD7WPitchF + r * kD7WRowF + 2 * j];
+    };
+    float fa[3][2], fb[3][2];      // fragments of steps s, s + 1, s + 2: two steps (8 MFMAs = 512 cycles) of LDS latency cover
+    frag(0, fa[0], fb[0]);
+    frag(1, fa[1], fb[1]);
+#pragma unroll
+    for (int step = 0; step < 77; ++step) {
+        if (step + 2 < 77) frag(step + 2, fa[(step + 2) % 3], fb[(step + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the reads to their first use and waits there)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[step % 3][mt], fb[step % 3][nt], acc[mt][nt], 0, 0, 0);
+    }
+    FCN_STAMP(3);
+    // ---- epilogue through LDS: accumulator register v of lane (nl, h) is pixel ox = (v & 3) + 8 (v >> 2) + 4 h, channel nl (+32)
+    __syncthreads();      // every wave is done with the patch and the bank
+    float* epi = smem + wave * (2 * 32 * kD7EpiPitch);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) epi[(mt * 32 + (v & 3) + 8 * (v >> 2) + 4 * h) * kD7EpiPitch + nl + 32 * nt] = acc[mt][nt][v];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave reads back its own image only)
+    __builtin_amdgcn_sched_barrier(0);
+    const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int oy = oy0 + 2 * wave + mt;
+        float* yrow = p.y + ((size_t)(n * p.OH + oy) * p.OW + ox0) * p.y_cstride + p.y_coffset + c4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ox = (lane >> 4) + 4 * i;
+            v4f v = *reinterpret_cast<const v4f*>(epi + (mt * 32 + ox) * kD7EpiPitch + c4) + bias_v;
+            if (do_relu)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            if (oy < p.OH && ox0 + ox < p.OW && c4 < p.Cout) *reinterpret_cast<v4f*>(yrow + (size_t)ox * p.y_cstride) = v;
+        }
+    }
+#ifdef FCN_CONV_STAMPS
+    FCN_STAMP(5);
+    wait_vmcnt<0>();
+    FCN_STAMP(6);
+#endif
+#endif
+}
+
+// Does the first-layer kernel take this problem?
+bool first7_ok(const ConvP& p) {
+    return p.kh == 7 && p.kw == 7 && p.stride == 2 && p.pad == 3 && p.Cin == 4 && p.x_cstride == 4 && p.Cout > 32 && p.Cout <= 64 &&
+           p.Cout % 4 == 0 && ((p.y_cstride | p.y_coffset) & 3) == 0 && ((uintptr_t)p.y & 15) == 0 && (!p.bias || ((uintptr_t)p.bias & 15) == 0) &&
+           (p.flags & ~FCN_CONV_RELU) == 0;
+}
+
 // ---- host side -------------------------------------------------------------------------------
 
 // tile configurations: X(index, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, ring slots, fragment prefetch)
@@ -937,8 +1096,10 @@ constexpr int kCfgWavesK[] = {
     FCN_CONV_CONFIGS(X)
 #undef X
 };
-constexpr int kNumCfg = 30;
-constexpr TileCfg kCfgs[kNumCfg] = {
+constexpr int kNumTileCfg = 30;            // configurations of the implicit-GEMM kernel (the X table)
+constexpr int kFirst7Cfg = kNumTileCfg;    // conv_first7_kernel: single 7x7 / stride 2 / 4-channel problems only (first7_ok)
+constexpr int kNumCfg = kNumTileCfg + 1;
+constexpr TileCfg kCfgs[kNumTileCfg] = {
 #define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
     FCN_CONV_CONFIGS(X)
 #undef X
@@ -996,10 +1157,11 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
 // costs about max(MFMA cycles, staged bytes / 12) plus a barrier; workgroups run in rounds over 256 CUs.
 int choose_cfg(const ConvP* ps, int n) {
     const char* force = getenv("FCN_CONV_CFG");
-    if (force && force[0] >= '0' && force[0] <= '9' && atoi(force) < kNumCfg) return atoi(force);
+    if (force && force[0] >= '0' && force[0] <= '9' && atoi(force) < kNumTileCfg) return atoi(force);
+    if (n == 1 && first7_ok(ps[0]) && !(getenv("FCN_CONV_FIRST7") && atoi(getenv("FCN_CONV_FIRST7")) == 0)) return kFirst7Cfg;
     int best = 0;
     double best_cost = 1e300;
-    for (int c = 0; c < kNumCfg; ++c) {
+    for (int c = 0; c < kNumTileCfg; ++c) {
         const double bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = kCfgs[c].bk;
         const double mf = bm * bn * bk / 128.0, ld = (bm + bn) * bk * 4.0 / 12.0;
         const double per_chunk = (mf > ld ? mf : ld) + 150.0 + (kCfgs[c].prefetch ? 0.0 : 200.0 * bk / 8.0);
@@ -1023,6 +1185,15 @@ int choose_cfg(const ConvP* ps, int n) {
 }
 
 int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
+    if (cfg == kFirst7Cfg) {
+        if (n != 1 || !first7_ok(ps[0])) return -2;
+        ps[0].tiles_m = ps[0].N * cdiv(ps[0].OH, kD7Th) * cdiv(ps[0].OW, kD7Tw);
+        ps[0].tiles_n = 1;
+        ps[0].tiles_n_magic = 0;
+        ps[0].lean_chunks = 0;
+        ps[0].tile_end = ps[0].tiles_m;
+        return ps[0].tiles_m;
+    }
     const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
     static const bool lean_ok = !(getenv("FCN_CONV_LEAN") && atoi(getenv("FCN_CONV_LEAN")) == 0);      // (experiments: per-lane loader only)
     int total = 0;
@@ -1050,6 +1221,10 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
 
 template <typename T>
 void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
+    if (cfg == kFirst7Cfg) {
+        hipLaunchKernelGGL(conv_first7_kernel, dim3(total), dim3(kD7Threads), 0, st, p);
+        return;
+    }
     switch (cfg) {
 #define X(I, A, B, C_, D, E, F, G, H)                                                                                                 \
     case I:                                                                                                                           \
@@ -1113,9 +1288,11 @@ size_t fcn_conv2d_group_workspace_bytes(int n) { return sizeof(ConvP) * (size_t)
 
 int fcn_conv2d_num_configs(void) { return kNumCfg; }
 
-int fcn_conv2d_config_lds_bytes(int cfg) { return cfg >= 0 && cfg < kNumCfg ? kCfgLdsBytes[cfg] : -1; }
+int fcn_conv2d_first_layer_config(void) { return kFirst7Cfg; }
 
-int fcn_conv2d_config_waves_k(int cfg) { return cfg >= 0 && cfg < kNumCfg ? kCfgWavesK[cfg] : -1; }
+int fcn_conv2d_config_lds_bytes(int cfg) { return cfg == kFirst7Cfg ? kD7LdsBytes : cfg >= 0 && cfg < kNumTileCfg ? kCfgLdsBytes[cfg] : -1; }
+
+int fcn_conv2d_config_waves_k(int cfg) { return cfg == kFirst7Cfg ? 1 : cfg >= 0 && cfg < kNumTileCfg ? kCfgWavesK[cfg] : -1; }
 
 int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out) {
     return fcn_conv2d_group_prepare_fused(h_descs, n, nullptr, 0, d_workspace, cfg_request, h_out);
@@ -1160,6 +1337,8 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
     }
     const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
     const int total = plan_tiles_cfg(cfg, ps, n);
+    FCN_REQUIRE(total != -2 && !(cfg == kFirst7Cfg && npools), FCN_E_UNSUPPORTED,
+                "conv group: configuration %d is the first-layer kernel (one 7x7 / stride 2 / pad 3 problem on 4-channel pixels, 33..64 outputs, no poolings)", cfg);
     FCN_REQUIRE(total > 0, FCN_E_UNSUPPORTED, "conv group: too many tiles for the 32-bit tile decode");
     FCN_HIP(hipMemcpy(d_workspace, ps, sizeof(ConvP) * n, hipMemcpyHostToDevice));
     {
@@ -1192,6 +1371,12 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
         auto it = g_groups.find(g->d_probs);
         FCN_REQUIRE(it != g_groups.end() && it->second.n == g->n, FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared by this library instance");
         hg = it->second;
+    }
+    if (g->cfg == kFirst7Cfg) {
+        FCN_REQUIRE(hg.n == 1 && hg.npool == 0 && first7_ok(hg.ps[0]), FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared for the first-layer kernel");
+        launch_one_cfg<float>(kFirst7Cfg, hg.ps[0], g->total_tiles, as_stream(s));
+        FCN_LAUNCH_CHECK("conv_first7");
+        return 0;
     }
     // at most kMaxGroup problems ride in one launch's kernel arguments; larger groups take several launches
     for (int first = 0; first < hg.n; first += kMaxGroup) {

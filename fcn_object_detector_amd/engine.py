@@ -706,10 +706,16 @@ class Engine:
         e0, e1 = self._tune_events
         best, best_ms = -1, 1e30
         grp = L.ConvGroup()
+        first_layer = int(lib.fcn_conv2d_first_layer_config())
         for cfg in range(int(lib.fcn_conv2d_num_configs())):
-            if int(lib.fcn_conv2d_config_lds_bytes(cfg)) > self._tune_max_lds:
+            # (the LDS cap keeps the tiles of several frames in flight resident on one CU; the first-layer kernel puts one
+            #  workgroup per CU and frame and is exempt)
+            if int(lib.fcn_conv2d_config_lds_bytes(cfg)) > self._tune_max_lds and cfg != first_layer:
                 continue
-            L.call("fcn_conv2d_group_prepare_fused", arr, n, parr, npool, ws.ptr, cfg, C.byref(grp))
+            if cfg == first_layer and os.environ.get("FCN_CONV_FIRST7", "1") == "0":
+                continue
+            if lib.fcn_conv2d_group_prepare_fused(arr, n, parr, npool, ws.ptr, cfg, C.byref(grp)) != 0:
+                continue      # a configuration that does not take this group (the first-layer kernel is shape-specific)
             for _ in range(2):
                 L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))
             L.call("fcn_event_record", e0, self.stream)

@@ -116,6 +116,7 @@ PROTOTYPES = {
     "fcn_conv2d_fwd_f32": (_i, [C.POINTER(ConvDesc), _vp]),
     "fcn_conv2d_group_workspace_bytes": (_sz, [_i]),
     "fcn_conv2d_num_configs": (_i, []),
+    "fcn_conv2d_first_layer_config": (_i, []),
     "fcn_conv2d_config_lds_bytes": (_i, [_i]),
     "fcn_conv2d_config_waves_k": (_i, [_i]),
     "fcn_conv2d_group_prepare": (_i, [C.POINTER(ConvDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),

@@ -214,6 +214,41 @@ def test_lrn_matches_oracle(gpu, c, ls):
     assert rel_err(nchw(dev_to(sd, (2, 5, 7, c)), c), scale) < 1e-6
 
 
+@pytest.mark.parametrize("n,h,w,cout,relu", [(1, 64, 64, 64, 1), (2, 37, 51, 64, 0), (1, 30, 130, 48, 1), (1, 448, 448, 64, 1), (3, 16, 16, 40, 1)])
+def test_first_layer_kernel_matches_oracle(gpu, n, h, w, cout, relu):
+    """Configuration 30 = conv_first7_kernel (7x7, stride 2, pad 3 on 4-channel pixels: conv1/7x7_s2 of deploy.prototxt),
+    output sizes that are not multiples of its 8 x 32 patch included; other shapes must be refused for it."""
+    lib = L.load()
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((n, 3, h, w)).astype(np.float32)
+    wt = (rng.standard_normal((cout, 3, 7, 7)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    oh, ow = R.conv_out(h, 7, 3, 2), R.conv_out(w, 7, 3, 2)
+    xd = dev_from(nhwc(x, 4))
+    wd = dev_from(np.ascontiguousarray(np.pad(wt, ((0, 0), (0, 1), (0, 0), (0, 0))).transpose(0, 2, 3, 1)))
+    bd = dev_from(b)
+    yd = dev_from(np.full((n, oh, ow, cout + 4), 7.0, np.float32))
+    d = conv_desc(xd, wd, bd, yd, n, h, w, 4, 4, cout, 7, 3, 2, oh, ow, cout + 4, 4, L.CONV_RELU if relu else 0)
+    arr = (L.ConvDesc * 1)(d)
+    ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(1)), zero=False)
+    grp = L.ConvGroup()
+    L.call("fcn_conv2d_group_prepare", arr, 1, ws.ptr, 30, C.byref(grp))
+    assert grp.cfg == 30 and grp.total_tiles == n * ((oh + 7) // 8) * ((ow + 31) // 32)
+    L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+    full = dev_to(yd, (n, oh, ow, cout + 4))
+    ref = R.conv2d(x, wt, b, 3, 2)
+    if relu:
+        ref = R.relu(ref)
+    assert rel_err(nchw(full, cout, 4), ref) < 1e-5
+    assert np.all(full[..., :4] == 7.0)      # the channels in front of the slice are not touched
+    # auto-selection (no autotune) picks it for this shape; a 3x3 problem is refused for configuration 30
+    L.call("fcn_conv2d_group_prepare", arr, 1, ws.ptr, -1, C.byref(grp))
+    assert grp.cfg == 30
+    d3 = conv_desc(xd, wd, bd, yd, n, h, w, 4, 4, cout, 3, 1, 1, h, w, cout + 4, 4, 0)
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d3), 1, ws.ptr, 30, C.byref(grp)) != 0
+    L.call("fcn_conv2d_group_release", ws.ptr)
+
+
 @pytest.mark.parametrize("lrn_first", [0, 1])
 @pytest.mark.parametrize("k,s,p,h,w,c,cs", [(3, 2, 0, 28, 28, 64, 64), (3, 2, 0, 15, 21, 8, 12), (3, 1, 1, 9, 7, 12, 12), (3, 2, 1, 10, 11, 40, 40),
                                             (3, 2, 0, 17, 9, 192, 192)])

@@ -79,7 +79,8 @@ def main():
             else:
                 os.environ["FCN_CONV_CFG"] = cfg
             grp = L.ConvGroup()
-            L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, -1 if cfg == "auto" else int(cfg), C.byref(grp))
+            if lib.fcn_conv2d_group_prepare(arr, len(descs), ws.ptr, -1 if cfg == "auto" else int(cfg), C.byref(grp)) != 0:
+                continue      # (the first-layer kernel only takes conv1-shaped problems)
             for _ in range(3):
                 L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
             L.call("fcn_event_record", e0, st)

@@ -63,8 +63,7 @@ def main():
         timed = []
         for cfg in (cfgs_env or range(lib.fcn_conv2d_num_configs())):
             grp = L.ConvGroup()
-            L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, cfg, C.byref(grp))
-            if grp.total_tiles > CAP:
+            if lib.fcn_conv2d_group_prepare(arr, len(descs), ws.ptr, cfg, C.byref(grp)) != 0 or grp.total_tiles > CAP:
                 continue
             L.check(lib.fcn_debug_conv_stamps(None, 0))
             for _ in range(3):
