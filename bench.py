@@ -547,7 +547,7 @@ def main() -> None:
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
         tr = profile_traffic("r02_bench")      # HBM bytes per conv launch from the committed PMC passes (stamped with the sources' hash)
         traffic = tr["bytes_per_launch"] if tr else None
-        roofline = {"bound": "mfma", "kernel": "conv_fwd (f32 MFMA implicit GEMM; %d launches covering the 59 convolutions)" % len(conv),
+        roofline = {"bound": "mfma", "kernel": "conv_fwd_group + conv_first7 (f32 MFMA convolution family; %d launches covering the 59 convolutions)" % len(conv),
                     "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": tr, "algorithmic_bytes_per_launch": round(sum(o[4] for o in conv) / max(len(conv), 1)),

@@ -71,7 +71,7 @@ def main():
             for c in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F16"):
                 if c in v:
                     v["mfma_flops_executed_per_call"] = round(v[c] * 512.0 / max(v["calls"], 1))
-    conv = {k: v for k, v in res["counters"].items() if k.startswith("conv_fwd")}
+    conv = {k: v for k, v in res["counters"].items() if k.startswith("conv_fwd") or k.startswith("conv_first7")}      # the forward convolution family
     if conv:
         calls = sum(v["calls"] for v in conv.values())
         fetch_kib = sum(v.get("FETCH_SIZE", 0.0) for v in conv.values())
