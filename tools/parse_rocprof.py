@@ -22,7 +22,33 @@ def short(name):
     return m.group(1) if m else name[:60]
 
 
+def derive_mfma(res):
+    """Matrix-core figures where the MFMA counters were collected (rocprofv3's derived MfmaUtil has no gfx950 section).
+    SQ_VALU_MFMA_BUSY_CYCLES is exact: the sum over all SIMDs of 64 cycles per v_mfma_f32_32x32x2_f32 (conv_first7_kernel:
+    196 workgroups x 4 waves x 308 MFMAs x 64 = 15 454 208 per launch, the value the counter reports), so
+    mfma_busy_cycles_per_simd = busy / 1024 is the time the average matrix pipe of the chip (256 CUs x 4) was busy, in shader
+    cycles; divide by the kernel's duration from the kernel-trace pass x the shader clock for the busy fraction.
+    GRBM_GUI_ACTIVE (sum over the 8 XCDs) is NOT that duration under --pmc: it includes ~10 us of counter set-up per
+    dispatch (64 k cycles for an 18 us kernel), so `mfma_util` = busy / (GRBM_GUI_ACTIVE / 8 x 1024) is a lower bound that only
+    means something for long kernels.  flops executed = MOPS x 512 (padding included)."""
+    for k, v in res["counters"].items():
+        calls = max(v.get("calls", 1), 1)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v:
+            v["mfma_busy_cycles_per_simd_per_call"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / calls, 1)
+            if v.get("GRBM_GUI_ACTIVE"):
+                v["mfma_util"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+        for c in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F16"):
+            if c in v:
+                v["mfma_flops_executed_per_call"] = round(v[c] * 512.0 / calls)
+
+
 def main():
+    if sys.argv[1] == "--rederive":      # refresh the derived fields of an existing summary (the raw traces are not kept)
+        for path in sys.argv[2:]:
+            res = json.load(open(path))
+            derive_mfma(res)
+            json.dump(res, open(path, "w"), indent=1, sort_keys=True)
+        return
     src, out = sys.argv[1], sys.argv[2]
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
     res = {"source": os.path.basename(os.path.normpath(src)), "kernels": {}, "counters": {}}
@@ -61,16 +87,7 @@ def main():
         res["all_kernels_hbm"] = {"launches": calls, "read_bytes_total": 2.0 * fetch_kib * 1024, "write_bytes_total": write_kib * 1024,
                                   "read_bytes_per_launch": 2.0 * fetch_kib * 1024 / max(calls, 1), "write_bytes_per_launch": write_kib * 1024 / max(calls, 1),
                                   "note": "every kernel of the run; read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB"}
-        # Matrix-core utilisation where the MFMA counters were collected (rocprofv3's derived MfmaUtil has no gfx950 section):
-        # SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 matrix pipes (256 CUs x 4 SIMDs); GRBM_GUI_ACTIVE is
-        # reported as the sum over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back), so the kernel was active for
-        # GRBM_GUI_ACTIVE / 8 cycles.  mfma_util = busy / (active x 1024).  flops = MOPS x 512 (executed, padding included).
-        for k, v in res["counters"].items():
-            if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE"):
-                v["mfma_util"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
-            for c in ("SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_F16"):
-                if c in v:
-                    v["mfma_flops_executed_per_call"] = round(v[c] * 512.0 / max(v["calls"], 1))
+        derive_mfma(res)
     conv = {k: v for k, v in res["counters"].items() if k.startswith("conv_fwd") or k.startswith("conv_first7")}      # the forward convolution family
     if conv:
         calls = sum(v["calls"] for v in conv.values())
