@@ -124,9 +124,10 @@ def cpu_baseline(msg, params, x, budget_s: float = 20.0):
         pass
     return {"value": round(1.0 / med, 3), "unit": "frames/s", "cores": threads, "kind": "port", "single_thread_frames_per_s": single,
             "blas": "OpenBLAS (numpy's bundled scipy-openblas)",
-            "sample": "%d forward passes of the same 448x448 frame through the oracle = Caffe's CPU schedule restated in numpy: per "
+            "sample": "%d forward passes of the same 448x448 frame through the oracle = Caffe's CPU schedule restated: per "
                       "convolution im2col (skipped for 1x1, as Caffe's is_1x1_) + one OpenBLAS sgemm + bias pass, separate ReLU / "
-                      "pooling / LRN passes (median %.1f ms, %d BLAS threads - the fastest of several counts - of %d available cores)"
+                      "pooling / LRN passes; im2col, MAX pooling and LRN are compiled C loops with OpenMP (oracle/caffe_cpu.c), the "
+                      "rest numpy (median %.1f ms, %d BLAS threads - the fastest of several counts - of %d available cores)"
                       % (len(times), med * 1e3, threads, avail)}, ref.blobs
 
 
