@@ -236,7 +236,11 @@ def lrn_across(x: np.ndarray, local_size: int, alpha: float, beta: float, k: flo
         x = np.ascontiguousarray(x)
         y, scale = np.empty_like(x), np.empty_like(x)
         _C.oracle_lrn_f32(_ptr(x), n, c, h, w, local_size, F32(alpha / local_size), beta, k, _ptr(y), _ptr(scale))
-        return (y, scale) if return_scale else y
+        if return_scale:
+            # TRAIN phase (backward reads the scale; the committed training fixtures were made by the numpy statement): the
+            # compiled loop's scale is bit-identical to numpy's, its powf is not (a last-bit difference) - so the power is numpy's
+            return (x * np.power(scale, F32(-beta))).astype(F32), scale
+        return y
     pre = (local_size - 1) // 2
     sq = np.zeros((n, c + local_size - 1, h, w), dtype=F32)
     sq[:, pre:pre + c] = x * x

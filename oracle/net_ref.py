@@ -157,9 +157,12 @@ class RefNet:
                     B[tops[0]] = R.ave_pool(bots[0], k, s, pad)
             elif t == "LRN":
                 p = l.get("lrn_param")
-                y, scale = R.lrn_across(bots[0], int(p.get("local_size", 5)), float(p.get("alpha", 1.0)),
-                                        float(p.get("beta", 0.75)), float(p.get("k", 1.0)), return_scale=True)
-                self.aux[name] = scale
+                args = (bots[0], int(p.get("local_size", 5)), float(p.get("alpha", 1.0)), float(p.get("beta", 0.75)), float(p.get("k", 1.0)))
+                if self.phase == "TRAIN":      # the scale is what backward needs
+                    y, scale = R.lrn_across(*args, return_scale=True)
+                    self.aux[name] = scale
+                else:
+                    y = R.lrn_across(*args)
                 B[tops[0]] = y
             elif t == "Concat":
                 B[tops[0]] = np.concatenate(bots, axis=1)

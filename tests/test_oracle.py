@@ -274,7 +274,8 @@ def test_c_maxpool_equals_numpy(monkeypatch, k, s, p, h, w):
 def test_c_lrn_equals_numpy(monkeypatch, c, n, alpha, beta):
     x = (np.random.default_rng(5).standard_normal((2, c, 6, 5)) * 3).astype(np.float32)
     y, sc = R.lrn_across(x, n, alpha, beta, 1.0, return_scale=True)
+    y_only = R.lrn_across(x, n, alpha, beta, 1.0)
     _numpy_twin(monkeypatch)
     ry, rsc = R.lrn_across(x, n, alpha, beta, 1.0, return_scale=True)
-    assert np.array_equal(sc, rsc)                          # same additions in the same order, no fused multiply-add
-    assert np.allclose(y, ry, rtol=3e-7, atol=0)            # powf against numpy's float32 power: a last-bit difference at most
+    assert np.array_equal(sc, rsc) and np.array_equal(y, ry)      # same additions in the same order, no fused multiply-add; numpy's power
+    assert np.allclose(y_only, ry, rtol=3e-7, atol=0)             # TEST phase: powf against numpy's float32 power, a last-bit difference at most
