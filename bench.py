@@ -597,10 +597,28 @@ def main() -> None:
         out["detector_batch1"] = bench_detector_stream(local, msg, params)
     if not args.no_train:
         tsteps = args.train_steps or max(min(args.steps, 30), 1)
+        watchdog = None
+        if world > 1:
+            # A rank that dies or stalls inside an RCCL call leaves the others blocked in the collective for good (the control
+            # plane's sockets time out, ncclAllReduce does not).  The headline measured above must still be reported: after
+            # $FCN_BENCH_TRAIN_TIMEOUT seconds rank 0 prints the line with the failure in `train` and every rank leaves.
+            import threading
+            limit = float(os.environ.get("FCN_BENCH_TRAIN_TIMEOUT", "240"))
+
+            def give_up() -> None:
+                if out is not None:
+                    out["train"] = {"error": "training step did not finish within %.0f s on %d ranks (a rank died or an RCCL call hung)" % (limit, world)}
+                    print(json.dumps(out), flush=True)
+                os._exit(0 if out is not None else 3)
+            watchdog = threading.Timer(limit, give_up)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             tr = bench_train(cp, rank, world, local, args.train_batch, tsteps, max(min(args.warmup, 5), 2))
         except Exception as e:      # the headline measured above must survive a failure in the secondary measurement
             tr = {"error": "%s: %s" % (type(e).__name__, e)}
+        if watchdog is not None:
+            watchdog.cancel()
         if out is not None:
             out["train"] = tr
     if out is not None and world == 1 and not args.no_secondary:

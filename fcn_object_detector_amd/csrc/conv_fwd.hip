@@ -1045,6 +1045,113 @@ bool first7_ok(const ConvP& p) {
            (p.flags & ~FCN_CONV_RELU) == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Narrow 1x1 convolutions (the detection heads: cvg/classifier and bbox/regressor, 4 + 16 outputs over K = 1024 at 784
+// pixels - 32 MFLOP).  As 32 x 32 MFMA tiles they are 50 workgroups that walk 32 chunks of K one after the other behind a
+// full prologue and epilogue: 8-9 us for 0.2 us of arithmetic, whatever the tile shape (tools/conv_sweep.py heads).  Here K
+// is spread over the 64 LANES of a wave instead: a workgroup owns 4 pixels, each of its waves up to 8 output channels of
+// one problem, a lane multiplies the same 4-float slice of every 256-float stretch of K (16-byte loads, 1 KiB contiguous
+// per wave-instruction) into 4 x 8 partial sums, and the 64 partials of every sum are added in lane order through LDS
+// (fixed order: bit-reproducible).  Bias, ReLU and the sigmoid second output as in the tile kernel's epilogue.
+constexpr int kDotPx = 4, kDotOut = 8, kDotMaxSlices = 4;
+constexpr int kDotRedPx = 4;          // pixels per reduction round (the LDS image holds kDotRedPx x kDotOut sums per wave)
+constexpr int kDotRedPitch = 68;      // floats per sum in the reduction image: 64 lane partials + 4 (16-byte rows, banks rotate by 4)
+struct DotSlice {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    float* y2;
+    int K, x_cstride, y_cstride, y_coffset, y2_cstride, y2_coffset, nout, flags;
+};
+struct DotArgs {
+    int M, nslices;
+    DotSlice s[kDotMaxSlices];
+};
+
+__global__ __launch_bounds__(64 * kDotMaxSlices) void conv_dot1x1_kernel(const DotArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[kDotMaxSlices][kDotRedPx * kDotOut * kDotRedPitch];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wave >= a.nslices) return;      // (no workgroup barrier below: every wave reduces through its own LDS rows)
+    DotSlice sl = a.s[0];
+#pragma unroll
+    for (int i = 1; i < kDotMaxSlices; ++i)
+        if (wave == i) sl = a.s[i];
+    const int m0 = blockIdx.x * kDotPx;
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    v4f acc[kDotPx][kDotOut];      // (packed FMAs: two multiply-adds per instruction)
+#pragma unroll
+    for (int p = 0; p < kDotPx; ++p)
+#pragma unroll
+        for (int o = 0; o < kDotOut; ++o) acc[p][o] = zero4;
+    // Four 256-float stretches of K per trip, ALL their loads issued before the first multiply: the launch is a few memory
+    // latencies long, and a loop that waits for every stretch pays one per stretch.  (Measured alternatives: scalar partial
+    // sums - 8 instead of 2 vector instructions per term, 6.7 us; eight pixels per workgroup - half the filter re-reads but
+    // twice the serial work per wave, 9.5 us.)
+    constexpr int U = 4;
+    for (int k0 = lane * 4; k0 < sl.K; k0 += 256 * U) {
+        v4f xa[U][kDotPx], wb[U][kDotOut];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 256 * u;
+            const bool in = k < sl.K;
+#pragma unroll
+            for (int p = 0; p < kDotPx; ++p)
+                xa[u][p] = in && m0 + p < a.M ? *reinterpret_cast<const v4f*>(sl.x + (size_t)(m0 + p) * sl.x_cstride + k) : zero4;
+#pragma unroll
+            for (int o = 0; o < kDotOut; ++o) wb[u][o] = in && o < sl.nout ? *reinterpret_cast<const v4f*>(sl.w + (size_t)o * sl.K + k) : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int p = 0; p < kDotPx; ++p)
+#pragma unroll
+                for (int o = 0; o < kDotOut; ++o) acc[p][o] += xa[u][p] * wb[u][o];
+    }
+    float* r = red[wave];
+#pragma unroll
+    for (int round = 0; round < kDotPx / kDotRedPx; ++round) {      // (a wave's LDS operations complete in order: no wait between rounds)
+#pragma unroll
+        for (int p = 0; p < kDotRedPx; ++p)
+#pragma unroll
+            for (int o = 0; o < kDotOut; ++o) {
+                const v4f t = acc[round * kDotRedPx + p][o];
+                r[(p * kDotOut + o) * kDotRedPitch + lane] = (t[0] + t[1]) + (t[2] + t[3]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave reads its own rows only
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane < kDotRedPx * kDotOut) {
+            const int p = lane / kDotOut, o = lane % kDotOut;
+            v4f q = *reinterpret_cast<const v4f*>(r + lane * kDotRedPitch);      // sixteen 16-byte reads in flight, a fixed tree: the same sum in every run
+#pragma unroll
+            for (int j = 1; j < 16; ++j) q += *reinterpret_cast<const v4f*>(r + lane * kDotRedPitch + 4 * j);
+            float v = (q[0] + q[1]) + (q[2] + q[3]);
+            const int m = m0 + round * kDotRedPx + p;
+            if (m < a.M && o < sl.nout) {
+                if (sl.bias) v += sl.bias[o];
+                if (sl.flags & FCN_CONV_RELU) v = fmaxf(v, 0.f);
+                sl.y[(size_t)m * sl.y_cstride + sl.y_coffset + o] = v;
+                if (sl.flags & FCN_CONV_SIGMOID2) sl.y2[(size_t)m * sl.y2_cstride + sl.y2_coffset + o] = 1.f / (1.f + expf(-v));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Does the lane-split kernel take this group?  (all problems 1x1 / stride 1 / unpadded float32 over the same pixels, at most
+// four slices of eight output channels in all)
+bool dot1x1_ok(const ConvP* ps, int n) {
+    int slices = 0;
+    for (int i = 0; i < n; ++i) {
+        const ConvP& p = ps[i];
+        if (p.kh != 1 || p.kw != 1 || p.stride != 1 || p.pad != 0 || (p.flags & ~(FCN_CONV_RELU | FCN_CONV_SIGMOID2)) != 0) return false;
+        if (p.M != ps[0].M || p.Cin % 4 != 0) return false;
+        slices += cdiv(p.Cout, kDotOut);
+    }
+    return slices <= kDotMaxSlices;
+}
+
 // ---- host side -------------------------------------------------------------------------------
 
 // tile configurations: X(index, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, ring slots, fragment prefetch)
@@ -1098,7 +1205,8 @@ constexpr int kCfgWavesK[] = {
 };
 constexpr int kNumTileCfg = 30;            // configurations of the implicit-GEMM kernel (the X table)
 constexpr int kFirst7Cfg = kNumTileCfg;    // conv_first7_kernel: single 7x7 / stride 2 / 4-channel problems only (first7_ok)
-constexpr int kNumCfg = kNumTileCfg + 1;
+constexpr int kDot1x1Cfg = kNumTileCfg + 1;  // conv_dot1x1_kernel: groups of narrow 1x1 problems only (dot1x1_ok)
+constexpr int kNumCfg = kNumTileCfg + 2;
 constexpr TileCfg kCfgs[kNumTileCfg] = {
 #define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
     FCN_CONV_CONFIGS(X)
@@ -1185,6 +1293,17 @@ int choose_cfg(const ConvP* ps, int n) {
 }
 
 int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
+    if (cfg == kDot1x1Cfg) {
+        if (!dot1x1_ok(ps, n)) return -2;
+        for (int i = 0; i < n; ++i) {
+            ps[i].tiles_m = cdiv(ps[0].M, kDotPx);
+            ps[i].tiles_n = 1;
+            ps[i].tiles_n_magic = 0;
+            ps[i].lean_chunks = 0;
+            ps[i].tile_end = ps[i].tiles_m;
+        }
+        return ps[0].tiles_m;
+    }
     if (cfg == kFirst7Cfg) {
         if (n != 1 || !first7_ok(ps[0])) return -2;
         ps[0].tiles_m = ps[0].N * cdiv(ps[0].OH, kD7Th) * cdiv(ps[0].OW, kD7Tw);
@@ -1290,9 +1409,11 @@ int fcn_conv2d_num_configs(void) { return kNumCfg; }
 
 int fcn_conv2d_first_layer_config(void) { return kFirst7Cfg; }
 
-int fcn_conv2d_config_lds_bytes(int cfg) { return cfg == kFirst7Cfg ? kD7LdsBytes : cfg >= 0 && cfg < kNumTileCfg ? kCfgLdsBytes[cfg] : -1; }
+int fcn_conv2d_config_lds_bytes(int cfg) {
+    return cfg == kFirst7Cfg ? kD7LdsBytes : cfg == kDot1x1Cfg ? kDotMaxSlices * kDotRedPx * kDotOut * kDotRedPitch * 4 : cfg >= 0 && cfg < kNumTileCfg ? kCfgLdsBytes[cfg] : -1;
+}
 
-int fcn_conv2d_config_waves_k(int cfg) { return cfg == kFirst7Cfg ? 1 : cfg >= 0 && cfg < kNumTileCfg ? kCfgWavesK[cfg] : -1; }
+int fcn_conv2d_config_waves_k(int cfg) { return cfg == kFirst7Cfg || cfg == kDot1x1Cfg ? 1 : cfg >= 0 && cfg < kNumTileCfg ? kCfgWavesK[cfg] : -1; }
 
 int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out) {
     return fcn_conv2d_group_prepare_fused(h_descs, n, nullptr, 0, d_workspace, cfg_request, h_out);
@@ -1337,8 +1458,10 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
     }
     const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
     const int total = plan_tiles_cfg(cfg, ps, n);
-    FCN_REQUIRE(total != -2 && !(cfg == kFirst7Cfg && npools), FCN_E_UNSUPPORTED,
-                "conv group: configuration %d is the first-layer kernel (one 7x7 / stride 2 / pad 3 problem on 4-channel pixels, 33..64 outputs, no poolings)", cfg);
+    FCN_REQUIRE(total != -2 && !((cfg == kFirst7Cfg || cfg == kDot1x1Cfg) && npools), FCN_E_UNSUPPORTED,
+                "conv group: configuration %d is shape-specific (%d: one 7x7 / stride 2 / pad 3 problem on 4-channel pixels, 33..64 outputs; "
+                "%d: 1x1 / stride 1 float32 problems over the same pixels, at most 32 output channels in slices of 8) and takes no poolings",
+                cfg, kFirst7Cfg, kDot1x1Cfg);
     FCN_REQUIRE(total > 0, FCN_E_UNSUPPORTED, "conv group: too many tiles for the 32-bit tile decode");
     FCN_HIP(hipMemcpy(d_workspace, ps, sizeof(ConvP) * n, hipMemcpyHostToDevice));
     {
@@ -1371,6 +1494,24 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
         auto it = g_groups.find(g->d_probs);
         FCN_REQUIRE(it != g_groups.end() && it->second.n == g->n, FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared by this library instance");
         hg = it->second;
+    }
+    if (g->cfg == kDot1x1Cfg) {
+        FCN_REQUIRE(hg.npool == 0 && dot1x1_ok(hg.ps, hg.n), FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared for the lane-split 1x1 kernel");
+        DotArgs da = {};
+        da.M = hg.ps[0].M;
+        for (int i = 0; i < hg.n; ++i)
+            for (int n0 = 0; n0 < hg.ps[i].Cout; n0 += kDotOut) {
+                const ConvP& q = hg.ps[i];
+                DotSlice& d = da.s[da.nslices++];
+                d.x = q.x; d.w = q.w + (size_t)n0 * q.K; d.bias = q.bias ? q.bias + n0 : nullptr; d.y = q.y; d.y2 = q.y2;
+                d.K = q.K; d.x_cstride = q.x_cstride; d.y_cstride = q.y_cstride; d.y_coffset = q.y_coffset + n0;
+                d.y2_cstride = q.y2_cstride; d.y2_coffset = q.y2_coffset + n0;
+                d.nout = q.Cout - n0 < kDotOut ? q.Cout - n0 : kDotOut;
+                d.flags = q.flags;
+            }
+        hipLaunchKernelGGL(conv_dot1x1_kernel, dim3(g->total_tiles), dim3(64 * kDotMaxSlices), 0, as_stream(s), da);
+        FCN_LAUNCH_CHECK("conv_dot1x1");
+        return 0;
     }
     if (g->cfg == kFirst7Cfg) {
         FCN_REQUIRE(hg.n == 1 && hg.npool == 0 && first7_ok(hg.ps[0]), FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared for the first-layer kernel");

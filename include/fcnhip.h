@@ -127,10 +127,14 @@ size_t fcn_conv2d_group_workspace_bytes(int n);
 /* cfg_request: -1 = built-in heuristic, 0 .. fcn_conv2d_num_configs()-1 = that tile configuration (the engine
  * times every configuration once per launch at plan time and keeps the fastest) */
 int  fcn_conv2d_num_configs(void);
-/* The last configuration is not a tile shape of the implicit-GEMM kernel but the first-layer kernel (conv_first7_kernel):
- * a single 7x7 / stride 2 / pad 3 problem on 4-channel pixels with 33..64 output channels (conv1/7x7_s2 of
- * models/deploy.prototxt), ReLU optional.  prepare() returns FCN_E_UNSUPPORTED when it is requested for anything else, and
- * the built-in heuristic picks it for the problems it takes. */
+/* The last two configurations are not tile shapes of the implicit-GEMM kernel but shape-specific kernels; prepare() returns
+ * FCN_E_UNSUPPORTED when one is requested for a group it does not take (a tuner walking all configurations skips those):
+ *   fcn_conv2d_first_layer_config()      conv_first7_kernel: a single 7x7 / stride 2 / pad 3 problem on 4-channel pixels with
+ *                                        33..64 output channels (conv1/7x7_s2 of models/deploy.prototxt), ReLU optional; the
+ *                                        built-in heuristic picks it for the problems it takes;
+ *   fcn_conv2d_first_layer_config() + 1  conv_dot1x1_kernel: groups of 1x1 / stride 1 / unpadded float32 problems over the same
+ *                                        pixels with at most 32 output channels in all, counted in slices of 8 per problem (the
+ *                                        detection heads cvg/classifier + bbox/regressor); ReLU and FCN_CONV_SIGMOID2 allowed. */
 int  fcn_conv2d_first_layer_config(void);
 /* LDS bytes one workgroup of that configuration holds (a CU has 160 KiB: it bounds how many workgroups - of this or of a
  * concurrent launch on another stream - fit on a CU); -1 for an unknown index */

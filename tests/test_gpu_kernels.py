@@ -249,6 +249,49 @@ def test_first_layer_kernel_matches_oracle(gpu, n, h, w, cout, relu):
     L.call("fcn_conv2d_group_release", ws.ptr)
 
 
+@pytest.mark.parametrize("n,h,w,cin,couts", [(1, 28, 28, 1024, (4, 16)), (2, 5, 7, 480, (1, 4)), (1, 3, 3, 36, (8, 8, 8, 3)), (1, 9, 5, 1024, (20,))])
+def test_lane_split_1x1_kernel_matches_oracle(gpu, n, h, w, cin, couts):
+    """Configuration 31 = conv_dot1x1_kernel (the detection heads: narrow 1x1 convolutions, K spread over the lanes of a wave):
+    groups of up to four 8-channel slices, pixel counts that are not multiples of 4, K that is not a multiple of 256, the
+    sigmoid second output and ReLU; groups it does not take must be refused."""
+    lib = L.load()
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    xd = dev_from(nhwc(x, cin))
+    keep, descs, refs = [xd], [], []
+    for i, cout in enumerate(couts):
+        wt = (rng.standard_normal((cout, cin, 1, 1)) * 0.05).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        wd, bd = dev_from(pack_ohwi(wt)), dev_from(b)
+        yd = dev_from(np.full((n, h, w, cout + 4), 3.0, np.float32))
+        sig = i == 0
+        y2d = dev_from(np.zeros((n, h, w, cout), np.float32)) if sig else None
+        flags = L.CONV_SIGMOID2 if sig else (L.CONV_RELU if i == 1 else 0)
+        descs.append(conv_desc(xd, wd, bd, yd, n, h, w, cin, cin, cout, 1, 0, 1, h, w, cout + 4, 4, flags, 0.0, y2d, cout, 0))
+        keep += [wd, bd, yd, y2d]
+        ref = R.conv2d(x, wt, b, 0, 1)
+        refs.append((yd, y2d, cout, R.relu(ref) if flags == L.CONV_RELU else ref))
+    arr = (L.ConvDesc * len(descs))(*descs)
+    ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(descs))), zero=False)
+    grp = L.ConvGroup()
+    L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, 31, C.byref(grp))
+    assert grp.cfg == 31 and grp.total_tiles == (n * h * w + 3) // 4
+    L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+    for yd, y2d, cout, ref in refs:
+        full = dev_to(yd, (n, h, w, cout + 4))
+        assert rel_err(nchw(full, cout, 4), ref) < 1e-5
+        assert np.all(full[..., :4] == 3.0)
+        if y2d is not None:
+            assert rel_err(nchw(dev_to(y2d, (n, h, w, cout)), cout), R.sigmoid(ref)) < 1e-5
+    # a 3x3 problem, or more than four slices, is refused for this configuration
+    d3 = conv_desc(xd, keep[1], keep[2], keep[3], n, h, w, cin, cin, couts[0], 3, 1, 1, h, w, couts[0] + 4, 4, 0)
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d3), 1, ws.ptr, 31, C.byref(grp)) != 0
+    five = (L.ConvDesc * 5)(*([descs[0]] * 5))
+    ws5 = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(5)), zero=False)
+    assert lib.fcn_conv2d_group_prepare(five, 5, ws5.ptr, 31, C.byref(grp)) != 0
+    L.call("fcn_conv2d_group_release", ws.ptr)
+
+
 @pytest.mark.parametrize("lrn_first", [0, 1])
 @pytest.mark.parametrize("k,s,p,h,w,c,cs", [(3, 2, 0, 28, 28, 64, 64), (3, 2, 0, 15, 21, 8, 12), (3, 1, 1, 9, 7, 12, 12), (3, 2, 1, 10, 11, 40, 40),
                                             (3, 2, 0, 17, 9, 192, 192)])
