@@ -1038,6 +1038,162 @@ __global__ __launch_bounds__(kD7Threads) void conv_first7_kernel(const ConvP p) 
 #endif
 }
 
+// The same layer in the half-float engine (BASELINE configs[4], batch 32): the image holds 8 halves per pixel (3 channels,
+// two constant-1 channels that carry the folded Power shift, 3 zeros - Engine._packed_weight), so a pixel IS one lane's
+// operand of v_mfma_f32_32x32x16_f16 (8 k-values per half-wave): lane (pixel ox, half h) feeds tap q + 4 h of filter row r
+// with ONE ds_read_b128 at a per-lane base + immediate, 28 steps x 4 MFMAs per wave and tile.  The implicit-GEMM kernel
+// ran this layer at 239 us per 32 frames (a tap decode per lane and chunk, a seventh of the forward).  Workgroups are
+// PERSISTENT and the filters are STATIONARY IN REGISTERS: a lane always multiplies by the same 56 filter segments (its two
+// output channels x 7 rows x 4 tap pairs = 224 VGPRs, one wave per SIMD anyway), loaded once; with the bank in LDS the 32-cycle
+// half-float MFMA waited on fragment reads (four 16-byte reads per four MFMAs: the LDS array, not the matrix core, set the
+// pace - 114 us).  The workgroup then walks its share of the 8 x 32 pixel tiles; the next tile's patch is fetched into
+// registers before the MFMA loop and written to the other patch buffer behind it, the accumulators get bias and ReLU in f32,
+// are rounded to halves once, and leave through LDS as 16-byte stores.  N-tile 0 holds
+// the even output channels and N-tile 1 the odd ones, so a lane's two results of a pixel are neighbours and go out as one dword.
+constexpr int kH7PatchSlots = (kD7Ph * kD7Pw + 63) / 64 * 64;      // 16-byte slots per patch buffer
+constexpr int kH7EpiOff = 2 * kH7PatchSlots * 16;                // bytes: two patch buffers, then the epilogue image
+constexpr int kH7EpiPitch = 144;                                 // bytes per pixel in the epilogue image: 64 halves + 16 (bank spread)
+constexpr int kH7LdsBytes = kH7EpiOff + 4 * 64 * kH7EpiPitch;
+static_assert(kH7LdsBytes <= 160 * 1024, "half-float first-layer kernel: LDS image");
+
+__global__ __launch_bounds__(kD7Threads) void conv_first7_f16_kernel(const ConvP p, const int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) char smem[kH7LdsBytes];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (p.OW + kD7Tw - 1) / kD7Tw, tiles_y = (p.OH + kD7Th - 1) / kD7Th;
+    const f16_t* xh = reinterpret_cast<const f16_t*>(p.x);
+    const f16_t* wh = reinterpret_cast<const f16_t*>(p.w);
+    f16_t* yh = reinterpret_cast<f16_t*>(p.y);
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int PI = (kD7Ph * kD7Pw + kD7Threads - 1) / kD7Threads;
+    // where a tile's patch comes from: the 16-byte pixels of this thread's slots (zeros outside the image / past the last tile)
+    auto fetch_patch = [&](const int tile, v4f (&px)[PI]) {
+        int t = tile;
+        const int tx = t % tiles_x;
+        t /= tiles_x;
+        const int ty = t % tiles_y, n = t / tiles_y;
+        const int iy0 = 2 * ty * kD7Th - 3, ix0 = 2 * tx * kD7Tw - 3;
+        const f16_t* xn = xh + (size_t)n * p.H * p.W * 8;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int s = tid + kD7Threads * i;
+            const int pr = s / kD7Pw, pc = s - pr * kD7Pw;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            const bool ok = tile < ntiles && s < kD7Ph * kD7Pw && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            px[i] = ok ? *reinterpret_cast<const v4f*>(xn + ((size_t)iy * p.W + ix) * 8) : zero4;
+        }
+    };
+    auto store_patch = [&](const int buf, const v4f (&px)[PI]) {
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int s = tid + kD7Threads * i;
+            if (s < kD7Ph * kD7Pw) *reinterpret_cast<v4f*>(smem + (buf * kH7PatchSlots + s) * 16) = px[i];
+        }
+    };
+    // ---- once per workgroup: this lane's filter segments (channel 2 nl + nt, row r, tap q + 4 h; tap 7 does not exist: zeros)
+    //      and the first patch
+    const int nl = lane & 31, h = lane >> 5;
+    v4f px[PI];
+    int tile = blockIdx.x;
+    fetch_patch(tile, px);
+    v4f breg[28][2];
+#pragma unroll
+    for (int step = 0; step < 28; ++step)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int r = step >> 2, q = (step & 3) + 4 * h, co = 2 * nl + nt;
+            breg[step][nt] = (q < 7 && co < p.Cout) ? *reinterpret_cast<const v4f*>(wh + ((size_t)co * 49 + r * 7 + q) * 8) : zero4;
+        }
+    store_patch(0, px);
+    // ---- per-lane constants: fragment base (bytes), bias of this lane's two channels (2 nl, 2 nl + 1)
+    const char* a_lane = smem + ((4 * wave) * kD7Pw + 2 * nl + 4 * h) * 16;
+    const float bias0 = (p.bias && 2 * nl < p.Cout) ? p.bias[2 * nl] : 0.f;
+    const float bias1 = (p.bias && 2 * nl + 1 < p.Cout) ? p.bias[2 * nl + 1] : 0.f;
+    const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
+    char* epi = smem + kH7EpiOff + wave * (64 * kH7EpiPitch);
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    __syncthreads();
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        fetch_patch(tile + (int)gridDim.x, px);      // the next tile's pixels travel while this tile multiplies
+        const char* a_base = a_lane + buf * kH7PatchSlots * 16;
+        v16f acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        auto frag = [&](const int step, v4f (&a)[2]) {
+            const int r = step >> 2, q = step & 3;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const v4f*>(a_base + ((2 * mt + r) * kD7Pw + q) * 16);
+        };
+        v4f fa[3][2];
+        frag(0, fa[0]);
+        frag(1, fa[1]);
+#pragma unroll
+        for (int step = 0; step < 28; ++step) {
+            if (step + 2 < 28) frag(step + 2, fa[(step + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fa[step % 3][mt]), __builtin_bit_cast(v8h, breg[step][nt]),
+                                                                         acc[mt][nt], 0, 0, 0);
+        }
+        // ---- epilogue: register v of lane (nl, h) is pixel ox = (v & 3) + 8 (v >> 2) + 4 h, channels 2 nl (N-tile 0) and 2 nl + 1 (N-tile 1)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float e0 = acc[mt][0][v] + bias0, e1 = acc[mt][1][v] + bias1;
+                if (do_relu) {
+                    e0 = fmaxf(e0, 0.f);
+                    e1 = fmaxf(e1, 0.f);
+                }
+                typedef f16_t v2h __attribute__((ext_vector_type(2)));
+                const v2h pk = {(f16_t)e0, (f16_t)e1};
+                *reinterpret_cast<v2h*>(epi + (mt * 32 + (v & 3) + 8 * (v >> 2) + 4 * h) * kH7EpiPitch + nl * 4) = pk;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave reads back its own image only)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            int t = tile;
+            const int tx = t % tiles_x;
+            t /= tiles_x;
+            const int ty = t % tiles_y, n = t / tiles_y;
+            const int c8 = (lane & 7) * 8;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int oy = ty * kD7Th + 2 * wave + mt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ox = (lane >> 3) + 8 * i;
+                    const v4f val = *reinterpret_cast<const v4f*>(epi + (mt * 32 + ox) * kH7EpiPitch + c8 * 2);
+                    if (oy < p.OH && tx * kD7Tw + ox < p.OW && c8 < p.Cout)
+                        *reinterpret_cast<v4f*>(yh + ((size_t)(n * p.OH + oy) * p.OW + tx * kD7Tw + ox) * p.y_cstride + p.y_coffset + c8) = val;
+                }
+            }
+        }
+        store_patch(buf ^ 1, px);      // (behind the epilogue: the fetch has had the MFMA loop and the epilogue to arrive)
+        // the next patch is in LDS and everybody is done with this one: a raw barrier behind the wave's own LDS writes -
+        // __syncthreads() would also wait for the tile's global stores (a write latency per tile)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        buf ^= 1;
+    }
+#endif
+}
+
+bool first7_f16_ok(const ConvP& p) {
+    return p.kh == 7 && p.kw == 7 && p.stride == 2 && p.pad == 3 && p.Cin == 8 && p.x_cstride == 8 && p.Cout > 32 && p.Cout <= 64 &&
+           p.Cout % 8 == 0 && ((p.y_cstride | p.y_coffset) & 7) == 0 && ((uintptr_t)p.y & 15) == 0 &&
+           (p.flags & ~FCN_CONV_RELU) == FCN_CONV_F16;
+}
+
 // Does the first-layer kernel take this problem?
 bool first7_ok(const ConvP& p) {
     return p.kh == 7 && p.kw == 7 && p.stride == 2 && p.pad == 3 && p.Cin == 4 && p.x_cstride == 4 && p.Cout > 32 && p.Cout <= 64 &&
@@ -1266,7 +1422,7 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
 int choose_cfg(const ConvP* ps, int n) {
     const char* force = getenv("FCN_CONV_CFG");
     if (force && force[0] >= '0' && force[0] <= '9' && atoi(force) < kNumTileCfg) return atoi(force);
-    if (n == 1 && first7_ok(ps[0]) && !(getenv("FCN_CONV_FIRST7") && atoi(getenv("FCN_CONV_FIRST7")) == 0)) return kFirst7Cfg;
+    if (n == 1 && (first7_ok(ps[0]) || first7_f16_ok(ps[0])) && !(getenv("FCN_CONV_FIRST7") && atoi(getenv("FCN_CONV_FIRST7")) == 0)) return kFirst7Cfg;
     int best = 0;
     double best_cost = 1e300;
     for (int c = 0; c < kNumTileCfg; ++c) {
@@ -1305,7 +1461,7 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
         return ps[0].tiles_m;
     }
     if (cfg == kFirst7Cfg) {
-        if (n != 1 || !first7_ok(ps[0])) return -2;
+        if (n != 1 || !(first7_ok(ps[0]) || first7_f16_ok(ps[0]))) return -2;
         ps[0].tiles_m = ps[0].N * cdiv(ps[0].OH, kD7Th) * cdiv(ps[0].OW, kD7Tw);
         ps[0].tiles_n = 1;
         ps[0].tiles_n_magic = 0;
@@ -1338,10 +1494,25 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
     return total;
 }
 
+// workgroups of the persistent half-float first-layer kernel: one per compute unit of the current device
+int first7_f16_grid() {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    return cus;
+}
+
 template <typename T>
 void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
     if (cfg == kFirst7Cfg) {
-        hipLaunchKernelGGL(conv_first7_kernel, dim3(total), dim3(kD7Threads), 0, st, p);
+        if (p.flags & FCN_CONV_F16) {      // persistent: one workgroup per CU (a wave per SIMD holds its filters in registers), each walks its share of the tiles
+            const int grid = total < first7_f16_grid() ? total : first7_f16_grid();
+            hipLaunchKernelGGL(conv_first7_f16_kernel, dim3(grid), dim3(kD7Threads), 0, st, p, total);
+        } else {
+            hipLaunchKernelGGL(conv_first7_kernel, dim3(total), dim3(kD7Threads), 0, st, p);
+        }
         return;
     }
     switch (cfg) {
@@ -1410,7 +1581,7 @@ int fcn_conv2d_num_configs(void) { return kNumCfg; }
 int fcn_conv2d_first_layer_config(void) { return kFirst7Cfg; }
 
 int fcn_conv2d_config_lds_bytes(int cfg) {
-    return cfg == kFirst7Cfg ? kD7LdsBytes : cfg == kDot1x1Cfg ? kDotMaxSlices * kDotRedPx * kDotOut * kDotRedPitch * 4 : cfg >= 0 && cfg < kNumTileCfg ? kCfgLdsBytes[cfg] : -1;
+    return cfg == kFirst7Cfg ? kD7LdsBytes :      /* (the half-float variant holds 84 KB) */ cfg == kDot1x1Cfg ? kDotMaxSlices * kDotRedPx * kDotOut * kDotRedPitch * 4 : cfg >= 0 && cfg < kNumTileCfg ? kCfgLdsBytes[cfg] : -1;
 }
 
 int fcn_conv2d_config_waves_k(int cfg) { return cfg == kFirst7Cfg || cfg == kDot1x1Cfg ? 1 : cfg >= 0 && cfg < kNumTileCfg ? kCfgWavesK[cfg] : -1; }
@@ -1514,7 +1685,8 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
         return 0;
     }
     if (g->cfg == kFirst7Cfg) {
-        FCN_REQUIRE(hg.n == 1 && hg.npool == 0 && first7_ok(hg.ps[0]), FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared for the first-layer kernel");
+        FCN_REQUIRE(hg.n == 1 && hg.npool == 0 && (first7_ok(hg.ps[0]) || first7_f16_ok(hg.ps[0])), FCN_E_STATE,
+                    "fcn_conv2d_fwd_group_f32: group was not prepared for the first-layer kernel");
         launch_one_cfg<float>(kFirst7Cfg, hg.ps[0], g->total_tiles, as_stream(s));
         FCN_LAUNCH_CHECK("conv_first7");
         return 0;

@@ -210,3 +210,34 @@ def test_f16_engine_forward_of_the_detectnet_deploy_net(gpu):
     finally:
         del os.environ["FCN_F16_IMAGE"]
     eng.close()
+
+
+@pytest.mark.parametrize("n,h,w,cout,relu", [(2, 448, 448, 64, 1), (5, 100, 130, 48, 0), (1, 64, 64, 64, 1), (11, 40, 200, 40, 1)])
+def test_f16_first_layer_kernel_matches_oracle(gpu, monkeypatch, n, h, w, cout, relu):
+    """conv_first7_f16_kernel (configuration 30 on half-float problems: 7x7 / stride 2 / pad 3 on 8-half pixels), chosen by the
+    built-in heuristic: more tiles than workgroups (the persistent loop, both patch buffers), partial tiles, fewer than 64 channels."""
+    monkeypatch.delenv("FCN_CONV_CFG", raising=False)
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((n, 3, h, w)).astype(np.float16).astype(np.float32)
+    wt = (rng.standard_normal((cout, 3, 7, 7)) / np.sqrt(147)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = R.conv2d(x, wt, b, 3, 2)
+    if relu:
+        ref = np.maximum(ref, 0)
+    y16 = f16_conv(x, wt, b, 3, 2, L.CONV_RELU if relu else 0, False, r8(cout) + 8, 8)
+    got = y16[..., 8:8 + cout].astype(np.float32).transpose(0, 3, 1, 2)
+    assert rel_err(got, ref) < 1e-3
+    assert np.abs(got - ref).max() <= np.abs(ref).max() * 2.0 ** -10
+    assert np.all(y16[..., :8] == np.float16(-7.0)) and np.all(y16[..., 8 + cout:] == np.float16(-7.0))
+    # the group interface prepares the same configuration for this problem
+    lib = L.load()
+    xd = dev_from(np.zeros((n, h, w, 8), np.float16))
+    wd = dev_from(np.zeros((cout, 7, 7, 8), np.float16))
+    oh, ow = R.conv_out(h, 7, 3, 2), R.conv_out(w, 7, 3, 2)
+    yd = dev_from(np.zeros((n, oh, ow, r8(cout)), np.float16))
+    d = conv_desc(xd, wd, None, yd, n, h, w, 8, 8, cout, 7, 3, 2, oh, ow, r8(cout), 0, L.CONV_F16)
+    ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(1)), zero=False)
+    grp = L.ConvGroup()
+    L.call("fcn_conv2d_group_prepare", (L.ConvDesc * 1)(d), 1, ws.ptr, -1, C.byref(grp))
+    assert grp.cfg == lib.fcn_conv2d_first_layer_config()
+    L.call("fcn_conv2d_group_release", ws.ptr)
