@@ -470,6 +470,24 @@ __global__ __launch_bounds__(448) void maxpool_f16_quad_kernel(const _Float16* _
 }
 
 // LRN across channels, local_size 5: the window of 8 channels lives in the 24 halves c-8..c+15 of the pixel
+// LRN of the 8 channels in `c` given their neighbour groups (zeros outside the blob), f32 arithmetic, one rounding to half
+__device__ __forceinline__ h8_t lrn5_h8(const h8_t l, const h8_t c, const h8_t r, float alpha_over_n, float beta, float kk) {
+    float q[12];      // squares of channels c-2 .. c+9
+    q[0] = (float)l[6] * (float)l[6];
+    q[1] = (float)l[7] * (float)l[7];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) q[2 + e] = (float)c[e] * (float)c[e];
+    q[10] = (float)r[0] * (float)r[0];
+    q[11] = (float)r[1] * (float)r[1];
+    h8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float s = kk + alpha_over_n * (q[e] + q[e + 1] + q[e + 2] + q[e + 3] + q[e + 4]);
+        o[e] = (_Float16)((float)c[e] * pow_neg_beta_fast(s, beta));
+    }
+    return o;
+}
+
 __global__ __launch_bounds__(256) void lrn5_f16_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, long long pixels, int C,
                                                        int x_cstride, int y_cstride, float alpha_over_n, float beta, float kk) {
     const int cg = C / 8;
@@ -484,21 +502,57 @@ __global__ __launch_bounds__(256) void lrn5_f16_kernel(const _Float16* __restric
         for (int e = 0; e < 8; ++e) l[e] = r[e] = (_Float16)0.f;
         if (g > 0) l = *(const h8_t*)(xp - 8);
         if (g + 1 < cg) r = *(const h8_t*)(xp + 8);
-        float q[12];      // squares of channels c-2 .. c+9
-        q[0] = (float)l[6] * (float)l[6];
-        q[1] = (float)l[7] * (float)l[7];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) q[2 + e] = (float)c[e] * (float)c[e];
-        q[10] = (float)r[0] * (float)r[0];
-        q[11] = (float)r[1] * (float)r[1];
-        h8_t o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float s = kk + alpha_over_n * (q[e] + q[e + 1] + q[e + 2] + q[e + 3] + q[e + 4]);
-            o[e] = (_Float16)((float)c[e] * pow_neg_beta_fast(s, beta));
-        }
-        *(h8_t*)(y + (size_t)pix * y_cstride + g * 8) = o;
+        *(h8_t*)(y + (size_t)pix * y_cstride + g * 8) = lrn5_h8(l, c, r, alpha_over_n, beta, kk);
     }
+}
+
+// MAX pooling and LRN of one half-float blob in a single pass (the half twin of maxpool_lrn5_kernel; bit-identical to the two
+// stand-alone kernels: the maximum of halves is exact and every normalised value is rounded to a half before it is compared)
+__device__ __forceinline__ h8_t max8(const h8_t a, const h8_t b) {
+    h8_t m;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = b[e] > a[e] ? b[e] : a[e];
+    return m;
+}
+
+template <bool LRN_FIRST>
+__global__ __launch_bounds__(512) void maxpool_lrn5_f16_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int H, int W, int C,
+                                                               int x_cstride, int k, int stride, int pad, int OH, int OW, int y_cstride,
+                                                               int cgroups, float alpha_over_n, float beta, float kk) {
+    const int cg64 = (int)blockIdx.x % cgroups, tx = (int)blockIdx.x / cgroups;
+    const int g = cg64 * 8 + ((int)threadIdx.x & 7), cg = C / 8;
+    const int pp = (int)threadIdx.x >> 3;
+    const int oy = (int)blockIdx.y * 8 + (pp >> 3), ox = tx * 8 + (pp & 7), n = (int)blockIdx.z;
+    if (g >= cg || oy >= OH || ox >= OW) return;
+    int hs = oy * stride - pad, ws = ox * stride - pad;
+    const int he = min(hs + k, H), we = min(ws + k, W);
+    hs = max(hs, 0);
+    ws = max(ws, 0);
+    const _Float16* xb = x + (size_t)n * H * W * x_cstride + g * 8;
+    const bool hl = g > 0, hr = g + 1 < cg;
+    h8_t zero, low;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        zero[e] = (_Float16)0.f;
+        low[e] = (_Float16)-65504.f;
+    }
+    h8_t m = low, ml = hl ? low : zero, mr = hr ? low : zero;
+    for (int iy = hs; iy < he; ++iy)
+        for (int ix = ws; ix < we; ++ix) {
+            const _Float16* xp = xb + ((size_t)iy * W + ix) * x_cstride;
+            const h8_t c = *(const h8_t*)xp;
+            const h8_t l = hl ? *(const h8_t*)(xp - 8) : zero;
+            const h8_t r = hr ? *(const h8_t*)(xp + 8) : zero;
+            if (LRN_FIRST) {
+                m = max8(m, lrn5_h8(l, c, r, alpha_over_n, beta, kk));
+            } else {
+                m = max8(m, c);
+                if (hl) ml = max8(ml, l);
+                if (hr) mr = max8(mr, r);
+            }
+        }
+    if (!LRN_FIRST) m = lrn5_h8(ml, m, mr, alpha_over_n, beta, kk);
+    *(h8_t*)(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + g * 8) = m;
 }
 
 extern "C" {
@@ -702,6 +756,30 @@ int fcn_maxpool_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int 
         hipLaunchKernelGGL(maxpool_f16_kernel, dim3(stream_grid((long long)N * OH * OW * (C / 8), 256)), dim3(256), 0, as_stream(s), xh, yh, N, H, W, C,
                            x_cstride, k, stride, pad, OH, OW, y_cstride, y_coffset);
     FCN_LAUNCH_CHECK("maxpool_f16");
+    return 0;
+}
+
+int fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad, int OH, int OW,
+                             int y_cstride, int lrn_first, float alpha, float beta, float lrn_k, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && pad >= 0 && OH > 0 && OW > 0, FCN_E_ARG,
+                "maxpool_lrn5_f16: bad args");
+    FCN_REQUIRE(pad < k && (OH - 1) * stride - pad < H && (OW - 1) * stride - pad < W, FCN_E_ARG, "maxpool_lrn5_f16: OH/OW too large or pad >= kernel");
+    FCN_REQUIRE(C % 8 == 0 && x_cstride % 8 == 0 && y_cstride % 8 == 0 && x_cstride >= C && y_cstride >= C && aligned16(x) && aligned16(y), FCN_E_ALIGN,
+                "maxpool_lrn5_f16: channels / strides must be multiples of 8");
+    const int cgroups = cdiv(C, 64);
+    const long long gx = (long long)cgroups * cdiv(OW, 8);
+    FCN_REQUIRE(gx < (1ll << 31) && cdiv(OH, 8) <= 65535 && N <= 65535, FCN_E_UNSUPPORTED, "maxpool_lrn5_f16: grid too large");
+    const dim3 grid((unsigned)gx, cdiv(OH, 8), N);
+    const _Float16* xh = reinterpret_cast<const _Float16*>(x);
+    _Float16* yh = reinterpret_cast<_Float16*>(y);
+    const float aon = alpha / 5.f;
+    if (lrn_first)
+        hipLaunchKernelGGL(maxpool_lrn5_f16_kernel<true>, grid, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
+                           cgroups, aon, beta, lrn_k);
+    else
+        hipLaunchKernelGGL(maxpool_lrn5_f16_kernel<false>, grid, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
+                           cgroups, aon, beta, lrn_k);
+    FCN_LAUNCH_CHECK("maxpool_lrn5_f16");
     return 0;
 }
 

@@ -215,6 +215,9 @@ int  fcn_maxpool_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int
                          int y_cstride, int y_coffset, fcn_stream_t s);
 int  fcn_lrn_fwd_f16(const void* x, void* y, int pixels, int C, int x_cstride, int y_cstride, int local_size, float alpha, float beta,
                      float k, fcn_stream_t s);
+/* the half twin of fcn_maxpool_lrn5_fwd_f32 (8-channel groups); bit-identical to fcn_maxpool_fwd_f16 + fcn_lrn_fwd_f16 in either order */
+int  fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
+                              int OH, int OW, int y_cstride, int lrn_first, float alpha, float beta, float lrn_k, fcn_stream_t s);
 /* n equally sized frames (h*w*3 bytes apart) -> the n images of an N x H x W x dst_cstride blob in three launches;
  * each frame is normalised with its own min / max.  d_minmax: 32 bytes per frame. */
 int  fcn_preprocess_bgr8_batch(const uint8_t* frames, int n, int h, int w, void* dst, int dst_f16, int H, int W, int dst_cstride,

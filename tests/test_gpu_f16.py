@@ -241,3 +241,30 @@ def test_f16_first_layer_kernel_matches_oracle(gpu, monkeypatch, n, h, w, cout, 
     L.call("fcn_conv2d_group_prepare", (L.ConvDesc * 1)(d), 1, ws.ptr, -1, C.byref(grp))
     assert grp.cfg == lib.fcn_conv2d_first_layer_config()
     L.call("fcn_conv2d_group_release", ws.ptr)
+
+
+@pytest.mark.parametrize("lrn_first", [0, 1])
+@pytest.mark.parametrize("k,s,p,h,w,c", [(3, 2, 0, 28, 28, 64), (3, 2, 0, 15, 21, 8), (3, 1, 1, 9, 7, 16), (3, 2, 1, 10, 11, 40), (3, 2, 0, 17, 9, 192)])
+def test_f16_maxpool_lrn_single_pass_equals_the_two_launches(gpu, lrn_first, k, s, p, h, w, c):
+    """fcn_maxpool_lrn5_fwd_f16 against fcn_maxpool_fwd_f16 + fcn_lrn_fwd_f16 in the same order: bit for bit (the maximum of
+    halves is exact, every normalised value is rounded to a half before it is compared), and against the oracle at half precision."""
+    rng = np.random.default_rng(17)
+    x = (rng.standard_normal((2, c, h, w)) * 30).astype(np.float16)
+    oh, ow = R.pool_out(h, k, p, s), R.pool_out(w, k, p, s)
+    xd = dev_from(np.ascontiguousarray(x.transpose(0, 2, 3, 1)))
+    yd = dev_from(np.zeros((2, oh, ow, c), np.float16))
+    L.call("fcn_maxpool_lrn5_fwd_f16", xd.ptr, yd.ptr, 2, h, w, c, c, k, s, p, oh, ow, c, lrn_first, 1e-4, 0.75, 1.0, None)
+    y = dev_to(yd, (2, oh, ow, c), np.float16)
+    mh, mw = (h, w) if lrn_first else (oh, ow)
+    md = dev_from(np.zeros((2, mh, mw, c), np.float16))
+    zd = dev_from(np.zeros((2, oh, ow, c), np.float16))
+    if lrn_first:
+        L.call("fcn_lrn_fwd_f16", xd.ptr, md.ptr, 2 * h * w, c, c, c, 5, 1e-4, 0.75, 1.0, None)
+        L.call("fcn_maxpool_fwd_f16", md.ptr, zd.ptr, 2, h, w, c, c, k, s, p, oh, ow, c, 0, None)
+    else:
+        L.call("fcn_maxpool_fwd_f16", xd.ptr, md.ptr, 2, h, w, c, c, k, s, p, oh, ow, c, 0, None)
+        L.call("fcn_lrn_fwd_f16", md.ptr, zd.ptr, 2 * oh * ow, c, c, c, 5, 1e-4, 0.75, 1.0, None)
+    assert np.array_equal(y, dev_to(zd, (2, oh, ow, c), np.float16))
+    x32 = x.astype(np.float32)
+    ref = R.max_pool(R.lrn_across(x32, 5, 1e-4, 0.75, 1.0), k, s, p) if lrn_first else R.lrn_across(R.max_pool(x32, k, s, p), 5, 1e-4, 0.75, 1.0)
+    assert rel_err(y.astype(np.float32).transpose(0, 3, 1, 2), ref) < 1e-3
