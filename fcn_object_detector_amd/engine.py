@@ -1181,6 +1181,8 @@ class ForwardPipeline:
         if depth < 1:
             raise ValueError("depth must be at least 1")
         self.engines: List[Engine] = []
+        if os.environ.get("FCN_PIPE_LDS_KB"):      # (experiments: another cap, 0 = none)
+            max_lds_kb = int(os.environ["FCN_PIPE_LDS_KB"]) or None
         if max_lds_kb is not None:
             engine_kw.setdefault("tune_max_lds_kb", max_lds_kb)
         for i in range(depth):
