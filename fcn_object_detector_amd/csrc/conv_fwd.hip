@@ -32,6 +32,7 @@
 // Several independent problems (the branches of an inception module) share ONE launch
 // (fcn_conv2d_fwd_group_f32).
 #include <cstddef>
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 #include <type_traits>
@@ -831,7 +832,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
 __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT)) void conv_fwd_group(const int nprob, const int te0, const int te1, const int te2,
                                                                                   const int te3, const int te4, const int te5, const int te6,
-                                                                                  const int te7, const int pool_wgs, const GroupArgs a) {
+                                                                                  const int te7, const int pool_wgs, const int snake, const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
     // The launch's fixed cost is what counts at M = 784 (9 us launches, 1.5 us of MFMA work).  The problem table (nprob and
     // the exclusive tile prefix of every problem) travels as the kernel's first nine SCALAR arguments: the build preloads
@@ -842,7 +843,7 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
     typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
     // the GroupArgs copy sits behind the nine ints in the kernarg segment, at its natural alignment
-    constexpr size_t kArgsOffset = (10 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
+    constexpr size_t kArgsOffset = (11 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
     karg_ptr ka = (karg_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kArgsOffset);
     const int head[1 + kMaxGroup] = {nprob, te0, te1, te2, te3, te4, te5, te6, te7};
     static_assert(kMaxGroup == 8, "the tile prefix travels as eight scalar kernel arguments");
@@ -855,7 +856,19 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
         else pool_body<T, Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT>(a.pool[1], w - a.pool[0].wg_end);
         return;
     }
-    const int tile = (int)blockIdx.x - pool_wgs;
+    // Workgroup p and workgroup p + #CUs land on the same CU (HW_ID stamps, tools/conv_timeline.py TIMELINE_PLACEMENT=1), and a
+    // group's problems are sorted by chunks per tile, longest first: dealt in index order, the CUs that drew long tiles in one
+    // round draw long tiles in every round and the launch ends on them (inception_3b's 3x3 group: 141 chunk-units on the
+    // fullest CU against an average of 117).  So the rounds are dealt like cards in a snake: the last (partial) round forward,
+    // the one before it backward, and so on; round 0 (where the poolings sit) always forward.
+    // snake = rounds << 8 | log2(#CUs), 0 = off; scalar unit only.
+    int pos = blockIdx.x;
+    if (snake) {
+        const int sh = snake & 255, rounds = snake >> 8;
+        const int r = pos >> sh, j = pos & ((1 << sh) - 1);
+        if (r > 0 && r < rounds - 1 && ((rounds - 1 - r) & 1)) pos = (r << sh) + ((1 << sh) - 1 - j);
+    }
+    const int tile = pos - pool_wgs;
     int pi = 0, begin = 0;
 #pragma unroll
     for (int i = 0; i < kMaxGroup - 1; ++i) {      // tile_end is increasing: count the problems that end at or before this tile
@@ -1470,6 +1483,9 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
         return ps[0].tiles_m;
     }
     const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+    // longest tiles first (chunks of K per tile; the order of a group's problems is free - each writes its own output): what
+    // the snake dealing of rounds in conv_fwd_group assumes
+    if (n > 1) std::stable_sort(ps, ps + n, [&](const ConvP& a, const ConvP& b) { return cdiv(a.K, kCfgs[cfg].bk) > cdiv(b.K, kCfgs[cfg].bk); });
     static const bool lean_ok = !(getenv("FCN_CONV_LEAN") && atoi(getenv("FCN_CONV_LEAN")) == 0);      // (experiments: per-lane loader only)
     int total = 0;
     for (int i = 0; i < n; ++i) {
@@ -1494,21 +1510,23 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
     return total;
 }
 
-// workgroups of the persistent half-float first-layer kernel: one per compute unit of the current device
-int first7_f16_grid() {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
+// compute units of the current device (cached per device: asked at every launch)
+int device_cus() {
+    static int cached[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
         int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        cached[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
-    return cus;
+    return cached[dev];
 }
 
 template <typename T>
 void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
     if (cfg == kFirst7Cfg) {
         if (p.flags & FCN_CONV_F16) {      // persistent: one workgroup per CU (a wave per SIMD holds its filters in registers), each walks its share of the tiles
-            const int grid = total < first7_f16_grid() ? total : first7_f16_grid();
+            const int grid = total < device_cus() ? total : device_cus();      // persistent: one workgroup per compute unit
             hipLaunchKernelGGL(conv_first7_f16_kernel, dim3(grid), dim3(kD7Threads), 0, st, p, total);
         } else {
             hipLaunchKernelGGL(conv_first7_kernel, dim3(total), dim3(kD7Threads), 0, st, p);
@@ -1526,13 +1544,13 @@ void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
 }
 
 template <typename T>
-void launch_group_cfg(int cfg, const GroupArgs& ga, int pool_wgs, int total, hipStream_t st) {
+void launch_group_cfg(int cfg, const GroupArgs& ga, int pool_wgs, int snake, int total, hipStream_t st) {
     switch (cfg) {
 #define X(I, A, B, C_, D, E, F, G, H)                                                                                                     \
     case I:                                                                                                                               \
         hipLaunchKernelGGL((conv_fwd_group<T, A, B, C_, D, E, F, G, H>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, ga.nprob,      \
                            ga.tile_end[0], ga.tile_end[1], ga.tile_end[2], ga.tile_end[3], ga.tile_end[4], ga.tile_end[5], ga.tile_end[6],          \
-                           ga.tile_end[7], pool_wgs, ga);                                                                                          \
+                           ga.tile_end[7], pool_wgs, snake, ga);                                                                                   \
         break;
         FCN_CONV_CONFIGS(X)
 #undef X
@@ -1717,8 +1735,19 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
             grid += end;
             pool_wgs = end;
         }
-        if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, pool_wgs, grid, as_stream(s));
-        else launch_group_cfg<float>(g->cfg, ga, pool_wgs, grid, as_stream(s));
+        // snake dealing of the rounds (conv_fwd_group): mixed tile lengths, at least three rounds, a power-of-two CU count
+        int snake = 0;
+        {
+            static const bool snake_ok = !(getenv("FCN_CONV_SNAKE") && atoi(getenv("FCN_CONV_SNAKE")) == 0);
+            const int cus = device_cus();
+            if (snake_ok && ga.nprob > 1 && (cus & (cus - 1)) == 0 && grid > 2 * cus && pool_wgs < cus) {
+                int sh = 0;
+                while ((1 << sh) < cus) ++sh;
+                snake = ((grid + cus - 1) / cus) << 8 | sh;
+            }
+        }
+        if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, pool_wgs, snake, grid, as_stream(s));
+        else launch_group_cfg<float>(g->cfg, ga, pool_wgs, snake, grid, as_stream(s));
         FCN_LAUNCH_CHECK("conv_fwd_group");
     }
     return 0;

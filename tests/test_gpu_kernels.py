@@ -160,6 +160,39 @@ def test_conv_group_launch(gpu):
     assert rel_err(y, ref) < TOL
 
 
+@pytest.mark.parametrize("cfg", [23, 21, 18])      # 32 x 32 tiles: 588 / 744 workgroups
+@pytest.mark.parametrize("hw", [56, 61])
+def test_conv_group_many_rounds_of_workgroups(gpu, cfg, hw):
+    """A group whose tiles need more than two rounds of workgroups over the chip's CUs and whose problems differ in chunks
+    per tile (given shortest first: prepare() sorts them): conv_fwd_group deals the rounds in a snake so that no CU keeps
+    drawing the long tiles - every tile must still be computed exactly once, whatever the permutation."""
+    rng = np.random.default_rng(88)
+    x = rng.standard_normal((1, 64, hw, hw)).astype(np.float32)
+    xd = dev_from(nhwc(x))
+    couts, ks, cins = [64, 32, 96], [1, 5, 3], [64, 16, 32]      # 1x1 on 64, 5x5 on the first 16, 3x3 on the first 32 channels
+    ws = [(rng.standard_normal((co, ci, k, k)) * 0.05).astype(np.float32) for co, k, ci in zip(couts, ks, cins)]
+    bs = [rng.standard_normal(co).astype(np.float32) for co in couts]
+    total = sum(couts)
+    yd = dev_from(np.full((1, hw, hw, total), -3.0, np.float32))
+    keep, descs, off = [], [], 0
+    for wt, b, co, k, ci in zip(ws, bs, couts, ks, cins):
+        wd, bd = dev_from(pack_ohwi(wt)), dev_from(b)
+        keep += [wd, bd]
+        descs.append(conv_desc(xd, wd, bd, yd, 1, hw, hw, ci, 64, co, k, k // 2, 1, hw, hw, total, off, L.CONV_RELU))
+        off += co
+    arr = (L.ConvDesc * 3)(*descs)
+    lib = L.load()
+    wsd = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(3)), zero=False)
+    grp = L.ConvGroup()
+    L.call("fcn_conv2d_group_prepare", arr, 3, wsd.ptr, cfg, C.byref(grp))
+    assert grp.total_tiles > 512
+    L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+    y = nchw(dev_to(yd, (1, hw, hw, total)), total)
+    ref = np.concatenate([R.relu(R.conv2d(x[:, :ci], wt, b, k // 2, 1)) for wt, b, k, ci in zip(ws, bs, ks, cins)], axis=1)
+    assert rel_err(y, ref) < TOL
+    L.call("fcn_conv2d_group_release", wsd.ptr)
+
+
 def test_conv_rejects_bad_arguments(gpu):
     lib = L.load()
     xd = dev_from(np.zeros(64, np.float32))

@@ -103,6 +103,14 @@ def main():
             print("  cfg %d  %d workgroups (%d stamped)  event %.2f us%s  span %.2f us  shader clock %.2f GHz  wg per XCC %s" % (
                 cfg, tiles, int(ok.sum()), us, " (cold)" if cold else "", t[:, -1].max(), float(np.median(clk)),
                 np.bincount(xcc, minlength=8).tolist()))
+            if os.environ.get("TIMELINE_PLACEMENT"):      # which CU did workgroup p run on?  (HW_ID: cu_id [11:8], sh_id [12], se_id [15:13])
+                hw = raw[:, 31].astype(np.int64)
+                cu = ((raw[:, 30].astype(np.int64) & 0xF) << 8) | ((hw >> 8) & 0xFF)
+                n = len(cu)
+                per_cu = np.bincount(np.unique(cu, return_inverse=True)[1])
+                same = [int((cu[:n - d] == cu[d:]).sum()) for d in (8, 32, 256)]
+                print("    placement: %d distinct CUs, workgroups per CU min %d max %d; workgroup p and p+8 / p+32 / p+256 on the same CU: %s of %s" % (
+                    len(per_cu), per_cu.min(), per_cu.max(), same, [n - 8, n - 32, n - 256]))
             have = [i for i in range(len(NAMES)) if (real[ok, i] > 0).all()]      # (split-role configs: thread 0 is a multiplier wave and never
             prev_i = 0                                                              #  executes the loader's stamps; short K loops lack iter1..3)
             for i, nm in enumerate(NAMES):
