@@ -835,14 +835,14 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
                                                                                   const int te7, const int pool_wgs, const int snake, const GroupArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
     // The launch's fixed cost is what counts at M = 784 (9 us launches, 1.5 us of MFMA work).  The problem table (nprob and
-    // the exclusive tile prefix of every problem) travels as the kernel's first nine SCALAR arguments: the build preloads
+    // the exclusive tile prefix of every problem) travels as the kernel's first SCALAR arguments (eleven with the pooling count and the round dealing): the build preloads
     // them into SGPRs at wave launch (-amdgpu-kernarg-preload-count, Makefile), so a workgroup knows its problem without
     // a memory round trip, and the problem itself is ONE round trip to the kernarg segment - written as inline asm because
     // the compiler sinks each field's load to its first use and pays four or five dependent round trips instead.
     typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
     typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
-    // the GroupArgs copy sits behind the nine ints in the kernarg segment, at its natural alignment
+    // the GroupArgs copy sits behind the eleven ints in the kernarg segment, at its natural alignment
     constexpr size_t kArgsOffset = (11 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
     karg_ptr ka = (karg_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kArgsOffset);
     const int head[1 + kMaxGroup] = {nprob, te0, te1, te2, te3, te4, te5, te6, te7};
