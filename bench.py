@@ -475,6 +475,10 @@ def main() -> None:
             raise SystemExit("bench.py: --devices names %d GPUs for --gpus %d" % (len(devices), args.gpus))
         sys.exit(dp.spawn_ranks(__file__, sys.argv[1:], devices))
     rank, world, local = dp.env_rank(), dp.env_world_size(), dp.env_device()
+    if args.devices and "FCN_DEVICE" not in os.environ:      # ranks started by another launcher (torch.distributed.run): --devices still maps rank -> GPU
+        devs = [int(d) for d in args.devices.split(",") if d != ""]
+        if len(devs) == world:
+            local = devs[dp.env_local_rank()]
     if world != max(args.gpus, 1):
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
 
