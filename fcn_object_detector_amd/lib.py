@@ -215,6 +215,12 @@ def load() -> C.CDLL:
                                  "FCN_SET_HW_QUEUES=0 to keep the runtime's default; FCN_QUIET=1 silences this line)\n")
         else:
             HW_QUEUES = {"value": None, "set_by": "nobody (FCN_SET_HW_QUEUES=0): the HIP runtime's default of 4 applies"}
+        # RCCL's intra-node transport shares buffers between rank processes through dmabuf IPC; on hosts whose driver only
+        # supports that mode the legacy handle path fails with `hipIpcGetMemHandle: invalid argument`.  Read by the HSA
+        # runtime when it initialises, so it is filled in here for ranks that a foreign launcher (torch.distributed.run)
+        # started without it - only when the job has more than one rank and nobody has set it.
+        if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         try:
             lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
         except OSError as e:  # pragma: no cover - depends on the box
