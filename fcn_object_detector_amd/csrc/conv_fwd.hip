@@ -445,6 +445,10 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
         // loops.  Every barrier below is executed by BOTH loops (1 + nchunks + 1).
         static_assert(PF, "split roles use the prefetching multiplier loop");
         if (is_loader) {
+            // (Tried: issuing only the chunks that exist - a scalar branch around issue_chunk and tail waits that count down -
+            // so that the epilogue does not wait for D all-zero transfers.  8 % SLOWER end to end (3335 -> 3057 frames/s, same
+            // box): behind a branch the chunk's address arithmetic can no longer be scheduled above the barrier, every chunk
+            // is issued a few dozen cycles later, and the loop's pace is set by issue-to-landed latency over D - 1 chunks.)
 #pragma unroll 1
             for (int c = 0; c < D; ++c) {
                 issue_chunk(buf_issue);
