@@ -38,13 +38,9 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_common.h"
 
 using namespace fcn;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef _Float16 f16_t;
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 
 namespace fcn {
 
@@ -76,46 +72,6 @@ const float* zero_page_for_current_device(int* rc) {
 
 namespace {
 
-struct ConvP {
-    const float* x;
-    const float* w;
-    const float* bias;
-    float* y;
-    float* y2;
-    int N, H, W, Cin, x_cstride;
-    int Cout, kh, kw, pad, stride, OH, OW;
-    int y_cstride, y_coffset, y2_cstride, y2_coffset;
-    int flags;
-    int lean_chunks;  // > 0: the scalar-addressed loader runs this many chunks (plan_tiles_cfg); 0: the per-lane loader
-    int kw_magic;
-    int M, K, tiles_m, tiles_n, tile_end;  // tile_end: exclusive prefix end of this problem's tiles in a group launch
-    unsigned ow_magic, oh_magic;          // ceil(2^32 / OW), ceil(2^32 / OH): exact for every m < M (validate()); 0: OW / OH == 1
-    const float* zero_page;               // 16 zero bytes in HBM: what out-of-image / out-of-tile lanes load
-    unsigned tiles_n_magic;               // ceil(2^32 / tiles_n): tile / tiles_n without a division (tiles * tiles_n < 2^32), 0: tiles_n == 1
-    unsigned cin_magic24;                 // ceil(2^24 / Cin): k / Cin for k < 256 (Cin <= 16384)
-                                          // (160 bytes: the group kernel fetches a problem with three wide scalar loads)
-};
-static_assert(sizeof(ConvP) == 160, "conv_fwd_group loads a ConvP as 16 + 16 + 8 dwords");
-
-// A group launch carries its problems in the kernel arguments: a workgroup finds its problem with scalar
-// compares on the prefix table and ONE scalar load, instead of chasing a table in global memory (three or four
-// dependent L2 round trips in front of the first LDS-DMA of a kernel that only runs for ~10 us).
-constexpr int kMaxGroup = 8;
-constexpr int kMaxPool = 2;
-struct PoolP {
-    const float* x;
-    float* y;
-    int* idx;
-    int N, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride, y_coffset;
-    int items, wg_end;     // float4 work items; exclusive prefix end of this pool's workgroups (after the conv tiles)
-};
-struct GroupArgs {
-    int nprob;
-    int tile_end[kMaxGroup];
-    int npool;
-    PoolP pool[kMaxPool];
-    ConvP p[kMaxGroup];
-};
 constexpr int kPoolItemsPerThread = 2;
 
 // MAX pooling riding in a convolution launch (Caffe semantics as in pointwise.hip: window clipped to the image, strict
@@ -166,12 +122,6 @@ __device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
     }
 }
 
-// m / d through the host's multiplier ceil(2^32 / d) (exact while m * d < 2^32, which validate() / plan_tiles_cfg guarantee);
-// magic 0 stands for d == 1.  No division fallback on purpose: an integer division is ~30 instructions, and the launch
-// prologue is straight-line code that every workgroup runs once from a cold instruction cache.
-__device__ __forceinline__ int fast_div(int m, unsigned magic) { return magic ? (int)__umulhi((unsigned)m, magic) : m; }
-
-
 // Ring slots >= 16 select SPLIT ROLES (the value minus 16 is the ring depth): the workgroup has twice the waves, the first
 // half multiplies (fragment reads + MFMAs, no vector-memory work), the second half loads (address arithmetic + LDS-DMA, no
 // MFMAs).  With one wave per SIMD the loader's ~45 VALU instructions per chunk do not hide behind the wave's own MFMAs (the
@@ -207,20 +157,6 @@ struct Cfg {
     static_assert(!PF || NBUF >= 4, "fragment prefetch needs chunk c+1 landed while c+2.. are in flight");
     static_assert(LDS_FLOATS * 4 <= 160 * 1024, "exceeds the CU's 160 KiB LDS");
 };
-
-// swizzle of the 16-byte slots of staged row r: slot s of the LDS row holds k-segment s ^ swz(r).  An LDS-DMA
-// wave-instruction writes 1 KiB lane-linearly, so the permutation is applied to the SOURCE address on the way in
-// and to the slot index on the way out; 16 consecutive rows then hit 16 distinct 16-byte slots of the 256-byte
-// bank row and every ds_read_b128 fragment read is conflict-free.
-template <int SEGS>
-__device__ __forceinline__ int swz(int row) { return SEGS == 8 ? (row >> 1) & 7 : row & 15; }
-
-typedef float __attribute__((address_space(1))) * gf_ptr;
-typedef const void __attribute__((address_space(1))) * gvoid_cptr;
-typedef void __attribute__((address_space(3))) * lds_ptr;
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Diagnostic build only (make stamps -> libfcnhip_stamps.so, tools/conv_timeline.py): wave 0 of every workgroup records
 // the constant 100 MHz clock and the shader clock at fixed points of conv_body into a buffer of its own.  No stamp exists
@@ -1379,7 +1315,9 @@ constexpr int kCfgWavesK[] = {
 constexpr int kNumTileCfg = 30;            // configurations of the implicit-GEMM kernel (the X table)
 constexpr int kFirst7Cfg = kNumTileCfg;    // conv_first7_kernel: single 7x7 / stride 2 / 4-channel problems only (first7_ok)
 constexpr int kDot1x1Cfg = kNumTileCfg + 1;  // conv_dot1x1_kernel: groups of narrow 1x1 problems only (dot1x1_ok)
-constexpr int kNumCfg = kNumTileCfg + 2;
+constexpr int kStreamCfg0 = kNumTileCfg + 2;  // conv_stream_f16 (conv_stream.hip): persistent half-float streaming kernel, configurations 32 ..
+inline int num_cfgs() { return kStreamCfg0 + stream_num_cfgs(); }
+inline bool is_stream_cfg(int cfg) { return cfg >= kStreamCfg0 && cfg < num_cfgs(); }
 constexpr TileCfg kCfgs[kNumTileCfg] = {
 #define X(I, A, B, C_, D, E, F, G, H) {Cfg<A, B, C_, D, E, F, G, H>::BM, Cfg<A, B, C_, D, E, F, G, H>::BN, F, H},
     FCN_CONV_CONFIGS(X)
@@ -1433,12 +1371,19 @@ void fill(ConvP& p, const fcn_conv_desc& d, const float* zero_page) {
     p.cin_magic24 = (unsigned)(((1u << 24) + d.Cin - 1) / d.Cin);
 }
 
+int plan_tiles_cfg(int cfg, ConvP* ps, int n);
+
 // Heuristic used when the caller does not autotune (cfg_request = -1).  Fitted to tools/conv_sweep.py on
 // MI355X: loads that miss a CU's L1 stream at ~12-16 B/clk into LDS whatever the ring depth, so a workgroup's chunk
 // costs about max(MFMA cycles, staged bytes / 12) plus a barrier; workgroups run in rounds over 256 CUs.
 int choose_cfg(const ConvP* ps, int n) {
     const char* force = getenv("FCN_CONV_CFG");
     if (force && force[0] >= '0' && force[0] <= '9' && atoi(force) < kNumTileCfg) return atoi(force);
+    if (force && is_stream_cfg(atoi(force)) && (ps[0].flags & FCN_CONV_F16)) {      // (tests / sweeps: the streaming kernel where it applies)
+        ConvP tmp[16];
+        for (int i = 0; i < n && i < 16; ++i) tmp[i] = ps[i];
+        if (n <= kMaxGroup && plan_tiles_cfg(atoi(force), tmp, n) > 0) return atoi(force);
+    }
     if (n == 1 && (first7_ok(ps[0]) || first7_f16_ok(ps[0])) && !(getenv("FCN_CONV_FIRST7") && atoi(getenv("FCN_CONV_FIRST7")) == 0)) return kFirst7Cfg;
     int best = 0;
     double best_cost = 1e300;
@@ -1485,6 +1430,30 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
         ps[0].lean_chunks = 0;
         ps[0].tile_end = ps[0].tiles_m;
         return ps[0].tiles_m;
+    }
+    if (is_stream_cfg(cfg)) {
+        // conv_stream_f16: half problems with half outputs, bias + ReLU only, channel counts / strides in whole 16-byte groups,
+        // every problem fed by the scalar-addressed loader (1x1 filters, or each tap's Cin padded to whole chunks, at most 2x)
+        const StreamCfgInfo sc = stream_cfg_info(cfg - kStreamCfg0);
+        const int bke = sc.bk * 2;
+        int total = 0;
+        for (int i = 0; i < n; ++i) {
+            ConvP& q = ps[i];
+            const int taps = q.kh * q.kw, cpt = cdiv(q.Cin, bke);
+            const long long xb = (((long long)q.N * q.H * q.W - 1) * q.x_cstride + q.Cin) * 2, wb = (long long)q.Cout * q.K * 2;
+            const long long yb = (((long long)q.M - 1) * q.y_cstride + q.y_coffset + q.Cout) * 2;
+            if ((q.flags & ~FCN_CONV_RELU) != FCN_CONV_F16 || (q.Cout | q.y_cstride | q.y_coffset) % 8 != 0 || ((uintptr_t)q.y & 15) != 0 ||
+                ((uintptr_t)q.bias & 15) != 0 || xb >= (1ll << 31) || wb >= (1ll << 31) || yb >= (1ll << 31) ||
+                !(taps == 1 || (long long)cpt * bke <= 2ll * q.Cin) || taps > 64)
+                return -2;
+            q.tiles_m = cdiv(q.M, sc.bm);
+            q.tiles_n = cdiv(q.Cout, sc.bn);
+            q.tiles_n_magic = q.tiles_n > 1 ? (unsigned)(((1ull << 32) + q.tiles_n - 1) / q.tiles_n) : 0u;
+            total += q.tiles_m * q.tiles_n;
+            q.tile_end = total;
+            q.lean_chunks = taps * cpt;
+        }
+        return total;
     }
     const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
     // longest tiles first (chunks of K per tile; the order of a group's problems is free - each writes its own output): what
@@ -1598,15 +1567,16 @@ int fcn_conv2d_fwd_f32(const fcn_conv_desc* h_desc, fcn_stream_t s) {
 
 size_t fcn_conv2d_group_workspace_bytes(int n) { return sizeof(ConvP) * (size_t)(n > 0 ? n : 0); }
 
-int fcn_conv2d_num_configs(void) { return kNumCfg; }
+int fcn_conv2d_num_configs(void) { return num_cfgs(); }
 
 int fcn_conv2d_first_layer_config(void) { return kFirst7Cfg; }
 
 int fcn_conv2d_config_lds_bytes(int cfg) {
+    if (is_stream_cfg(cfg)) return stream_cfg_info(cfg - kStreamCfg0).lds_bytes;
     return cfg == kFirst7Cfg ? kD7LdsBytes :      /* (the half-float variant holds 84 KB) */ cfg == kDot1x1Cfg ? kDotMaxSlices * kDotRedPx * kDotOut * kDotRedPitch * 4 : cfg >= 0 && cfg < kNumTileCfg ? kCfgLdsBytes[cfg] : -1;
 }
 
-int fcn_conv2d_config_waves_k(int cfg) { return cfg == kFirst7Cfg || cfg == kDot1x1Cfg ? 1 : cfg >= 0 && cfg < kNumTileCfg ? kCfgWavesK[cfg] : -1; }
+int fcn_conv2d_config_waves_k(int cfg) { return cfg == kFirst7Cfg || cfg == kDot1x1Cfg || is_stream_cfg(cfg) ? 1 : cfg >= 0 && cfg < kNumTileCfg ? kCfgWavesK[cfg] : -1; }
 
 int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_workspace, int cfg_request, fcn_conv_group* h_out) {
     return fcn_conv2d_group_prepare_fused(h_descs, n, nullptr, 0, d_workspace, cfg_request, h_out);
@@ -1615,7 +1585,7 @@ int fcn_conv2d_group_prepare(const fcn_conv_desc* h_descs, int n, void* d_worksp
 int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fcn_pool_desc* h_pools, int npools, void* d_workspace,
                                    int cfg_request, fcn_conv_group* h_out) {
     FCN_REQUIRE(h_descs && h_out && d_workspace && n > 0 && n <= 16, FCN_E_ARG, "fcn_conv2d_group_prepare: need 1..16 problems, workspace, out");
-    FCN_REQUIRE(cfg_request >= -1 && cfg_request < kNumCfg, FCN_E_ARG, "fcn_conv2d_group_prepare: tile configuration %d out of range", cfg_request);
+    FCN_REQUIRE(cfg_request >= -1 && cfg_request < num_cfgs(), FCN_E_ARG, "fcn_conv2d_group_prepare: tile configuration %d out of range", cfg_request);
     FCN_REQUIRE(npools >= 0 && npools <= kMaxPool && (npools == 0 || (h_pools && n <= kMaxGroup)), FCN_E_ARG,
                 "fcn_conv2d_group_prepare_fused: at most %d poolings, and only beside at most %d convolutions", kMaxPool, kMaxGroup);
     ConvP ps[16];
@@ -1651,6 +1621,9 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
     }
     const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
     const int total = plan_tiles_cfg(cfg, ps, n);
+    FCN_REQUIRE(!(is_stream_cfg(cfg) && (total == -2 || npools || n > kMaxGroup)), FCN_E_UNSUPPORTED,
+                "conv group: configuration %d (persistent half-float streaming kernel) takes at most %d half problems with half outputs, "
+                "bias + ReLU only, Cout / y_cstride / y_coffset multiples of 8, 1x1 filters or taps padded at most 2x, and no poolings", cfg, kMaxGroup);
     FCN_REQUIRE(total != -2 && !((cfg == kFirst7Cfg || cfg == kDot1x1Cfg) && npools), FCN_E_UNSUPPORTED,
                 "conv group: configuration %d is shape-specific (%d: one 7x7 / stride 2 / pad 3 problem on 4-channel pixels, 33..64 outputs; "
                 "%d: 1x1 / stride 1 float32 problems over the same pixels, at most 32 output channels in slices of 8) and takes no poolings",
@@ -1680,7 +1653,7 @@ int fcn_conv2d_group_release(void* d_workspace) {
 
 int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
     FCN_REQUIRE(g && g->d_probs && g->n > 0 && g->total_tiles > 0, FCN_E_ARG, "fcn_conv2d_fwd_group_f32: unprepared group");
-    FCN_REQUIRE(g->cfg >= 0 && g->cfg < kNumCfg, FCN_E_ARG, "fcn_conv2d_fwd_group_f32: bad cfg %d", g->cfg);
+    FCN_REQUIRE(g->cfg >= 0 && g->cfg < num_cfgs(), FCN_E_ARG, "fcn_conv2d_fwd_group_f32: bad cfg %d", g->cfg);
     HostGroup hg;
     {
         std::lock_guard<std::mutex> lock(g_groups_mu);
@@ -1711,6 +1684,21 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
                     "fcn_conv2d_fwd_group_f32: group was not prepared for the first-layer kernel");
         launch_one_cfg<float>(kFirst7Cfg, hg.ps[0], g->total_tiles, as_stream(s));
         FCN_LAUNCH_CHECK("conv_first7");
+        return 0;
+    }
+    if (is_stream_cfg(g->cfg)) {
+        FCN_REQUIRE(hg.npool == 0 && hg.n <= kMaxGroup && (hg.ps[0].flags & FCN_CONV_F16), FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared for the streaming kernel");
+        GroupArgs ga;
+        ga.npool = 0;
+        for (int i = 0; i < kMaxPool; ++i) ga.pool[i] = PoolP{};
+        ga.nprob = hg.n;
+        for (int i = 0; i < kMaxGroup; ++i) {
+            const ConvP& src = hg.ps[i < hg.n ? i : hg.n - 1];
+            ga.p[i] = src;
+            ga.tile_end[i] = src.tile_end;
+        }
+        launch_stream(g->cfg - kStreamCfg0, ga, g->total_tiles, as_stream(s));
+        FCN_LAUNCH_CHECK("conv_stream_f16");
         return 0;
     }
     // at most kMaxGroup problems ride in one launch's kernel arguments; larger groups take several launches

@@ -51,6 +51,9 @@ def f16_conv(x, wt, b, pad, stride, flags, out_f32, y_cstride=None, y_coffset=0)
     return y
 
 
+STREAM_CFGS = [32, 33, 34, 35, 36]      # conv_stream_f16: persistent workgroups, 256 x 128 ... 128 x 128 tiles
+
+
 @pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15", "23", "24", "26", "29"])
 @pytest.mark.parametrize("case", CASES)
 def test_f16_conv_matches_oracle_on_the_same_rounded_inputs(gpu, monkeypatch, case, cfg):
@@ -72,6 +75,111 @@ def test_f16_conv_matches_oracle_on_the_same_rounded_inputs(gpu, monkeypatch, ca
     assert rel_err(got, ref) < 1e-3
     assert np.array_equal(got, ref.astype(np.float16).astype(np.float32)) or np.abs(got - ref).max() <= np.abs(ref).max() * 2.0 ** -10
     assert np.all(y16[..., :8] == np.float16(-7.0)) and np.all(y16[..., 8 + cout:] == np.float16(-7.0))
+
+
+def _stream_problem(rng, cin, cout, k, pad, h, w, n, relu=True, bias=True, y_cstride=None, y_coffset=0, xd=None, x=None):
+    """One half-float problem for the streaming kernel: device operands, descriptor, reference output (f32 of the rounded operands)."""
+    ci8 = r8(cin)
+    if x is None:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float16).astype(np.float32)
+        xh = np.zeros((n, h, w, ci8), np.float16)
+        xh[..., :cin] = x.transpose(0, 2, 3, 1)
+        xd = dev_from(xh)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float16).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) if bias else None
+    wh = np.zeros((cout, k, k, ci8), np.float16)
+    wh[..., :cin] = wt.transpose(0, 2, 3, 1)
+    oh, ow = R.conv_out(h, k, pad, 1), R.conv_out(w, k, pad, 1)
+    ycs = y_cstride or cout
+    yd = dev_from(np.full((n, oh, ow, ycs), -7.0, np.float16))
+    wd, bd = dev_from(wh), (dev_from(b) if bias else None)
+    d = conv_desc(xd, wd, bd, yd, n, h, w, ci8, ci8, cout, k, pad, 1, oh, ow, ycs, y_coffset, L.CONV_F16 | (L.CONV_RELU if relu else 0))
+    ref = R.conv2d(x, wt, b if bias else np.zeros(cout, np.float32), pad, 1)
+    if relu:
+        ref = np.maximum(ref, 0)
+    return dict(desc=d, keep=[xd, wd, bd, yd], yd=yd, ref=ref, shape=(n, oh, ow, ycs), cout=cout, coff=y_coffset, x=x, xd=xd)
+
+
+def _stream_takes(cfg, cin, k):
+    """Taps padded to whole chunks (32 halves; 64 for the configurations with 128-byte rows) may cost at most 2x."""
+    bke = 64 if cfg in (35, 36) else 32
+    return k == 1 or -(-r8(cin) // bke) * bke <= 2 * r8(cin)
+
+
+def _run_stream_group(probs, cfg):
+    lib = L.load()
+    arr = (L.ConvDesc * len(probs))(*[q["desc"] for q in probs])
+    ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(probs))), zero=False)
+    grp = L.ConvGroup()
+    L.call("fcn_conv2d_group_prepare", arr, len(probs), ws.ptr, cfg, C.byref(grp))
+    assert grp.cfg == cfg
+    L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+    L.call("fcn_device_sync")
+    for q in probs:
+        yfull = dev_to(q["yd"], q["shape"], np.float16)
+        got = yfull[..., q["coff"]:q["coff"] + q["cout"]].astype(np.float32).transpose(0, 3, 1, 2)
+        assert rel_err(got, q["ref"]) < 1e-3
+        assert np.abs(got - q["ref"]).max() <= max(np.abs(q["ref"]).max(), 1.0) * 2.0 ** -10      # half an f16 ulp of the largest value
+        assert np.all(yfull[..., :q["coff"]] == np.float16(-7.0)) and np.all(yfull[..., q["coff"] + q["cout"]:] == np.float16(-7.0))
+    L.call("fcn_conv2d_group_release", ws.ptr)
+    return grp
+
+
+@pytest.mark.parametrize("cfg", STREAM_CFGS)
+@pytest.mark.parametrize("case", [  # cin, cout, k, pad, h, w, n
+    (96, 208, 3, 1, 28, 28, 3),       # several row tiles with a ragged last one, two column tiles, taps padded to whole chunks (96 = 3 x 32)
+    (480, 304, 1, 0, 28, 28, 2),      # a long 1x1 walk, three column tiles with a ragged last one
+    (48, 64, 5, 2, 28, 28, 2),        # 5x5 on 48 channels: every tap padded (48 -> 64 halves)
+    (16, 32, 5, 2, 20, 12, 1),        # 5x5 on 16 channels: 2x padding, a single ragged tile
+    (64, 192, 3, 1, 40, 36, 5),       # more tiles than a small grid would hold per workgroup: the persistent walk
+    (192, 16, 1, 0, 9, 11, 1),        # M = 99 < one tile, Cout = 16
+])
+def test_stream_kernel_matches_oracle(gpu, case, cfg):
+    cin, cout, k, pad, h, w, n = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    if not _stream_takes(cfg, cin, k):
+        q = _stream_problem(rng, cin, cout, k, pad, h, w, n)
+        ws = DeviceBuffer(int(L.load().fcn_conv2d_group_workspace_bytes(1)), zero=False)
+        assert L.load().fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, cfg, C.byref(L.ConvGroup())) != 0
+        return
+    grp = _run_stream_group([_stream_problem(rng, cin, cout, k, pad, h, w, n)], cfg)
+    assert grp.total_tiles >= 1
+
+
+@pytest.mark.parametrize("cfg", STREAM_CFGS)
+def test_stream_kernel_group_slices_and_flags(gpu, cfg):
+    """Several problems in one persistent launch (an inception module's three 1x1 convolutions on one input, then its 3x3 / 5x5 /
+    pool_proj level): different K per problem, outputs as channel slices of a wider buffer, one problem without bias, one without ReLU."""
+    rng = np.random.default_rng(17)
+    n, h, w = 3, 28, 28
+    first = _stream_problem(rng, 192, 64, 1, 0, h, w, n, y_cstride=256, y_coffset=0)
+    probs = [first,
+             _stream_problem(rng, 192, 96, 1, 0, h, w, n, bias=False, x=first["x"], xd=first["xd"]),
+             _stream_problem(rng, 192, 16, 1, 0, h, w, n, relu=False, x=first["x"], xd=first["xd"])]
+    _run_stream_group(probs, cfg)
+    probs = [_stream_problem(rng, 96, 128, 3, 1, h, w, n, y_cstride=256, y_coffset=64),
+             _stream_problem(rng, 16 if _stream_takes(cfg, 16, 5) else 32, 32, 5, 2, h, w, n, y_cstride=256, y_coffset=192),
+             _stream_problem(rng, 192, 32, 1, 0, h, w, n, y_cstride=256, y_coffset=224)]
+    grp = _run_stream_group(probs, cfg)
+    assert grp.n == 3
+
+
+def test_stream_kernel_refuses_what_it_does_not_cover(gpu):
+    rng = np.random.default_rng(3)
+    lib = L.load()
+    ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(1)), zero=False)
+    grp = L.ConvGroup()
+    q = _stream_problem(rng, 64, 33, 1, 0, 8, 8, 1, y_cstride=40)        # Cout not a multiple of 8
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
+    q = _stream_problem(rng, 8, 64, 7, 3, 20, 20, 1)                      # 7x7 on 8 channels: taps would be padded 4x
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
+    q = _stream_problem(rng, 64, 64, 1, 0, 8, 8, 1)
+    q["desc"].flags |= L.CONV_OUT_F32                                     # float32 output (the detection heads)
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
+    x = dev_from(np.zeros((1, 8, 8, 64), np.float32))                     # float32 problems never take it
+    wt, yd = dev_from(np.zeros((64, 1, 1, 64), np.float32)), dev_from(np.zeros((1, 8, 8, 64), np.float32))
+    d = conv_desc(x, wt, None, yd, 1, 8, 8, 64, 64, 64, 1, 0, 1, 8, 8, 64, 0, 0)
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d), 1, ws.ptr, 32, C.byref(grp)) != 0
 
 
 def test_f16_group_with_fused_pool_and_sigmoid_head(gpu):

@@ -26,6 +26,13 @@ SHAPES = [
     ("5b_A", [(832, 384, 1, 0, 1, 28, 28), (832, 192, 1, 0, 1, 28, 28), (832, 48, 1, 0, 1, 28, 28)]),
     ("5b_B", [(192, 384, 3, 1, 1, 28, 28), (48, 128, 5, 2, 1, 28, 28), (832, 128, 1, 0, 1, 28, 28)]),
     ("heads", [(1024, 4, 1, 0, 1, 28, 28), (1024, 16, 1, 0, 1, 28, 28)]),
+    ("conv2_red", [(64, 64, 1, 0, 1, 112, 112)]),
+    ("3a_B", [(96, 128, 3, 1, 1, 56, 56), (16, 32, 5, 2, 1, 56, 56), (192, 32, 1, 0, 1, 56, 56)]),
+    ("3b_A", [(256, 128, 1, 0, 1, 56, 56), (256, 128, 1, 0, 1, 56, 56), (256, 32, 1, 0, 1, 56, 56)]),
+    ("3b_3x3", [(128, 192, 3, 1, 1, 56, 56)]),
+    ("4c_3x3", [(128, 256, 3, 1, 1, 28, 28)]),
+    ("4c_B", [(128, 256, 3, 1, 1, 28, 28), (24, 64, 5, 2, 1, 28, 28), (512, 64, 1, 0, 1, 28, 28)]),
+    ("5b_3x3", [(192, 384, 3, 1, 1, 28, 28)]),
     # K scaling at M=784, N=320 (3x3): separates the fixed cost from the per-chunk cost
     ("k288", [(32, 320, 3, 1, 1, 28, 28)]),
     ("k576", [(64, 320, 3, 1, 1, 28, 28)]),

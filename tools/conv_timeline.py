@@ -26,6 +26,8 @@ from conv_sweep import SHAPES  # noqa: E402
 NAMES = ("entry", "setup", "issued", "chunk0", "iter0", "iter1", "iter2", "iter3", "loop", "parked", "stored", "acked")
 ORDER = (0, 7, 1, 2, 8, 9, 10, 11, 3, 4, 5, 6)      # stamp slot of each name
 CAP = 4096
+F16 = bool(os.environ.get("SWEEP_F16"))          # half-float problems (as tools/conv_sweep.py)
+BATCH = int(os.environ.get("SWEEP_BATCH", "1"))
 
 
 def main():
@@ -51,13 +53,17 @@ def main():
         keep, descs, flops = [], [], 0.0
         for (cin, cout, k, pad, s, h, w) in probs:
             oh, ow = (h + 2 * pad - k) // s + 1, (w + 2 * pad - k) // s + 1
-            x = dev_from(rng.standard_normal((1, h, w, cin)).astype(np.float32))
-            wt = dev_from((rng.standard_normal((cout, k, k, cin)) * 0.05).astype(np.float32))
+            dt = np.float16 if F16 else np.float32
+            if F16:
+                cin = (cin + 7) // 8 * 8
+            co = (cout + 7) // 8 * 8 if F16 else cout
+            x = dev_from(rng.standard_normal((BATCH, h, w, cin)).astype(dt))
+            wt = dev_from((rng.standard_normal((cout, k, k, cin)) * 0.05).astype(dt))
             b = dev_from(np.zeros(cout, np.float32))
-            y = dev_from(np.zeros((1, oh, ow, cout), np.float32))
+            y = dev_from(np.zeros((BATCH, oh, ow, co), dt))
             keep += [x, wt, b, y]
-            descs.append(conv_desc(x, wt, b, y, 1, h, w, cin, cin, cout, k, pad, s, oh, ow, cout, 0, L.CONV_RELU))
-            flops += 2.0 * oh * ow * cout * cin * k * k
+            descs.append(conv_desc(x, wt, b, y, BATCH, h, w, cin, cin, cout, k, pad, s, oh, ow, co, 0, L.CONV_RELU | (L.CONV_F16 if F16 else 0)))
+            flops += 2.0 * BATCH * oh * ow * cout * cin * k * k
         arr = (L.ConvDesc * len(descs))(*descs)
         ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(descs))), zero=False)
         timed = []
