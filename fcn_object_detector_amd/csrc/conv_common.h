@@ -75,7 +75,7 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 
 // ---- persistent half-float streaming kernel (conv_stream.hip): configurations 32 .. 32 + stream_num_cfgs() - 1 ---------------
-struct StreamCfgInfo { int bm, bn, bk, lds_bytes, threads; };      // bk counts 4-byte words, as in the tiled family
+struct StreamCfgInfo { int bm, bn, bk, lds_bytes, threads, slab_rows, slab_buffers; };      // bk counts 4-byte words, as in the tiled family
 int stream_num_cfgs();
 StreamCfgInfo stream_cfg_info(int idx);
 // launches conv_stream_f16 over the prepared problems of `ga` (tile prefix, ConvP by value); total = number of tiles

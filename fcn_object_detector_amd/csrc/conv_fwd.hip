@@ -1433,25 +1433,29 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
     }
     if (is_stream_cfg(cfg)) {
         // conv_stream_f16: half problems with half outputs, bias + ReLU only, channel counts / strides in whole 16-byte groups,
-        // every problem fed by the scalar-addressed loader (1x1 filters, or each tap's Cin padded to whole chunks, at most 2x)
+        // stride-1 "same" convolutions with 1x1 / 3x3 / 5x5 filters whose slab (the tile's 256 pixels in padded raster order,
+        // plus the taps of a filter row) fits the configuration's slab buffer; 1x1 filters need three slab buffers
         const StreamCfgInfo sc = stream_cfg_info(cfg - kStreamCfg0);
-        const int bke = sc.bk * 2;
         int total = 0;
         for (int i = 0; i < n; ++i) {
             ConvP& q = ps[i];
-            const int taps = q.kh * q.kw, cpt = cdiv(q.Cin, bke);
             const long long xb = (((long long)q.N * q.H * q.W - 1) * q.x_cstride + q.Cin) * 2, wb = (long long)q.Cout * q.K * 2;
             const long long yb = (((long long)q.M - 1) * q.y_cstride + q.y_coffset + q.Cout) * 2;
+            const int k = q.kh, pw = q.W + 2 * q.pad;
+            const int wraps = (sc.bm - 2 + q.W) / q.W;      // image-row ends a tile's pixels can cross
+            const int rows = sc.bm - 1 + 2 * q.pad * wraps + 2 * q.pad + 1;
             if ((q.flags & ~FCN_CONV_RELU) != FCN_CONV_F16 || (q.Cout | q.y_cstride | q.y_coffset) % 8 != 0 || ((uintptr_t)q.y & 15) != 0 ||
                 ((uintptr_t)q.bias & 15) != 0 || xb >= (1ll << 31) || wb >= (1ll << 31) || yb >= (1ll << 31) ||
-                !(taps == 1 || (long long)cpt * bke <= 2ll * q.Cin) || taps > 64)
+                q.kh != q.kw || (k != 1 && k != 3 && k != 5) || q.stride != 1 || q.pad != (k - 1) / 2 || rows > sc.slab_rows ||
+                (k == 1 && sc.slab_buffers < 3) || pw < 16 || (long long)q.N * q.H * pw * pw >= (1ll << 32))
                 return -2;
             q.tiles_m = cdiv(q.M, sc.bm);
             q.tiles_n = cdiv(q.Cout, sc.bn);
             q.tiles_n_magic = q.tiles_n > 1 ? (unsigned)(((1ull << 32) + q.tiles_n - 1) / q.tiles_n) : 0u;
             total += q.tiles_m * q.tiles_n;
             q.tile_end = total;
-            q.lean_chunks = taps * cpt;
+            q.lean_chunks = q.kh * q.kw * cdiv(q.Cin, 64);
+            q.cin_magic24 = (unsigned)(((1ull << 32) + pw - 1) / pw);      // (stream problems: entry / PW of the padded raster)
         }
         return total;
     }
@@ -1623,7 +1627,8 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
     const int total = plan_tiles_cfg(cfg, ps, n);
     FCN_REQUIRE(!(is_stream_cfg(cfg) && (total == -2 || npools || n > kMaxGroup)), FCN_E_UNSUPPORTED,
                 "conv group: configuration %d (persistent half-float streaming kernel) takes at most %d half problems with half outputs, "
-                "bias + ReLU only, Cout / y_cstride / y_coffset multiples of 8, 1x1 filters or taps padded at most 2x, and no poolings", cfg, kMaxGroup);
+                "bias + ReLU only, Cout / y_cstride / y_coffset multiples of 8, stride-1 1x1 / 3x3 / 5x5 filters with pad (k - 1) / 2 on images wide "
+                "enough for its slab buffer (1x1 filters: the configurations with three slab buffers), and no poolings", cfg, kMaxGroup);
     FCN_REQUIRE(total != -2 && !((cfg == kFirst7Cfg || cfg == kDot1x1Cfg) && npools), FCN_E_UNSUPPORTED,
                 "conv group: configuration %d is shape-specific (%d: one 7x7 / stride 2 / pad 3 problem on 4-channel pixels, 33..64 outputs; "
                 "%d: 1x1 / stride 1 float32 problems over the same pixels, at most 32 output channels in slices of 8) and takes no poolings",

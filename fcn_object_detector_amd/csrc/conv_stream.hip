@@ -1,66 +1,56 @@
 // Persistent streaming convolution for half-float activations on gfx950 (BASELINE configs[4]: batch-32 inference).
 //
 // Stands in for the same Caffe ConvolutionLayer::Forward (+ in-place ReLU) as conv_fwd.hip, for the launches of a half-float
-// net whose M = N*OH*OW is large (models/deploy.prototxt at batch 32: M = 25 088 .. 401 408).  Same operands, same layouts
-// (NHWC halves, OHWI halves, f32 bias), same implicit GEMM  out[m][n] = bias[n] + sum_k A[m][k] * Wt[n][k].
+// net whose M = N*OH*OW is large (models/deploy.prototxt at batch 32: M = 25 088 .. 401 408): the stride-1 "same" convolutions
+// (1x1, 3x3 / pad 1, 5x5 / pad 2).  Same operands, same layouts (NHWC halves, OHWI halves, f32 bias), same implicit GEMM
+// out[m][n] = bias[n] + sum_k A[m][k] * Wt[n][k].
 //
-// Why a kernel of its own (round 3, tools/conv_timeline.py + the elimination builds of `make exp`, gpurun_out/r3/):
-// v_mfma_f32_32x32x16_f16 is 16x faster than the f32 instruction, so a tile's K loop is short - conv2/3x3 (K = 576) as
-// 256 x 128 tiles multiplies for 4 us - and everything AROUND the loop decides: with one workgroup per tile the first chunk
-// is usable 3.2 us after the workgroup starts (set-up + one cold memory latency) and the epilogue through LDS (park the
-// accumulators, read them back, 8-byte stores) takes 5.2 us; nothing overlaps them when a 144 KB ring leaves room for one
-// workgroup per CU.  The launch took 196 us with its MFMAs, 182 us without them and without fragment reads, 157 us without
-// any staging.  Here
-//   * workgroups are PERSISTENT (one per CU) and walk tiles v, v + G, ...; the LDS ring never drains: the chunk that follows
-//     a tile's last chunk is the next tile's first, issued by the loading waves D chunks ahead across the tile boundary, so a
-//     tile has no prologue;
-//   * the accumulator is TRANSPOSED - the weights are the MFMA's A operand and the pixels its B operand - and the weight rows
-//     of a 32-channel tile are dealt to the MFMA rows so that a lane ends up with 16 CONSECUTIVE output channels of ONE pixel
-//     (two runs of 8): bias arrives as the C operand of the tile's first MFMA, ReLU and rounding run on registers, and each
-//     lane stores 16 bytes per run straight to HBM.  No LDS in the epilogue, no barrier, and the loaders keep streaming the
-//     next tile meanwhile;
-//   * roles are split as in conv_fwd.hip's cfg 23-29: waves 0-3 multiply (fragment reads + MFMAs only, up to 4 x 2 MFMA
-//     tiles = 128 x 64 outputs per wave, the fragments of the k-step after the current one in flight), waves 4-7 load
-//     (scalar-addressed "lean" loader: tap / channel position in SGPRs, `buffer_load ... lds` with out-of-range offsets as the
-//     zero fill); one counted s_waitcnt vmcnt + one raw s_barrier per chunk;
-//   * workgroup b's tiles are consecutive on its XCD (b % 8 labels the XCD: tiles that share an A or B operand meet in one L2).
-// Takes: half inputs and outputs, flags within {RELU}, output channel counts / strides / offsets that are multiples of 8,
-// every problem lean (1x1 filters, or each tap's Cin padded to whole chunks at a cost of at most 2x).  Everything else stays
-// with the tiled family.
+// Why a kernel of its own (round 3; tools/conv_timeline.py, the elimination builds of `make exp`, tools/probes/stage_swz_probe.hip;
+// records in gpurun_out/r3 and DESIGN.md 4.7): v_mfma_f32_32x32x16_f16 is 16x faster than the f32 instruction, so what bounds a
+// half-float launch is everything AROUND the MFMAs.  conv2/3x3 as 256 x 128 tiles of the tiled family took 196 us with its MFMAs,
+// 182 us without MFMAs and fragment reads, 157 us without any staging: per tile 3.2 us until the first chunk is usable and 5.2 us
+// of epilogue through LDS, and with one workgroup per CU nothing overlaps them.  A first persistent version (im2col chunks, halo
+// tests per piece) still took 57 us with NO loads, reads, MFMAs or stores at all: ~100 vector instructions of loader bookkeeping
+// per chunk set the chunk period.  Here
+//   * workgroups are PERSISTENT (one per CU) and walk tiles v, v + G, ...; the LDS rings never drain: loaders run ahead across
+//     tile boundaries, so a tile has no prologue;
+//   * a tile is 256 consecutive output pixels.  For filter row r and a 64-channel chunk the input pixels under the tile are
+//     staged ONCE as a SLAB in "padded raster order" (every image row followed by 2 pad zero pixels): the kw taps of the row
+//     read the same slab kw times at row offsets 0 .. kw-1 - no halo tests and no re-staging per tap (3x / 5x less activation
+//     traffic than im2col chunks), and a slab piece costs the loader four vector instructions;
+//   * loading is split: waves 4-5 stage slabs, waves 6-7 stage weight chunks (BN channels x 64 k), each with its own
+//     vector-memory counter, so one counted s_waitcnt per role; all LDS rows are 128 bytes (64-byte rows halve the LDS-DMA
+//     rate: a 128-byte line is then fetched by two instructions);
+//   * the accumulator is TRANSPOSED - weights are the MFMA's A operand, pixels its B operand - and the weight rows of a
+//     32-channel tile are dealt to the MFMA rows so that a lane ends up with 16 consecutive output channels of ONE pixel (two
+//     runs of 8): the accumulators start as the bias, ReLU and rounding run on registers, each lane stores
+//     16 bytes per run straight to HBM.  No LDS in the epilogue, no barrier; the loaders stream the next tile meanwhile;
+//   * waves 0-3 multiply (128 x 32 WTN outputs each = 4 x WTN MFMA tiles; fragment reads + MFMAs + one address instruction per
+//     read, the fragments of the next k-step in flight); one raw s_barrier per chunk;
+//   * workgroup b's tiles are consecutive on its XCD (b % 8 labels the XCD): tiles that share operands meet in one L2.
+// Takes (plan_tiles_cfg): half inputs and outputs, flags within {RELU}, stride 1 with pad = (k - 1) / 2 and k in {1, 3, 5}, Cout /
+// y_cstride / y_coffset multiples of 8, image rows wide enough that a tile's slab fits.  Everything else stays with the tiled family.
 #include "conv_common.h"
 
 using namespace fcn;
 
 namespace {
 
-template <int WTM_, int WTN_, int BK_, int NBUF_>
-struct SCfg {
-    static constexpr int WTM = WTM_, WTN = WTN_, BK = BK_, NBUF = NBUF_;
-    static constexpr int NW = 4;                        // multiplying waves (2 x 2) = loading waves
-    static constexpr int NT = 64 * NW * 2;
-    static constexpr int BM = 64 * WTM, BN = 64 * WTN;  // pixels x output channels of a tile
-    static constexpr int SEGS = BK / 4;                 // 16-byte slots per staged row
-    static constexpr int RPI = 256 / BK;                // rows one LDS-DMA wave-instruction (1 KiB) fills
-    static constexpr int STEP = RPI * NW;
-    static constexpr int IA = BM / STEP, IB = BN / STEP, INST = IA + IB;
-    static constexpr int D = NBUF - 1;                  // chunks in flight
-    static constexpr int KS = BK / 8;                   // k-steps (one v_mfma_f32_32x32x16_f16 per MFMA tile) per chunk
-    static constexpr int BKE = BK * 2;                  // halves of K per chunk
-    static constexpr int BUF_BYTES = (BM + BN) * BK * 4;
-    static constexpr int LDS_BYTES = NBUF * BUF_BYTES;
-    static_assert(BK == 16 || BK == 32, "row swizzle: 4 or 8 slots per row");
-    static_assert(KS % 2 == 0, "the fragment parity of a k-step must not depend on the chunk");
-    static_assert(BM % STEP == 0 && BN % STEP == 0 && STEP % 16 == 0, "rows split into whole wave-instructions; a lane's rows agree mod 16");
-    static_assert(NBUF >= 3 && INST * (D - 1) <= 63, "vmcnt is a 6-bit counter");
-    static_assert(LDS_BYTES <= 160 * 1024, "exceeds the CU's 160 KiB LDS");
-    static_assert(WTM <= 4 && WTN <= 2, "fragment reads are written out for at most 4 x 2 MFMA tiles per wave");
-};
+constexpr int kBM = 256;          // pixels per tile
+constexpr int kChunkK = 64;       // halves of K per chunk (128-byte LDS rows)
 
-// what a multiplying wave keeps of a problem
-struct MulP {
-    f16_t* y;
-    const float* bias;
-    int M, Cout, y_cstride, y_coffset, relu, nch, m0, n0;
+template <int WTN_, int SRP_, int NA_, int NB_>
+struct SCfg {
+    static constexpr int WTN = WTN_, SRP = SRP_, NA = NA_, NB = NB_;
+    static constexpr int WTM = 4, BM = kBM, BN = 64 * WTN;
+    static constexpr int NT = 512;
+    static constexpr int NPA = SRP / 2;                 // slab pieces (1 KiB = 8 rows) per slab-loading wave
+    static constexpr int NPB = BN / 16;                 // weight pieces per weight-loading wave and chunk
+    static constexpr int SLAB_BYTES = SRP * 1024, WCH_BYTES = BN * 128;
+    static constexpr int LDS_BYTES = NA * SLAB_BYTES + NB * WCH_BYTES;
+    static_assert(SRP % 2 == 0 && NA >= 2 && NB >= 3, "ring shapes");
+    static_assert(NPA * (NA - 1) <= 63 && NPB * (NB - 1) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(LDS_BYTES <= 160 * 1024, "exceeds the CU's 160 KiB LDS");
 };
 
 template <class C>
@@ -68,8 +58,8 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                                                          const int te5, const int te6, const int te7, const int total, const int unused,
                                                          const GroupArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int WTM = C::WTM, WTN = C::WTN, BK = C::BK, NBUF = C::NBUF, NW = C::NW, BM = C::BM, BN = C::BN, SEGS = C::SEGS, RPI = C::RPI;
-    constexpr int STEP = C::STEP, IA = C::IA, IB = C::IB, INST = C::INST, D = C::D, KS = C::KS, BKE = C::BKE, BUF = C::BUF_BYTES;
+    constexpr int WTM = C::WTM, WTN = C::WTN, NA = C::NA, NB = C::NB, NPA = C::NPA, NPB = C::NPB, BM = C::BM, BN = C::BN;
+    constexpr int SLAB = C::SLAB_BYTES, WCH = C::WCH_BYTES, WRING0 = NA * SLAB;
     __shared__ __attribute__((aligned(16))) char smem[C::LDS_BYTES];
     typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
@@ -80,8 +70,6 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_loader = wid_all >= NW;
-    const int wid = wid_all & (NW - 1);
     const int G = gridDim.x;
     // Blocks b and b + 8 share an XCD (round-robin placement: observed, used for speed only): give the blocks of one XCD
     // consecutive tiles, so that the tiles that share operand rows (the column tiles of one row of pixels) meet in one L2.
@@ -91,7 +79,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
     }
     // tile -> (problem index, first tile of that problem): scalar compares on the preloaded prefix table
-    auto find_problem = [&](const int tile, int& pi, int& begin) {
+    auto find_problem = [&](const int tile, int& pi, int& begin) __attribute__((always_inline)) {
         pi = 0;
         begin = 0;
 #pragma unroll
@@ -104,10 +92,14 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         pi = __builtin_amdgcn_readfirstlane(pi);
         begin = __builtin_amdgcn_readfirstlane(begin);
     };
-    auto load_problem = [&](const int pi) {
+    auto load_problem = [&](const int pi) __attribute__((always_inline)) {      // (ends in s_waitcnt lgkmcnt(0): scalar loads do not return in order with LDS reads)
         u32x16 ra, rb;
         u32x8 rc;
-        const ConvP __attribute__((address_space(4)))* pbase = &ka->p[pi];
+        // (the address is wave-uniform by construction; say so, or a use under a branch the compiler cannot prove uniform lands in VGPRs)
+        const unsigned long long pa = (unsigned long long)&ka->p[pi];
+        const unsigned long long pu = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(pa >> 32)) << 32) |
+                                      (unsigned)__builtin_amdgcn_readfirstlane((int)pa);
+        const ConvP __attribute__((address_space(4)))* pbase = (const ConvP __attribute__((address_space(4)))*)pu;
         asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx8 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
                      : "=&s"(ra), "=&s"(rb), "=&s"(rc)
                      : "s"(pbase)
@@ -118,195 +110,307 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         __builtin_memcpy((char*)&prob + 128, &rc, 32);
         return prob;
     };
-    constexpr int OOB = (int)0x80000000u;      // >= num_records of every buffer (operands and outputs stay below 2 GiB: stream_problem_ok)
+    // The barrier walker every loading wave keeps: which chunk the multiplying waves start at the next barrier.
+    struct Walk {
+        int tile, kw, q, mac_left;
+    };
+    auto walk_begin = [&](Walk& w, const int tile) __attribute__((always_inline)) {
+        w.tile = tile;
+        w.q = 0;
+        w.kw = 1;
+        w.mac_left = 1;
+        if (tile < total) {
+            int pi, begin;
+            find_problem(tile, pi, begin);
+            const int kh = ka->p[pi].kh, kw = ka->p[pi].kw, cin = ka->p[pi].Cin;
+            w.kw = kw;
+            w.mac_left = kh * ((cin + kChunkK - 1) / kChunkK);
+        }
+    };
+    auto walk_step = [&](Walk& w) __attribute__((always_inline)) {
+        if (++w.q == w.kw) {
+            w.q = 0;
+            if (--w.mac_left == 0) walk_begin(w, w.tile + G);
+        }
+    };
+    constexpr int OOB = (int)0x80000000u;      // >= num_records of every buffer (operands and outputs stay below 2 GiB: plan_tiles_cfg)
 
-    if (is_loader) {
-        // ---- loading waves: the scalar-addressed loader of conv_fwd.hip, walking tile after tile ---------------------------------
-        const int lrow = RPI * wid + lane / SEGS;                  // row of instruction 0
-        const int lseg = (lane % SEGS) ^ swz<SEGS>(lrow);          // k-segment this lane fetches (the same for all its rows)
-        const int lane_c = lseg * 8;                               // channel of that segment inside a chunk
-        char* const lds_wave = smem + RPI * wid * BK * 4;
-        int a_iy0[IA], a_ix0[IA], a_vo[IA], b_vo[IB];
-        int ti = v;                                                // tile whose chunks are being issued
+    if (wid_all >= 6) {
+        // ---- weight-loading waves: chunk (r, cc, q) of a tile = rows n0 .. n0 + BN - 1 of the bank, 64 k each ---------------------
+        const int wb = wid_all - 6;
+        // piece p = wb + 2 t holds bank rows 8 p .. 8 p + 7; lane -> row 8 p + lane / 8, k-segment (lane % 8) ^ swz(row)
+        // ((row >> 1) & 7 = (4 (p & 1) + (lane >> 4)) & 7 and p & 1 = wb: one segment per lane for all its pieces)
+        const int lseg = (lane & 7) ^ ((4 * wb + (lane >> 4)) & 7);
+        const int lane_c = lseg * 8;
+        char* const lds_wave = smem + WRING0 + wb * 1024;
+        int b_vo[NPB];
+        int ti = v, r = 0, cc = 0, q = 0, kh = 1, kw = 1, ncc = 1, cin = 0;
         bool live = true;
-        const f16_t* px = nullptr;
         const f16_t* pw = nullptr;
-        int x_bytes = 0, w_bytes = 0, pH = 0, pW = 0, pCin = 0, pkw = 0, pxcs = 0;
-        int s_kr = 0, s_kq = 0, s_kc = 0, s_koff = 0, s_kb = 0, s_left = 0;
-        auto setup = [&]() {
+        int w_bytes = 0;
+        auto setup = [&]() __attribute__((always_inline)) {
             int pi, begin;
             find_problem(ti, pi, begin);
             const ConvP p = load_problem(pi);
             const int lt = ti - begin;
             const int tile_m = fast_div(lt, p.tiles_n_magic);
-            const int tile_n = lt - tile_m * p.tiles_n;
-            const int m0 = tile_m * BM, n0 = tile_n * BN;
+            const int n0 = (lt - tile_m * p.tiles_n) * BN;
 #pragma unroll
-            for (int i = 0; i < IA; ++i) {
-                const int m = m0 + STEP * i + lrow;
-                const bool ok = m < p.M;
-                const int mm = ok ? m : 0;
-                const int t = fast_div(mm, p.ow_magic);
-                const int ox = mm - t * p.OW;
-                const int img = fast_div(t, p.oh_magic);
-                const int oy = t - img * p.OH;
-                a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);      // rows past M never pass the bounds test
-                a_ix0[i] = ox * p.stride - p.pad;
-                a_vo[i] = (((img * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.x_cstride + lane_c) * 2;
+            for (int t = 0; t < NPB; ++t) {
+                const int n = n0 + 8 * (wb + 2 * t) + (lane >> 3);
+                b_vo[t] = n < p.Cout ? (n * p.K + lane_c) * 2 : OOB;
             }
-#pragma unroll
-            for (int i = 0; i < IB; ++i) {
-                const int n = n0 + STEP * i + lrow;
-                b_vo[i] = n < p.Cout ? (n * p.K + lane_c) * 2 : OOB;
-            }
-            px = reinterpret_cast<const f16_t*>(p.x);
             pw = reinterpret_cast<const f16_t*>(p.w);
-            x_bytes = (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * 2);
             w_bytes = p.Cout * p.K * 2;
-            pH = p.H; pW = p.W; pCin = p.Cin; pkw = p.kw; pxcs = p.x_cstride;
-            s_kr = s_kq = s_kc = s_koff = s_kb = 0;
-            s_left = p.lean_chunks;
+            kh = p.kh; kw = p.kw; cin = p.Cin;
+            ncc = (p.Cin + kChunkK - 1) / kChunkK;
+            r = cc = q = 0;
         };
-        auto issue_chunk = [&](const int buf) {
-            if (s_left == 0 && live) {      // the tile is issued: on to the next one (or to all-zero chunks behind the last)
-                ti += G;
-                if (ti < total) setup();
-                else live = false;
-            }
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(px), 0, x_bytes, 0x00020000);
+        auto issue_chunk = [&](const int slot) __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(pw), 0, w_bytes, 0x00020000);
-            const int thr = live ? pCin - s_kc : 0;      // channels of this tap the chunk still covers (0: behind the last tile)
-            const bool cvalid = lane_c < thr;
-            char* const dst = lds_wave + buf * BUF;
+            const int soff = ((r * kw + q) * cin + cc * kChunkK) * 2;
+            const bool cvalid = live && lane_c < cin - cc * kChunkK;      // (the last chunk of a tap may cover fewer than 64 channels)
+            char* const dst = lds_wave + slot * WCH;
 #pragma unroll
-            for (int i = 0; i < IA; ++i) {
-                const bool ok = (int)cvalid & (int)((unsigned)(a_iy0[i] + s_kr) < (unsigned)pH) & (int)((unsigned)(a_ix0[i] + s_kq) < (unsigned)pW);
-                int vo = ok ? a_vo[i] + s_koff : OOB;
-                asm volatile("" : "+v"(vo));      // one select, one DMA
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dst + STEP * i * BK * 4), 16, vo, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < IB; ++i) {
-                int vo = cvalid ? b_vo[i] + s_kb : OOB;
+            for (int t = 0; t < NPB; ++t) {
+                int vo = cvalid ? b_vo[t] : OOB;
                 asm volatile("" : "+v"(vo));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + (BM + STEP * i) * BK * 4), 16, vo, 0, 0, 0);
+#ifndef FCN_EXP_NOLOAD
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + 2048 * t), 16, vo, soff, 0, 0);
+#endif
             }
-            // the next chunk's K position: scalar unit only
-            --s_left;
-            const bool nt = s_kc + BKE >= pCin;                  // the next chunk starts the next tap
-            s_kb += (nt ? pCin - s_kc : BKE) * 2;                // weights are [tap][Cin]: the tap's end, or one chunk on
-            const int kq1 = s_kq + (nt ? 1 : 0);
-            const bool wq = kq1 == pkw;
-            s_kq = wq ? 0 : kq1;
-            s_kr += wq ? 1 : 0;
-            s_kc = nt ? 0 : s_kc + BKE;
-            s_koff = nt ? (s_kr * pW + s_kq) * pxcs * 2 : s_koff + BKE * 2;
-        };
-        setup();
-        // the barrier walker: which tile the multipliers are in (its chunk count decides when the workgroup is done)
-        int tb = v, left_b = s_left;
-        int buf_issue = 0;
-        auto next = [](int b) { return b + 1 == NBUF ? 0 : b + 1; };
-#pragma unroll 1
-        for (int c = 0; c < D; ++c) {
-            issue_chunk(buf_issue);
-            buf_issue = next(buf_issue);
-        }
-        wait_vmcnt<INST*(D - 1)>();        // chunk 0 landed (this wave's pieces) ...
-        __builtin_amdgcn_s_barrier();      // ... and everybody else's
-#pragma unroll 1
-        while (tb < total) {
-            wait_vmcnt<INST*(D - 2)>();    // the chunk after the one the multipliers start now has landed
-            __builtin_amdgcn_s_barrier();  // the multipliers are done with the chunk before it: its slot takes the chunk D ahead
-            asm volatile("" ::: "memory");
-            issue_chunk(buf_issue);
-            buf_issue = next(buf_issue);
-            if (--left_b == 0) {
-                tb += G;
-                if (tb < total) {
-                    int pi, begin;
-                    find_problem(tb, pi, begin);
-                    left_b = ka->p[pi].lean_chunks;
+            if (live) {      // next chunk: taps of the row, then channel chunks, then filter rows, then the next tile
+                if (++q == kw) {
+                    q = 0;
+                    if (++cc == ncc) {
+                        cc = 0;
+                        if (++r == kh) {
+                            ti += G;
+                            if (ti < total) setup();
+                            else live = false;
+                        }
+                    }
                 }
             }
+        };
+        setup();
+        Walk wk;
+        walk_begin(wk, v);
+        int slot = 0;
+        auto next = [](int b) __attribute__((always_inline)) { return b + 1 == NB ? 0 : b + 1; };
+#pragma unroll 1
+        for (int c = 0; c < NB - 1; ++c) {
+            issue_chunk(slot);
+            slot = next(slot);
+        }
+        wait_vmcnt<NPB*(NB - 2)>();        // chunk 0 landed
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        while (wk.tile < total) {
+            wait_vmcnt<NPB*(NB - 3)>();    // the chunk after the one the multipliers start now has landed
+            __builtin_amdgcn_s_barrier();  // the multipliers are done with the chunk before it: its slot takes the chunk NB - 1 ahead
+            asm volatile("" ::: "memory");
+            issue_chunk(slot);
+            slot = next(slot);
+            walk_step(wk);
         }
         wait_vmcnt<0>();                   // the all-zero chunks behind the last tile
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    } else if (wid_all >= 4) {
+        // ---- slab-loading waves: slab (r, cc) of a tile = padded-raster pixels Pbase .. Pbase + 8 SRP - 1 of input row offset r ---
+        const int wa = wid_all - 4;
+        const int lseg = (lane & 7) ^ ((4 * wa + (lane >> 4)) & 7);      // as for the weight pieces: piece p = wa + 2 t, row 8 p + lane / 8
+        const int lane_c = lseg * 8;
+        char* const lds_wave = smem + wa * 1024;
+        int off_c[NPA], vmask[NPA];      // byte offset of the lane's segment in the CENTRE row (r = pad); bit r: row r exists for it
+        int ti = v, r = 0, cc = 0, kh = 1, ncc = 1, cin = 0, pad = 0, row_bytes = 0;
+        bool live = true;
+        const f16_t* px = nullptr;
+        int x_bytes = 0;
+        auto setup = [&]() __attribute__((always_inline)) {
+            int pi, begin;
+            find_problem(ti, pi, begin);
+            const ConvP p = load_problem(pi);
+            const int lt = ti - begin;
+            const int tile_m = fast_div(lt, p.tiles_n_magic);
+            const int m0 = tile_m * BM;
+            // padded raster: P(img, y, x) = (img H + y) PW + x + pad, PW = W + 2 pad; the slab starts pad entries in front of P(m0)
+            const int PW = p.W + 2 * p.pad;
+            const int t0 = fast_div(m0, p.ow_magic);
+            const int pbase = t0 * PW + (m0 - t0 * p.W);      // = P(m0) - pad
+            const int rows_total = p.N * p.H;
+            // The wave's pieces are 16 slab rows apart: ONE division for its first row, then a step of 16 entries with a wrap at the
+            // end of an image row (PW >= 16, plan_tiles_cfg) - this runs once per tile on the critical path of the slab that follows.
+            const int pj = pbase + 8 * wa + (lane >> 3);
+            int t1 = fast_div(pj, p.cin_magic24);      // (stream problems: ceil(2^32 / PW), plan_tiles_cfg)
+            int xp = pj - t1 * PW;                      // 0 .. PW - 1: entry inside the padded image row
+            int y = t1 - fast_div(t1, p.oh_magic) * p.H;
+            int off = ((t1 * p.W + xp - p.pad) * p.x_cstride + lane_c) * 2;
+            const int step_off = 16 * p.x_cstride * 2, wrap_off = 2 * p.pad * p.x_cstride * 2;
+#pragma unroll
+            for (int t = 0; t < NPA; ++t) {
+                const bool okx = (unsigned)(xp - p.pad) < (unsigned)p.W && t1 < rows_total;
+                const int lo = max(p.pad - y, 0), hi = min(p.H + p.pad - y, p.kh);      // filter rows whose input row exists: lo .. hi - 1
+                vmask[t] = (okx && hi > lo) ? (1 << hi) - (1 << lo) : 0;
+                off_c[t] = off;
+                xp += 16;
+                off += step_off;
+                const bool wrap = xp >= PW;
+                xp -= wrap ? PW : 0;
+                off -= wrap ? wrap_off : 0;
+                t1 += wrap ? 1 : 0;
+                y += wrap ? 1 : 0;
+                y -= y >= p.H ? p.H : 0;
+            }
+            px = reinterpret_cast<const f16_t*>(p.x);
+            x_bytes = (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * 2);
+            kh = p.kh; cin = p.Cin; pad = p.pad;
+            ncc = (p.Cin + kChunkK - 1) / kChunkK;
+            row_bytes = p.W * p.x_cstride * 2;
+            r = cc = 0;
+        };
+        auto issue_slab = [&](const int buf) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(px), 0, x_bytes, 0x00020000);
+            const int soff = cc * kChunkK * 2;
+            const int roff = (r - pad) * row_bytes;
+            const bool cvalid = live && lane_c < cin - cc * kChunkK;
+            const int bit = 1 << r;
+            char* const dst = lds_wave + buf * SLAB;
+#pragma unroll
+            for (int t = 0; t < NPA; ++t) {
+                int vo = (cvalid && (vmask[t] & bit)) ? off_c[t] + roff : OOB;
+                asm volatile("" : "+v"(vo));
+#ifndef FCN_EXP_NOLOAD
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dst + 2048 * t), 16, vo, soff, 0, 0);
+#endif
+            }
+            if (live) {
+                if (++cc == ncc) {
+                    cc = 0;
+                    if (++r == kh) {
+                        ti += G;
+                        if (ti < total) setup();
+                        else live = false;
+                    }
+                }
+            }
+        };
+        setup();
+        Walk wk;
+        walk_begin(wk, v);
+        int buf = 0;
+        auto next = [](int b) __attribute__((always_inline)) { return b + 1 == NA ? 0 : b + 1; };
+#pragma unroll 1
+        for (int c = 0; c < NA - 1; ++c) {      // slabs 0 .. NA - 2: the lead the loop keeps
+            issue_slab(buf);
+            buf = next(buf);
+        }
+        wait_vmcnt<NPA*(NA - 2)>();        // slab 0 landed
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        while (wk.tile < total) {
+            // In front of the barrier that starts the LAST chunk of slab j the multipliers' next fragments may come from slab j + 1:
+            // it must have landed.  Slabs are issued behind the FIRST barrier of a slab (NA - 1 ahead), so the slabs younger than
+            // j + 1 that are in flight here number NA - 2 - or NA - 3 when the slab has a single chunk (1x1 filters: its own issue
+            // comes behind this very barrier; plan_tiles_cfg keeps 1x1 problems away from two-buffer configurations).
+            if (wk.q == wk.kw - 1) {
+                if (wk.kw == 1) wait_vmcnt<NPA*(NA >= 3 ? NA - 3 : 0)>();
+                else wait_vmcnt<NPA*(NA - 2)>();
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (wk.q == 0) {
+                issue_slab(buf);
+                buf = next(buf);
+            }
+            walk_step(wk);
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     } else {
         // ---- multiplying waves -----------------------------------------------------------------------------------------------------
-        const int wm = wid >> 1, wn = wid & 1;
-        const int fi = lane & 31, kh = lane >> 5;
+        const int wm = wid_all >> 1, wn = wid_all & 1;
+        const int fi = lane & 31, kh_ = lane >> 5;
         // MFMA row i of a 32-channel tile multiplies weight row tau(i): register r of half-wave kh then holds channel
         // 8 kh + (r & 7) + 16 (r >> 3) of the tile - two runs of 8 consecutive channels per lane.
         const int tau = (fi & 3) + 4 * ((fi >> 3) & 1) + 8 * ((fi >> 2) & 1) + 16 * (fi >> 4);
         const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
-        unsigned fx[KS], fw[KS];      // byte address of this lane's pixel / weight fragment inside ring slot 0, per k-step
-#pragma unroll
-        for (int st = 0; st < KS; ++st) {
-            fx[st] = lds0 + (unsigned)((wm * 32 * WTM + fi) * BK * 4 + (((2 * st + kh) ^ swz<SEGS>(fi)) * 16));
-            fw[st] = lds0 + (unsigned)((BM + wn * 32 * WTN + tau) * BK * 4 + (((2 * st + kh) ^ swz<SEGS>(tau)) * 16));
-        }
-        v4f xf[2][WTM], wf[2][WTN];
-        auto ds_read = [](v4f& dst, unsigned addr, auto off) {
+        // k-segment 2 st + kh of a row whose swizzle term is sw sits at ((2 st + kh) ^ sw) * 16 = (32 st) ^ (((sw ^ kh) & 7) * 16): the
+        // step rides in the address instruction as a constant (v_xad_u32)
+        const unsigned kh16 = (unsigned)kh_ * 16u;
+        const unsigned wrow = lds0 + (unsigned)(WRING0 + (wn * 32 * WTN + tau) * 128), xw = (unsigned)((((tau >> 1) ^ kh_) & 7) * 16);
+        v4f xf[WTM], wf[2][WTN];      // pixel fragments: one set, each re-read behind the MFMAs that consumed it; weight fragments: two sets
+        auto ds_read = [](v4f& dst, unsigned addr, auto off) __attribute__((always_inline)) {
+#ifdef FCN_EXP_NOREAD
+            asm volatile("" : "=v"(dst) : "v"(addr));
+            return;
+#endif
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value));
         };
-        auto read_step = [&](const int par, const int st, const unsigned slot_bytes) {
-            const unsigned ax = fx[st] + slot_bytes, aw = fw[st] + slot_bytes;
+        // pixel fragment addressing of a chunk: slab row of tile i's pixel + tap q, as a byte address and its swizzle term
+        unsigned rowb[WTM], xk[WTM];            // of the chunk whose fragments are read next
+        int rho[WTM], rho_nt[WTM];              // slab row of this lane's pixel per MFMA tile: this tile / the next tile
+        auto chunk_addr = [&](const int (&rh)[WTM], const int q, const unsigned abase) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) {
+                const unsigned rq = (unsigned)(rh[i] + q);
+                rowb[i] = lds0 + abase + rq * 128u;
+                xk[i] = (((rq >> 1) & 7u) << 4) ^ kh16;
+            }
+        };
+        auto read_w = [&](const int par, const int st, const unsigned wslot) __attribute__((always_inline)) {
+            const unsigned aw = (xw ^ (unsigned)(32 * st)) + (wrow + wslot);
 #pragma unroll
             for (int j = 0; j < WTN; ++j) {
                 if (j == 0) ds_read(wf[par][0], aw, std::integral_constant<int, 0>{});
-                if (j == 1) ds_read(wf[par][WTN > 1 ? 1 : 0], aw, std::integral_constant<int, 32 * BK * 4>{});
-            }
-#pragma unroll
-            for (int i = 0; i < WTM; ++i) {
-                if (i == 0) ds_read(xf[par][0], ax, std::integral_constant<int, 0>{});
-                if (i == 1) ds_read(xf[par][WTM > 1 ? 1 : 0], ax, std::integral_constant<int, 32 * BK * 4>{});
-                if (i == 2) ds_read(xf[par][WTM > 2 ? 2 : 0], ax, std::integral_constant<int, 64 * BK * 4>{});
-                if (i == 3) ds_read(xf[par][WTM > 3 ? 3 : 0], ax, std::integral_constant<int, 96 * BK * 4>{});
+                if (j == 1) ds_read(wf[par][WTN > 1 ? 1 : 0], aw, std::integral_constant<int, 32 * 128>{});
             }
         };
-        // LDS operations of a wave return in order: all but the WTM + WTN reads issued last (the next step's) are done.  The
-        // fragment registers are pinned across the wait and a scheduling barrier follows: hipcc moves register-only MFMAs
-        // past a bare inline-asm s_waitcnt.
-        auto step_landed = [&](const int par, auto pending) {
+        auto read_x = [&](const int i, const int st) __attribute__((always_inline)) {
+            ds_read(xf[i], (xk[i] ^ (unsigned)(32 * st)) + rowb[i], std::integral_constant<int, 0>{});
+        };
+        // LDS operations of a wave return in order.  In front of the MFMAs of pixel tile i the reads still allowed in flight are the
+        // WTM - 1 pixel fragments and WTN weight fragments issued after the ones it needs: one constant count for every wait of the
+        // loop.  The fragment registers are pinned across the wait and a scheduling barrier follows: hipcc moves register-only
+        // MFMAs past a bare inline-asm s_waitcnt.
+        auto frag_landed = [&](const int par, const int i, auto pending) __attribute__((always_inline)) {
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(pending)::value) : "memory");
-#pragma unroll
-            for (int i = 0; i < WTM; ++i) asm volatile("" : "+v"(xf[par][i]));
+            asm volatile("" : "+v"(xf[i]));
 #pragma unroll
             for (int j = 0; j < WTN; ++j) asm volatile("" : "+v"(wf[par][j]));
             __builtin_amdgcn_sched_barrier(0);
         };
         f32x16 acc[WTM][WTN], biasv[WTN];
-        auto mfma_step = [&](const int par, const bool first) {
-#pragma unroll
-            for (int i = 0; i < WTM; ++i)
+        // first: the tile's first k-step - the bias of the lane's channels is the C operand (a scalar branch around the MFMAs of a
+        // pair; biasv is dead behind that step: the next tile's is fetched into it during this tile's last chunk, in front of the
+        // tile's stores - the vector-memory counter retires in order, so waiting for those loads never waits for the stores)
+        auto mfma_pair = [&](const int par, const int i, const bool first) __attribute__((always_inline)) {
+#ifdef FCN_CONV_NOMFMA
+            return;
+#endif
+            if (first) {
 #pragma unroll
                 for (int j = 0; j < WTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, wf[par][j]), __builtin_bit_cast(v8h, xf[par][i]),
-                                                                       first ? biasv[j] : acc[i][j], 0, 0, 0);
-        };
-        unsigned slot_cur = 0;      // byte offset of the current chunk's ring slot
-        auto chunk = [&](auto first_c) {
-            constexpr bool FIRST = decltype(first_c)::value;
-            __builtin_amdgcn_s_barrier();      // the next chunk is in LDS too (and the loaders may refill the previous chunk's slot)
-            asm volatile("" ::: "memory");
-            const unsigned slot_next = slot_cur + BUF == (unsigned)(NBUF * BUF) ? 0u : slot_cur + BUF;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, wf[par][j]), __builtin_bit_cast(v8h, xf[i]), biasv[j], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int st = 0; st < KS; ++st) {
-                if (st + 1 < KS) read_step((st + 1) & 1, st + 1, slot_cur);
-                else read_step(0, 0, slot_next);
-                step_landed(st & 1, std::integral_constant<int, WTM + WTN>{});
-                mfma_step(st & 1, FIRST && st == 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int j = 0; j < WTN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, wf[par][j]), __builtin_bit_cast(v8h, xf[i]), acc[i][j], 0, 0, 0);
             }
-            slot_cur = slot_next;
         };
-        // a tile's problem, as far as this role needs it
-        auto mul_problem = [&](const int tile) {
+        // what this role keeps of a tile's problem
+        struct MulP {
+            f16_t* y;
+            const float* bias;
+            int M, Cout, y_cstride, y_coffset, relu, m0, n0, kw, nch, W, PW;
+            unsigned ow_magic;
+        };
+        auto mul_problem = [&](const int tile) __attribute__((always_inline)) {
             int pi, begin;
             find_problem(tile, pi, begin);
-            const ConvP p = load_problem(pi);      // (ends in s_waitcnt lgkmcnt(0): the scalar loads do not return in order with the LDS reads)
+            const ConvP p = load_problem(pi);
             const int lt = tile - begin;
             const int tile_m = fast_div(lt, p.tiles_n_magic);
             MulP q;
@@ -314,18 +418,31 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             q.bias = p.bias;
             q.M = p.M; q.Cout = p.Cout; q.y_cstride = p.y_cstride; q.y_coffset = p.y_coffset;
             q.relu = p.flags & FCN_CONV_RELU;
-            q.nch = p.lean_chunks;
             q.m0 = tile_m * BM;
             q.n0 = (lt - tile_m * p.tiles_n) * BN;
+            q.kw = p.kw;
+            q.nch = p.kh * ((p.Cin + kChunkK - 1) / kChunkK) * p.kw;
+            q.W = p.W; q.PW = p.W + 2 * p.pad; q.ow_magic = p.ow_magic;
             return q;
         };
-        // bias of this lane's channels as the C operand of the tile's first MFMAs (out-of-range channels read 0; no bias: 0 records)
-        auto load_bias = [&](const MulP& q) {
+        // slab row of this lane's pixel in MFMA tile i: P(m) - P(m0); the tap offset q is added per chunk
+        auto tile_rows = [&](const MulP& q, int (&rh)[WTM]) __attribute__((always_inline)) {
+            const int t0 = fast_div(q.m0, q.ow_magic), x0 = q.m0 - t0 * q.W;
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) {
+                int m = q.m0 + wm * 32 * WTM + 32 * i + fi;
+                m = m < q.M ? m : q.M - 1;      // (pixels past M: any row of the slab, the results are not stored)
+                const int t = fast_div(m, q.ow_magic);
+                rh[i] = (t - t0) * q.PW + (m - t * q.W) - x0;
+            }
+        };
+        // bias of this lane's channels, what a tile's accumulators start from (out-of-range channels read 0; no bias: 0 records)
+        auto load_bias = [&](const MulP& q) __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.bias ? q.bias : reinterpret_cast<const float*>(q.y)), 0,
                                                                                 q.bias ? q.Cout * 4 : 0, 0x00020000);
 #pragma unroll
             for (int j = 0; j < WTN; ++j) {
-                const int c0 = q.n0 + wn * 32 * WTN + 32 * j + 8 * kh;
+                const int c0 = q.n0 + wn * 32 * WTN + 32 * j + 8 * kh_;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {      // channels c0 + 0..3, 4..7, 16..19, 20..23
                     const v4f b4 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, (c0 + 4 * (g & 1) + 16 * (g >> 1)) * 4, 0, 0));
@@ -334,7 +451,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 }
             }
         };
-        auto epilogue = [&](const MulP& q) {
+        auto epilogue = [&](const MulP& q) __attribute__((always_inline)) {
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
@@ -346,7 +463,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 const int row_off = (m * q.y_cstride + q.y_coffset) * 2;
 #pragma unroll
                 for (int j = 0; j < WTN; ++j) {
-                    const int c0 = q.n0 + wn * 32 * WTN + 32 * j + 8 * kh;
+                    const int c0 = q.n0 + wn * 32 * WTN + 32 * j + 8 * kh_;
 #pragma unroll
                     for (int run = 0; run < 2; ++run) {
                         u32x4 pk;
@@ -358,6 +475,10 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                         }
                         const int c = c0 + 16 * run;
                         int vo = (m < q.M && c < q.Cout) ? row_off + c * 2 : OOB;
+#ifdef FCN_EXP_NOSTORE
+                        asm volatile("" ::"v"(pk), "v"(vo));
+                        continue;
+#endif
                         __builtin_amdgcn_raw_buffer_store_b128(pk, ry, vo, 0, 0);
                     }
                 }
@@ -365,49 +486,100 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         };
 
         int tile = v;
-        MulP cur = mul_problem(tile);
+        MulP cur = mul_problem(tile), nxt = cur;
         load_bias(cur);
-        __builtin_amdgcn_s_barrier();      // chunk 0 is in LDS
+        tile_rows(cur, rho);
+        unsigned abuf = 0, wslot = 0;      // byte offsets of the current chunk's slab / weight slot
+        chunk_addr(rho, 0, abuf);
+        __builtin_amdgcn_s_barrier();      // slab 0 and weight chunk 0 are in LDS
         asm volatile("" ::: "memory");
-        read_step(0, 0, 0u);
+        read_w(0, 0, wslot);
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) read_x(i, 0);
+        // one chunk = 4 k-steps of a tap: [barrier] then per step { the next step's weight fragments; per pixel tile: wait, WTN MFMAs,
+        // re-read the tile's fragment for the next step }.  ONE copy of this body in the kernel (the register allocator keeps the
+        // accumulators in place across a single loop; four specialised copies of it made it shuffle and spill them).
+        auto chunk = [&](const bool first, const int (&rh_next)[WTM], const int q_next, const unsigned abuf_next) __attribute__((always_inline)) {
+            __builtin_amdgcn_s_barrier();      // the next chunk's weights (and slab) are in LDS; the loaders may refill what the previous chunk used
+            asm volatile("" ::: "memory");
+            const unsigned wslot_next = wslot + WCH == (unsigned)(NB * WCH) ? 0u : wslot + WCH;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                // the next step is step 0 of the NEXT chunk behind step 3 (its addresses replace this chunk's, whose reads are all issued)
+                const int stn = st + 1 < 4 ? st + 1 : 0;
+                if (st + 1 < 4) {
+                    read_w((st + 1) & 1, stn, wslot);
+                } else {
+                    chunk_addr(rh_next, q_next, abuf_next);
+                    read_w(0, 0, wslot_next);
+                }
+#pragma unroll
+                for (int i = 0; i < WTM; ++i) {
+                    frag_landed(st & 1, i, std::integral_constant<int, WTM - 1 + WTN>{});
+                    mfma_pair(st & 1, i, st == 0 && first);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_x(i, stn);
+                }
+            }
+            wslot = wslot_next;
+        };
 #pragma unroll 1
         while (true) {
-            chunk(std::true_type{});
-            // biasv is dead behind the tile's first k-step: fetch the next tile's now, in front of this tile's stores (the
-            // vector-memory counter retires in order: waiting for these loads never waits for the stores behind them)
+            // the next tile's problem and pixel rows: the last chunk of this tile reads the first fragments of the next one
             const int tn = tile + G;
             const bool more = tn < total;
-            MulP nxt = cur;
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) rho_nt[i] = rho[i];
             if (more) {
                 nxt = mul_problem(tn);
-                load_bias(nxt);
+                tile_rows(nxt, rho_nt);
             }
+            int q = 0;
 #pragma unroll 1
-            for (int c = 1; c < cur.nch; ++c) chunk(std::false_type{});
+            for (int ch = 0; ch < cur.nch; ++ch) {
+                // the chunk after this one: the next tap of the slab, or tap 0 of the next slab (the next tile's behind the last chunk)
+                const bool last_q = q + 1 == cur.kw;
+                const int qn = last_q ? 0 : q + 1;
+                const unsigned abuf_n = last_q ? (abuf + SLAB == (unsigned)(NA * SLAB) ? 0u : abuf + SLAB) : abuf;
+                const bool tile_end = ch + 1 == cur.nch;
+                if (tile_end && more) load_bias(nxt);
+                int rsel[WTM];
+#pragma unroll
+                for (int i = 0; i < WTM; ++i) rsel[i] = tile_end ? rho_nt[i] : rho[i];
+                chunk(ch == 0, rsel, qn, abuf_n);
+                q = qn;
+                abuf = abuf_n;
+            }
             epilogue(cur);
             if (!more) break;
             cur = nxt;
             tile = tn;
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) rho[i] = rho_nt[i];
         }
         // the fragments prefetched last belong to a chunk nobody multiplies: retire the reads before the registers die
-        step_landed(0, std::integral_constant<int, 0>{});
-        step_landed(1, std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) frag_landed(0, i, std::integral_constant<int, 0>{});
+        frag_landed(1, 0, std::integral_constant<int, 0>{});
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
 #endif
 }
 
-// configurations: X(index, WTM, WTN, BK words, ring slots)
+// configurations: X(index, WTN, slab pieces, slab buffers, weight slots)
+//   0/1: 3x3 and 5x5 launches (slabs of 304 rows, two buffers: a slab is needed kw >= 2 chunks after its issue)
+//   2/3: 1x1 launches (256-row slabs, three / four buffers)       4/5: mixed 1x1 + 3x3 launches (288-row slabs, three buffers)
 #define FCN_STREAM_CONFIGS(X) \
-    X(0, 4, 2, 16, 6)         \
-    X(1, 4, 1, 16, 6)         \
-    X(2, 2, 2, 16, 6)         \
-    X(3, 4, 2, 32, 3)         \
-    X(4, 2, 2, 32, 4)
+    X(0, 2, 38, 2, 5)         \
+    X(1, 1, 38, 2, 5)         \
+    X(2, 2, 32, 3, 4)         \
+    X(3, 1, 32, 4, 4)         \
+    X(4, 2, 36, 3, 3)         \
+    X(5, 1, 36, 3, 4)
 
 constexpr StreamCfgInfo kStreamCfgs[] = {
-#define X(I, A, B, K, N) {SCfg<A, B, K, N>::BM, SCfg<A, B, K, N>::BN, K, SCfg<A, B, K, N>::LDS_BYTES, SCfg<A, B, K, N>::NT},
+#define X(I, A, B, NA_, NB_) {kBM, SCfg<A, B, NA_, NB_>::BN, 32, SCfg<A, B, NA_, NB_>::LDS_BYTES, SCfg<A, B, NA_, NB_>::NT, B * 8, NA_},
     FCN_STREAM_CONFIGS(X)
 #undef X
 };
@@ -428,9 +600,9 @@ void launch_stream(int idx, const GroupArgs& ga, int total, hipStream_t st) {
     }
     const int grid = total < cus ? total : cus;      // persistent: one workgroup per compute unit
     switch (idx) {
-#define X(I, A, B, K, N)                                                                                                                              \
+#define X(I, A, B, NA_, NB_)                                                                                                                          \
     case I:                                                                                                                                           \
-        hipLaunchKernelGGL((conv_stream_f16<SCfg<A, B, K, N>>), dim3(grid), dim3(SCfg<A, B, K, N>::NT), 0, st, ga.nprob, ga.tile_end[0], ga.tile_end[1], \
+        hipLaunchKernelGGL((conv_stream_f16<SCfg<A, B, NA_, NB_>>), dim3(grid), dim3(512), 0, st, ga.nprob, ga.tile_end[0], ga.tile_end[1],            \
                            ga.tile_end[2], ga.tile_end[3], ga.tile_end[4], ga.tile_end[5], ga.tile_end[6], ga.tile_end[7], total, 0, ga);              \
         break;
         FCN_STREAM_CONFIGS(X)

@@ -533,30 +533,42 @@ class Engine:
             levels.append(lv)
         order = sorted(range(len(tasks)), key=lambda i: (levels[i], 0 if tasks[i]["kind"] == "op" else 1, i))
 
+        def emit_group(chunk: List[dict], fused: List[dict]) -> None:
+            """One grouped launch of `chunk` (at most 16 convolutions of one level); `fused` MAX poolings ride in it."""
+            name = "+".join(it["layer"].name for it in chunk)
+            flops = sum(it["flops"] for it in chunk)
+            byts = sum(it["bytes"] for it in chunk)
+            arr = (L.ConvDesc * len(chunk))(*[it["desc"] for it in chunk])
+            ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(chunk))), zero=False)
+            self._group_workspaces.append(ws)
+            grp = L.ConvGroup()
+            parr = (L.PoolDesc * max(len(fused), 1))(*[pt["pool_desc"] for pt in fused])
+            tune_key = name + ("{+%d pool}" % len(fused) if fused else "")
+            cfg = self._tuned_cfg(tune_key, arr, len(chunk), ws, parr, len(fused)) if self.autotune else -1
+            L.call("fcn_conv2d_group_prepare_fused", arr, len(chunk), parr, len(fused), ws.ptr, cfg, C.byref(grp))
+            self._keep.extend([arr, parr, ws, grp])
+            kind = "conv_group" if len(chunk) > 1 else "conv"
+            label = "%s [cfg%d %dwg]" % (name, grp.cfg, grp.total_tiles)
+            if fused:
+                label = "%s {+%s}" % (label, "+".join(pt["layer"].name for pt in fused))
+                byts += sum(pt["ops"][0].bytes for pt in fused)
+            self.ops.append(Op(kind, label, lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
+
         def emit_convs(items: List[dict], pools: List[dict]) -> None:
-            """One grouped launch per 16 convolutions of a level; the level's fusable MAX poolings ride in the first one."""
+            """One grouped launch per 16 convolutions of a level; the level's fusable MAX poolings ride in the first one.  Half-float
+            engines may cut a level in two launches - its 3x3 / 5x5 convolutions and its 1x1 convolutions - when the autotuner
+            finds the pair faster (the streaming kernel's configurations are shaped for one kind or the other)."""
             for base in range(0, len(items), 16):
                 chunk = items[base:base + 16]
-                name = "+".join(it["layer"].name for it in chunk)
-                flops = sum(it["flops"] for it in chunk)
-                byts = sum(it["bytes"] for it in chunk)
-                arr = (L.ConvDesc * len(chunk))(*[it["desc"] for it in chunk])
-                ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(chunk))), zero=False)
-                self._group_workspaces.append(ws)
-                grp = L.ConvGroup()
                 fused = pools[:2] if base == 0 and len(chunk) <= 8 else []
-                parr = (L.PoolDesc * max(len(fused), 1))(*[pt["pool_desc"] for pt in fused])
-                tune_key = name + ("{+%d pool}" % len(fused) if fused else "")
-                cfg = self._tuned_cfg(tune_key, arr, len(chunk), ws, parr, len(fused)) if self.autotune else -1
-                L.call("fcn_conv2d_group_prepare_fused", arr, len(chunk), parr, len(fused), ws.ptr, cfg, C.byref(grp))
-                self._keep.extend([arr, parr, ws, grp])
-                kind = "conv_group" if len(chunk) > 1 else "conv"
-                label = "%s [cfg%d %dwg]" % (name, grp.cfg, grp.total_tiles)
-                if fused:
-                    label = "%s {+%s}" % (label, "+".join(pt["layer"].name for pt in fused))
-                    byts += sum(pt["ops"][0].bytes for pt in fused)
-                    del pools[:len(fused)]
-                self.ops.append(Op(kind, label, lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
+                parts = [chunk]
+                if self.f16 and self.autotune and not fused and len(chunk) > 1:
+                    parts = self._split_level(chunk)
+                for part in parts:
+                    emit_group(part, fused)
+                    fused = []
+                if base == 0 and len(chunk) <= 8:
+                    del pools[:2]
             for pt in pools:            # no convolution launch at this level to ride in
                 self.ops.extend(pt["ops"])
             pools.clear()
@@ -669,11 +681,8 @@ class Engine:
         d.f16 = 1 if xb.esize == 2 else 0
         return d
 
-    def _tuned_cfg(self, name: str, arr, n: int, ws: DeviceBuffer, parr=None, npool: int = 0) -> int:
-        """Autotuned tile configuration of one grouped launch, remembered in $FCN_TUNE_CACHE (JSON) when that is set so
-        that a profiled run replays the plan of an earlier run without the tuning launches."""
+    def _load_tune_cache(self) -> Optional[dict]:
         import json
-        import os
         path = os.environ.get("FCN_TUNE_CACHE")
         if path and not hasattr(self, "_tune_cache"):
             try:
@@ -681,10 +690,31 @@ class Engine:
                     self._tune_cache = json.load(f)
             except (OSError, ValueError):
                 self._tune_cache = {}
-        cache = getattr(self, "_tune_cache", None)
+        return getattr(self, "_tune_cache", None)
+
+    def _save_tune_cache(self) -> None:
+        import json
+        path = os.environ.get("FCN_TUNE_CACHE")
+        if path and getattr(self, "_tune_cache", None) is not None:
+            try:
+                with open(path, "w") as f:
+                    json.dump(self._tune_cache, f, indent=0, sort_keys=True)
+            except OSError:
+                pass
+
+    def _tune_key(self, name: str) -> str:
         key = "%s|%s" % (name, "x".join(str(d) for d in self.shapes.get(self.inputs[0], ())) if self.inputs else "")
+        if self.f16:
+            key += "|f16"
         if self._tune_max_lds < 160 * 1024:
             key += "|lds%d" % (self._tune_max_lds // 1024)
+        return key
+
+    def _tuned_cfg(self, name: str, arr, n: int, ws: DeviceBuffer, parr=None, npool: int = 0) -> int:
+        """Autotuned tile configuration of one grouped launch, remembered in $FCN_TUNE_CACHE (JSON) when that is set so
+        that a profiled run replays the plan of an earlier run without the tuning launches."""
+        cache = self._load_tune_cache()
+        key = self._tune_key(name)
         ncfg = int(L.load().fcn_conv2d_num_configs())
         if self._tune_from is not None and key in self._tune_from._chosen_cfgs:
             self._chosen_cfgs[key] = self._tune_from._chosen_cfgs[key]
@@ -696,15 +726,15 @@ class Engine:
         self._chosen_cfgs[key] = cfg
         if cache is not None:
             cache[key] = cfg
-            try:
-                with open(path, "w") as f:
-                    json.dump(cache, f, indent=0, sort_keys=True)
-            except OSError:
-                pass
+            self._save_tune_cache()
         return cfg
 
     def _pick_conv_cfg(self, arr, n: int, ws: DeviceBuffer, parr=None, npool: int = 0) -> int:
         """Plan-time autotune of one grouped launch: time every tile configuration on the device, keep the fastest."""
+        return self._time_conv_cfgs(arr, n, ws, parr, npool)[0]
+
+    def _time_conv_cfgs(self, arr, n: int, ws: DeviceBuffer, parr=None, npool: int = 0) -> Tuple[int, float]:
+        """(fastest configuration, its milliseconds per launch) of one grouped launch."""
         lib = L.load()
         if not hasattr(self, "_tune_events"):
             e0, e1 = C.c_void_p(), C.c_void_p()
@@ -735,7 +765,37 @@ class Engine:
             L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
             if ms.value < best_ms:
                 best, best_ms = cfg, ms.value
-        return best
+        return best, best_ms / 6.0
+
+    def _split_level(self, chunk: List[dict]) -> List[List[dict]]:
+        """Half-float engines: one launch for the level's convolutions, or one for its 3x3 / 5x5 ones and one for its 1x1 ones?
+        Timed once per level at plan time; the decision rides in the tune cache beside the configurations."""
+        big = [it for it in chunk if it["desc"].kh > 1]
+        small = [it for it in chunk if it["desc"].kh == 1]
+        if not big or not small:
+            return [chunk]
+        lib = L.load()
+        key = "split|" + self._tune_key("+".join(it["layer"].name for it in chunk))
+        if self._tune_from is not None and key in self._tune_from._chosen_cfgs:
+            choice = self._tune_from._chosen_cfgs[key]
+        else:
+            cache = self._load_tune_cache()
+            if cache is not None and key in cache:
+                choice = int(cache[key])
+            else:
+                times = []
+                for part in (chunk, big, small):
+                    arr = (L.ConvDesc * len(part))(*[it["desc"] for it in part])
+                    ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(part))), zero=False)
+                    times.append(self._time_conv_cfgs(arr, len(part), ws)[1])
+                    L.call("fcn_conv2d_group_release", ws.ptr)
+                    ws.free()
+                choice = 1 if times[1] + times[2] < times[0] else 0
+                if cache is not None:
+                    cache[key] = choice
+                    self._save_tune_cache()
+        self._chosen_cfgs[key] = choice
+        return [big, small] if choice else [chunk]
 
     def _loss_grad_ptr(self, blob: str) -> Optional[int]:
         """Device address the loss kernel writes d(loss)/d(blob) to; None in an inference engine."""

@@ -51,7 +51,9 @@ def f16_conv(x, wt, b, pad, stride, flags, out_f32, y_cstride=None, y_coffset=0)
     return y
 
 
-STREAM_CFGS = [32, 33, 34, 35, 36]      # conv_stream_f16: persistent workgroups, 256 x 128 ... 128 x 128 tiles
+STREAM_CFGS = [32, 33, 34, 35, 36, 37]      # conv_stream_f16: persistent workgroups, 256-pixel tiles x 128 / 64 channels
+# (slab rows, slab buffers) per configuration: 32/33 take 3x3 and 5x5 launches, 34/35 1x1 launches, 36/37 mixed 1x1 + 3x3
+_STREAM_SHAPE = {32: (304, 2), 33: (304, 2), 34: (256, 3), 35: (256, 4), 36: (288, 3), 37: (288, 3)}
 
 
 @pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15", "23", "24", "26", "29"])
@@ -100,10 +102,13 @@ def _stream_problem(rng, cin, cout, k, pad, h, w, n, relu=True, bias=True, y_cst
     return dict(desc=d, keep=[xd, wd, bd, yd], yd=yd, ref=ref, shape=(n, oh, ow, ycs), cout=cout, coff=y_coffset, x=x, xd=xd)
 
 
-def _stream_takes(cfg, cin, k):
-    """Taps padded to whole chunks (32 halves; 64 for the configurations with 128-byte rows) may cost at most 2x."""
-    bke = 64 if cfg in (35, 36) else 32
-    return k == 1 or -(-r8(cin) // bke) * bke <= 2 * r8(cin)
+def _stream_takes(cfg, k, w):
+    """A tile's 256 pixels in padded raster order, plus the taps of a filter row, must fit the configuration's slab; 1x1 filters
+    need three slab buffers; padded image rows hold at least 16 entries (conv_fwd.hip plan_tiles_cfg)."""
+    rows_max, bufs = _STREAM_SHAPE[cfg]
+    pad = (k - 1) // 2
+    rows = 255 + 2 * pad * ((254 + w) // w) + 2 * pad + 1
+    return rows <= rows_max and (k > 1 or bufs >= 3) and w + 2 * pad >= 16
 
 
 def _run_stream_group(probs, cfg):
@@ -127,17 +132,20 @@ def _run_stream_group(probs, cfg):
 
 @pytest.mark.parametrize("cfg", STREAM_CFGS)
 @pytest.mark.parametrize("case", [  # cin, cout, k, pad, h, w, n
-    (96, 208, 3, 1, 28, 28, 3),       # several row tiles with a ragged last one, two column tiles, taps padded to whole chunks (96 = 3 x 32)
-    (480, 304, 1, 0, 28, 28, 2),      # a long 1x1 walk, three column tiles with a ragged last one
-    (48, 64, 5, 2, 28, 28, 2),        # 5x5 on 48 channels: every tap padded (48 -> 64 halves)
-    (16, 32, 5, 2, 20, 12, 1),        # 5x5 on 16 channels: 2x padding, a single ragged tile
-    (64, 192, 3, 1, 40, 36, 5),       # more tiles than a small grid would hold per workgroup: the persistent walk
-    (192, 16, 1, 0, 9, 11, 1),        # M = 99 < one tile, Cout = 16
+    (96, 208, 3, 1, 28, 28, 3),       # several row tiles with a ragged last one, two column tiles, a 32-channel tail chunk (96 = 64 + 32)
+    (480, 304, 1, 0, 28, 28, 2),      # a long 1x1 walk (8 chunks, the last one 32 channels), three column tiles with a ragged last one
+    (48, 64, 5, 2, 28, 28, 2),        # 5x5 on 48 channels: five filter rows of one short chunk, ten image rows per tile
+    (16, 32, 5, 2, 20, 40, 1),        # 5x5 on 16 channels, a single ragged tile, image rows of 40
+    (64, 192, 3, 1, 40, 36, 5),       # more tiles than a small grid would hold per workgroup: the persistent walk, tiles across images
+    (192, 16, 1, 0, 6, 17, 1),        # M = 102 < one tile, Cout = 16
+    (192, 16, 1, 0, 9, 11, 1),        # image rows of 11: refused
+    (64, 64, 1, 0, 33, 31, 2),        # one chunk per tile (conv2/3x3_reduce): every chunk is a tile's first and last
+    (128, 256, 3, 1, 56, 56, 1),      # image rows of 56: a tile covers 4.6 of them
 ])
 def test_stream_kernel_matches_oracle(gpu, case, cfg):
     cin, cout, k, pad, h, w, n = case
     rng = np.random.default_rng(hash(case) % 2**32)
-    if not _stream_takes(cfg, cin, k):
+    if not _stream_takes(cfg, k, w):
         q = _stream_problem(rng, cin, cout, k, pad, h, w, n)
         ws = DeviceBuffer(int(L.load().fcn_conv2d_group_workspace_bytes(1)), zero=False)
         assert L.load().fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, cfg, C.byref(L.ConvGroup())) != 0
@@ -148,20 +156,27 @@ def test_stream_kernel_matches_oracle(gpu, case, cfg):
 
 @pytest.mark.parametrize("cfg", STREAM_CFGS)
 def test_stream_kernel_group_slices_and_flags(gpu, cfg):
-    """Several problems in one persistent launch (an inception module's three 1x1 convolutions on one input, then its 3x3 / 5x5 /
-    pool_proj level): different K per problem, outputs as channel slices of a wider buffer, one problem without bias, one without ReLU."""
+    """Several problems in one persistent launch: an inception module's three 1x1 convolutions on one input (one without bias, one
+    without ReLU), its 3x3 + 5x5 level, and a 3x3 beside a 1x1 - different K and filter sizes per problem, outputs as channel slices
+    of a wider buffer."""
     rng = np.random.default_rng(17)
     n, h, w = 3, 28, 28
-    first = _stream_problem(rng, 192, 64, 1, 0, h, w, n, y_cstride=256, y_coffset=0)
-    probs = [first,
-             _stream_problem(rng, 192, 96, 1, 0, h, w, n, bias=False, x=first["x"], xd=first["xd"]),
-             _stream_problem(rng, 192, 16, 1, 0, h, w, n, relu=False, x=first["x"], xd=first["xd"])]
-    _run_stream_group(probs, cfg)
-    probs = [_stream_problem(rng, 96, 128, 3, 1, h, w, n, y_cstride=256, y_coffset=64),
-             _stream_problem(rng, 16 if _stream_takes(cfg, 16, 5) else 32, 32, 5, 2, h, w, n, y_cstride=256, y_coffset=192),
-             _stream_problem(rng, 192, 32, 1, 0, h, w, n, y_cstride=256, y_coffset=224)]
-    grp = _run_stream_group(probs, cfg)
-    assert grp.n == 3
+    ran = 0
+    if _stream_takes(cfg, 1, w):
+        first = _stream_problem(rng, 192, 64, 1, 0, h, w, n, y_cstride=256, y_coffset=0)
+        _run_stream_group([first, _stream_problem(rng, 192, 96, 1, 0, h, w, n, bias=False, x=first["x"], xd=first["xd"]),
+                           _stream_problem(rng, 192, 16, 1, 0, h, w, n, relu=False, x=first["x"], xd=first["xd"])], cfg)
+        ran += 1
+    if _stream_takes(cfg, 3, w) and _stream_takes(cfg, 5, w):
+        grp = _run_stream_group([_stream_problem(rng, 96, 128, 3, 1, h, w, n, y_cstride=256, y_coffset=64),
+                                 _stream_problem(rng, 16, 32, 5, 2, h, w, n, y_cstride=256, y_coffset=192)], cfg)
+        assert grp.n == 2
+        ran += 1
+    if _stream_takes(cfg, 3, w) and _stream_takes(cfg, 1, w):
+        _run_stream_group([_stream_problem(rng, 96, 128, 3, 1, h, w, n, y_cstride=256, y_coffset=64),
+                           _stream_problem(rng, 192, 32, 1, 0, h, w, n, y_cstride=256, y_coffset=224)], cfg)
+        ran += 1
+    assert ran >= 1
 
 
 def test_stream_kernel_refuses_what_it_does_not_cover(gpu):
@@ -170,16 +185,19 @@ def test_stream_kernel_refuses_what_it_does_not_cover(gpu):
     ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(1)), zero=False)
     grp = L.ConvGroup()
     q = _stream_problem(rng, 64, 33, 1, 0, 8, 8, 1, y_cstride=40)        # Cout not a multiple of 8
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 34, C.byref(grp)) != 0
+    q = _stream_problem(rng, 8, 64, 7, 3, 40, 40, 1)                      # 7x7 filters
     assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
-    q = _stream_problem(rng, 8, 64, 7, 3, 20, 20, 1)                      # 7x7 on 8 channels: taps would be padded 4x
+    q = _stream_problem(rng, 64, 64, 3, 1, 20, 8, 1)                      # image rows of 8:  the padded slab of a tile does not fit
     assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
-    q = _stream_problem(rng, 64, 64, 1, 0, 8, 8, 1)
+    q = _stream_problem(rng, 64, 64, 1, 0, 8, 8, 1)                       # 1x1 filters need three slab buffers
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
     q["desc"].flags |= L.CONV_OUT_F32                                     # float32 output (the detection heads)
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 34, C.byref(grp)) != 0
     x = dev_from(np.zeros((1, 8, 8, 64), np.float32))                     # float32 problems never take it
     wt, yd = dev_from(np.zeros((64, 1, 1, 64), np.float32)), dev_from(np.zeros((1, 8, 8, 64), np.float32))
     d = conv_desc(x, wt, None, yd, 1, 8, 8, 64, 64, 64, 1, 0, 1, 8, 8, 64, 0, 0)
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d), 1, ws.ptr, 32, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d), 1, ws.ptr, 34, C.byref(grp)) != 0
 
 
 def test_f16_group_with_fused_pool_and_sigmoid_head(gpu):
