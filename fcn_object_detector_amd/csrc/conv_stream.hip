@@ -36,6 +36,32 @@ using namespace fcn;
 
 namespace {
 
+// Diagnostic build only (make exp EXP=-DFCN_STREAM_STAMPS): thread 0 of each role sums the 100 MHz clock over its phases into a
+// buffer of its own (tools/stream_timeline.py).  No stamp exists in the product build; no output value depends on one.
+#ifdef FCN_STREAM_STAMPS
+__device__ unsigned long long* g_stream_stamps = nullptr;
+__device__ int g_stream_stamps_cap = 0;
+#define SNOW() __builtin_amdgcn_s_memrealtime()
+#define SSTAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0_ = SNOW(), st_t_ = st_t0_
+#define SSTAMP(i)                                         \
+    do {                                                  \
+        const unsigned long long n_ = SNOW();             \
+        st_[i] += n_ - st_t_;                             \
+        st_t_ = n_;                                       \
+    } while (0)
+#define SSTAMP_FLUSH(role)                                                                                           \
+    do {                                                                                                             \
+        if (g_stream_stamps && (int)blockIdx.x < g_stream_stamps_cap && (threadIdx.x & 63) == 0) {                    \
+            unsigned long long* d_ = g_stream_stamps + ((size_t)blockIdx.x * 3 + (role)) * 8;                        \
+            for (int k_ = 0; k_ < 8; ++k_) d_[k_] = st_[k_];                                                          \
+        }                                                                                                            \
+    } while (0)
+#else
+#define SSTAMP_DECL do { } while (0)
+#define SSTAMP(i) do { } while (0)
+#define SSTAMP_FLUSH(role) do { } while (0)
+#endif
+
 constexpr int kBM = 256;          // pixels per tile
 constexpr int kChunkK = 64;       // halves of K per chunk (128-byte LDS rows)
 
@@ -193,6 +219,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 }
             }
         };
+        SSTAMP_DECL;
         setup();
         Walk wk;
         walk_begin(wk, v);
@@ -207,9 +234,12 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         __builtin_amdgcn_s_barrier();
 #pragma unroll 1
         while (wk.tile < total) {
+            SSTAMP(0);                     // [0] issue + walk
             wait_vmcnt<NPB*(NB - 3)>();    // the chunk after the one the multipliers start now has landed
+            SSTAMP(1);                     // [1] waiting for loads
             __builtin_amdgcn_s_barrier();  // the multipliers are done with the chunk before it: its slot takes the chunk NB - 1 ahead
             asm volatile("" ::: "memory");
+            SSTAMP(2);                     // [2] waiting at the barrier
             issue_chunk(slot);
             slot = next(slot);
             walk_step(wk);
@@ -217,6 +247,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         wait_vmcnt<0>();                   // the all-zero chunks behind the last tile
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (wb == 0) SSTAMP_FLUSH(2);
     } else if (wid_all >= 4) {
         // ---- slab-loading waves: slab (r, cc) of a tile = padded-raster pixels Pbase .. Pbase + 8 SRP - 1 of input row offset r ---
         const int wa = wid_all - 4;
@@ -296,6 +327,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 }
             }
         };
+        SSTAMP_DECL;
         setup();
         Walk wk;
         walk_begin(wk, v);
@@ -314,12 +346,15 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             // it must have landed.  Slabs are issued behind the FIRST barrier of a slab (NA - 1 ahead), so the slabs younger than
             // j + 1 that are in flight here number NA - 2 - or NA - 3 when the slab has a single chunk (1x1 filters: its own issue
             // comes behind this very barrier; plan_tiles_cfg keeps 1x1 problems away from two-buffer configurations).
+            SSTAMP(0);
             if (wk.q == wk.kw - 1) {
                 if (wk.kw == 1) wait_vmcnt<NPA*(NA >= 3 ? NA - 3 : 0)>();
                 else wait_vmcnt<NPA*(NA - 2)>();
             }
+            SSTAMP(1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            SSTAMP(2);
             if (wk.q == 0) {
                 issue_slab(buf);
                 buf = next(buf);
@@ -329,6 +364,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (wa == 0) SSTAMP_FLUSH(1);
     } else {
         // ---- multiplying waves -----------------------------------------------------------------------------------------------------
         const int wm = wid_all >> 1, wn = wid_all & 1;
@@ -436,20 +472,32 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 rh[i] = (t - t0) * q.PW + (m - t * q.W) - x0;
             }
         };
-        // bias of this lane's channels, what a tile's accumulators start from (out-of-range channels read 0; no bias: 0 records)
+        // bias of this lane's channels, the C operand of a tile's first MFMAs (out-of-range channels read 0; no bias: 0 records).
+        // The loads are inline asm ON PURPOSE: the compiler's own wait in front of the first use was s_waitcnt vmcnt(0), which
+        // also waits for the previous tile's 16 stores issued behind these loads - a write latency per tile.  bias_landed()
+        // waits for exactly "all but the stores".
+        typedef int v4i __attribute__((ext_vector_type(4)));
         auto load_bias = [&](const MulP& q) __attribute__((always_inline)) {
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q.bias ? q.bias : reinterpret_cast<const float*>(q.y)), 0,
-                                                                                q.bias ? q.Cout * 4 : 0, 0x00020000);
+            const unsigned long long ba = (unsigned long long)(q.bias ? (const void*)q.bias : (const void*)q.y);
+            const v4i rb = {(int)(unsigned)ba, (int)((unsigned)(ba >> 32) & 0xffffu), q.bias ? q.Cout * 4 : 0, 0x00020000};
 #pragma unroll
             for (int j = 0; j < WTN; ++j) {
                 const int c0 = q.n0 + wn * 32 * WTN + 32 * j + 8 * kh_;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {      // channels c0 + 0..3, 4..7, 16..19, 20..23
-                    const v4f b4 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rb, (c0 + 4 * (g & 1) + 16 * (g >> 1)) * 4, 0, 0));
+                    v4f b4;
+                    const int off = (c0 + 4 * (g & 1) + 16 * (g >> 1)) * 4;
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(b4) : "v"(off), "s"(rb) : "memory");
 #pragma unroll
                     for (int e = 0; e < 4; ++e) biasv[j][4 * g + e] = b4[e];
                 }
             }
+        };
+        auto bias_landed = [&](auto stores_behind) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(stores_behind)::value) : "memory");
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) asm volatile("" : "+v"(biasv[j]));
+            __builtin_amdgcn_sched_barrier(0);
         };
         auto epilogue = [&](const MulP& q) __attribute__((always_inline)) {
             typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -485,9 +533,11 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             }
         };
 
+        SSTAMP_DECL;
         int tile = v;
         MulP cur = mul_problem(tile), nxt = cur;
         load_bias(cur);
+        bias_landed(std::integral_constant<int, 0>{});
         tile_rows(cur, rho);
         unsigned abuf = 0, wslot = 0;      // byte offsets of the current chunk's slab / weight slot
         chunk_addr(rho, 0, abuf);
@@ -500,8 +550,10 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         // re-read the tile's fragment for the next step }.  ONE copy of this body in the kernel (the register allocator keeps the
         // accumulators in place across a single loop; four specialised copies of it made it shuffle and spill them).
         auto chunk = [&](const bool first, const int (&rh_next)[WTM], const int q_next, const unsigned abuf_next) __attribute__((always_inline)) {
+            SSTAMP(0);                         // [0] chunk bodies (+ the loop around them)
             __builtin_amdgcn_s_barrier();      // the next chunk's weights (and slab) are in LDS; the loaders may refill what the previous chunk used
             asm volatile("" ::: "memory");
+            SSTAMP(1);                         // [1] waiting at the barrier
             const unsigned wslot_next = wslot + WCH == (unsigned)(NB * WCH) ? 0u : wslot + WCH;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
@@ -513,6 +565,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                     chunk_addr(rh_next, q_next, abuf_next);
                     read_w(0, 0, wslot_next);
                 }
+                if (st == 0 && first) bias_landed(std::integral_constant<int, 2 * WTM * WTN>{});      // (behind the loads: the previous tile's stores)
 #pragma unroll
                 for (int i = 0; i < WTM; ++i) {
                     frag_landed(st & 1, i, std::integral_constant<int, WTM - 1 + WTN>{});
@@ -530,10 +583,12 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             const bool more = tn < total;
 #pragma unroll
             for (int i = 0; i < WTM; ++i) rho_nt[i] = rho[i];
+            SSTAMP(3);                         // [3] loop bookkeeping between tiles
             if (more) {
                 nxt = mul_problem(tn);
                 tile_rows(nxt, rho_nt);
             }
+            SSTAMP(4);                         // [4] next tile's problem + pixel rows
             int q = 0;
 #pragma unroll 1
             for (int ch = 0; ch < cur.nch; ++ch) {
@@ -550,7 +605,9 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 q = qn;
                 abuf = abuf_n;
             }
+            SSTAMP(0);
             epilogue(cur);
+            SSTAMP(2);                         // [2] epilogue
             if (!more) break;
             cur = nxt;
             tile = tn;
@@ -563,6 +620,10 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         frag_landed(1, 0, std::integral_constant<int, 0>{});
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef FCN_STREAM_STAMPS
+        st_[7] = SNOW() - st_t0_;
+        if (wid_all == 0) SSTAMP_FLUSH(0);
+#endif
     }
 #endif
 }
@@ -585,6 +646,14 @@ constexpr StreamCfgInfo kStreamCfgs[] = {
 };
 
 }  // namespace
+
+#ifdef FCN_STREAM_STAMPS
+extern "C" int fcn_debug_stream_stamps(void* d_buf, int cap) {
+    FCN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stream_stamps), &d_buf, sizeof(d_buf)));
+    FCN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stream_stamps_cap), &cap, sizeof(cap)));
+    return 0;
+}
+#endif
 
 namespace fcn {
 
