@@ -16,6 +16,7 @@ import json
 import os
 import socket
 import struct
+import sys
 import time
 from typing import Any, List, Optional
 
@@ -64,10 +65,40 @@ def spawn_ranks(script: str, argv: List[str], devices: List[int], extra_env: Opt
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL's intra-node transport needs on this driver
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=env))
+    # Watch ALL children: a rank that dies (bad weights file, out of memory, RCCL init error) leaves the others blocked in a
+    # collective that has no timeout, and a launcher that waits for rank 0 first would wait forever.  The first non-zero exit -
+    # or $FCN_SPAWN_TIMEOUT seconds, if set - ends the job: the ranks still running are terminated (then killed) and the launcher
+    # returns non-zero.  Children are only ever signalled, never re-executed.
+    deadline = None
+    if os.environ.get("FCN_SPAWN_TIMEOUT"):
+        deadline = time.time() + float(os.environ["FCN_SPAWN_TIMEOUT"])
     rc = 0
     try:
-        for p in procs:
-            rc = p.wait() or rc
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = [c for c in codes if c not in (None, 0)]
+            if failed:
+                rc = failed[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if deadline is not None and time.time() > deadline:
+                rc = 124
+                sys.stderr.write("spawn_ranks: ranks still running after FCN_SPAWN_TIMEOUT; ending the job\n")
+                break
+            time.sleep(0.05)
+        if rc != 0:
+            alive = [p for p in procs if p.poll() is None]
+            for p in alive:
+                p.terminate()
+            t_end = time.time() + 5.0
+            while alive and time.time() < t_end:
+                alive = [p for p in alive if p.poll() is None]
+                time.sleep(0.05)
+            for p in alive:
+                p.kill()
+            for p in procs:
+                p.wait()
     except BaseException:
         for p in procs:      # exactly the processes started here
             if p.poll() is None:
@@ -79,6 +110,29 @@ def spawn_ranks(script: str, argv: List[str], devices: List[int], extra_env: Opt
 def env_device() -> int:
     """GPU of this rank: FCN_DEVICE when a launcher of this package set it, else LOCAL_RANK."""
     return int(os.environ.get("FCN_DEVICE", env_local_rank()))
+
+
+def _single_node_job(world: int, master_addr: str) -> bool:
+    """Every rank on this host?  LOCAL_WORLD_SIZE == WORLD_SIZE (torch.distributed.run sets both), or MASTER_ADDR names this host."""
+    lws = os.environ.get("LOCAL_WORLD_SIZE")
+    if lws is not None and int(lws) == int(world):
+        return True
+    if master_addr in ("127.0.0.1", "localhost", "::1"):
+        return True
+    try:
+        mine = {socket.gethostname(), socket.getfqdn()}
+        if master_addr in mine:
+            return True
+        addrs = {ai[4][0] for ai in socket.getaddrinfo(master_addr, None)}
+        local = {"127.0.0.1", "127.0.1.1", "::1"}
+        for name in mine:
+            try:
+                local |= {ai[4][0] for ai in socket.getaddrinfo(name, None)}
+            except OSError:
+                pass
+        return bool(addrs & local)
+    except OSError:
+        return False
 
 
 MAX_MESSAGE = 1 << 20      # control-plane messages are ranks, timings, error strings and the 128-byte RCCL id
@@ -152,6 +206,16 @@ class ControlPlane:
         self.rank = env_rank() if rank is None else int(rank)
         self.world = env_world_size() if world is None else int(world)
         self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        # Rank 0 listens on $FCN_DP_BIND, by default the loopback interface.  `torch.distributed.run --standalone` sets MASTER_ADDR to
+        # the host's name, which resolves to 127.0.1.1 or a NIC address where nobody listens: on a single-node job (every rank on
+        # this host) the clients therefore connect to the loopback address too.  A multi-node job must name the interface.
+        if addr is None and not os.environ.get("FCN_DP_BIND"):
+            if _single_node_job(self.world, self.addr):
+                self.addr = "127.0.0.1"
+            elif self.world > 1 and self.rank == 0:
+                raise RuntimeError("control plane: MASTER_ADDR=%s is not this host and FCN_DP_BIND is unset: rank 0 would listen on "
+                                   "127.0.0.1 where the other nodes cannot reach it.  Set FCN_DP_BIND to the interface to listen on "
+                                   "(and FCN_DP_SECRET to a per-job secret shared by all ranks)." % self.addr)
         self.base_port = int(base_port if base_port is not None else os.environ.get("MASTER_PORT", "29500"))
         self.token = token or os.environ.get("TORCHELASTIC_RUN_ID", "fcn") + ":%d" % self.world
         secret = secret if secret is not None else os.environ.get("FCN_DP_SECRET")

@@ -1196,6 +1196,44 @@ class Engine:
             L.call("fcn_event_destroy", e1)
         return out
 
+    def time_ops_in_sequence(self, reps: int = 10) -> List[Tuple[str, str, float, float, float]]:
+        """Per-op HIP-event timing (ms) with every launch in the cache state it has inside a forward pass: for op i the ops
+        0 .. i-1 run (untimed) in front of it, then event, op i, event.  time_ops() repeats ONE launch back to back, so its
+        operands (the filters above all) come from a warm L2 - in a real forward the 24 MB of filters and the activations of the
+        other 26 launches have passed through the 4 MB L2s in between; rocprofv3's per-kernel durations of a forward are the
+        in-sequence ones and are matched by this method (the empty event pair's cost is measured and subtracted)."""
+        out = []
+        with self.lock:
+            e0, e1 = C.c_void_p(), C.c_void_p()
+            L.call("fcn_event_create", C.byref(e0))
+            L.call("fcn_event_create", C.byref(e1))
+            ms = C.c_float()
+            empty = []
+            for _ in range(10):      # what two events with nothing between them read
+                self.ops[0].run(self.stream)
+                L.call("fcn_event_record", e0, self.stream)
+                L.call("fcn_event_record", e1, self.stream)
+                L.call("fcn_event_sync", e1)
+                L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+                empty.append(ms.value)
+            floor = float(np.median(empty))
+            for i, op in enumerate(self.ops):
+                acc = []
+                for _ in range(reps):
+                    for prev in self.ops[:i]:
+                        prev.run(self.stream)
+                    L.call("fcn_event_record", e0, self.stream)
+                    op.run(self.stream)
+                    L.call("fcn_event_record", e1, self.stream)
+                    L.call("fcn_event_sync", e1)
+                    L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+                    acc.append(ms.value)
+                out.append((op.kind, op.name, max(float(np.median(acc)) - floor, 0.0), op.flops, op.bytes))
+            L.call("fcn_event_destroy", e0)
+            L.call("fcn_event_destroy", e1)
+        self.event_pair_floor_ms = floor
+        return out
+
     def close(self) -> None:
         with self.lock:
             lib = L.load()
@@ -1303,6 +1341,27 @@ class ForwardPipeline:
         lib = L.load()
         engines = self.engines[:depth or getattr(self, "active", None) or len(self.engines)]
         return self._run_resident(engines, iters, lib, time)
+
+    def run_io(self, iters: int, depth: Optional[int] = None) -> float:
+        """`iters` forwards INCLUDING the transfers (SURVEY 8(d) config 2's region: H2D of the input blob from the replica's pinned
+        host array, layout change, all kernels, D2H of the outputs into pinned host arrays), `depth` frames in flight: a frame's
+        copies ride on its replica's stream, so they overlap the kernels of the other replicas.  Wall-clock seconds."""
+        import time
+        engines = self.engines[:depth or getattr(self, "active", None) or len(self.engines)]
+        for e in engines:
+            e.forward_begin()
+            e.forward_end()
+        pending: List[Engine] = []
+        t0 = time.perf_counter()
+        for i in range(iters):
+            e = engines[i % len(engines)]
+            if len(pending) == len(engines):
+                pending.pop(0).forward_end()
+            e.forward_begin()
+            pending.append(e)
+        while pending:
+            pending.pop(0).forward_end()
+        return time.perf_counter() - t0
 
     def _run_resident(self, engines, iters, lib, time) -> float:
         for e in engines:

@@ -677,7 +677,12 @@ class TrainEngine(Engine):
                         L.check(lib.fcn_event_record(b["ready"], side if side_used else self.stream))
                         L.check(lib.fcn_stream_wait_event(self.comm_stream, b["ready"]))
                         if not getattr(self, "comm_dry", False):      # (benchmarks: the same step without the collective)
+                            if getattr(self, "_replicas_diverged", False):
+                                raise RuntimeError("TrainEngine: a comm_dry step applied un-reduced gradients; the replicas no longer hold the "
+                                                   "same weights and this engine must not take real data-parallel steps (bench.py closes it)")
                             self.comm.all_reduce_sum(self.grad_flat.ptr + 4 * b["offset"], b["count"], self.comm_stream)
+                        elif world > 1:
+                            self._replicas_diverged = True
                         L.check(lib.fcn_event_record(b["done"], self.comm_stream))
             for b in self.buckets:
                 L.check(lib.fcn_stream_wait_event(self.stream, b["done"]))

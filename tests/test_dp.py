@@ -165,3 +165,76 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_spawn_ranks_ends_the_job_when_one_rank_dies(tmp_path):
+    """A rank that exits non-zero while the others are blocked (here: in a barrier that the dead rank never joins, standing in
+    for an ncclAllReduce without a timeout) must not leave the launcher waiting for rank 0: the survivors are terminated and
+    the launcher returns the failure promptly."""
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "from fcn_object_detector_amd import dp\n"
+        "cp = dp.ControlPlane(timeout=300)\n"
+        "cp.barrier()\n"
+        "if dp.env_rank() == 1:\n"
+        "    os._exit(7)\n"           # dies without closing its sockets cleanly
+        "time.sleep(600)\n" % ROOT)     # the others: blocked for ten minutes
+    code = ("import sys; sys.path.insert(0, %r); from fcn_object_detector_amd import dp; "
+            "sys.exit(dp.spawn_ranks(%r, [], [0, 1, 2]))" % (ROOT, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FCN_DP_SECRET")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=env, timeout=120)
+    assert r.returncode == 7 and time.time() - t0 < 60
+
+
+def test_spawn_ranks_deadline(tmp_path):
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "rank.py"
+    script.write_text("import time\ntime.sleep(600)\n")
+    code = ("import sys; sys.path.insert(0, %r); from fcn_object_detector_amd import dp; "
+            "sys.exit(dp.spawn_ranks(%r, [], [0, 1]))" % (ROOT, str(script)))
+    env = dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FCN_DP_SECRET")}, FCN_SPAWN_TIMEOUT="2")
+    assert subprocess.run([sys.executable, "-c", code], env=env, timeout=60).returncode == 124
+
+
+def _worker_env_addr(rank, world, port, master_addr, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR=master_addr, MASTER_PORT=str(port))
+    os.environ.pop("FCN_DP_BIND", None)
+    cp = dp.ControlPlane(timeout=30)      # address and port from the environment, as under torch.distributed.run
+    q.put((rank, cp.all_gather(rank), cp.addr))
+    cp.close()
+
+
+def test_single_node_job_with_master_addr_set_to_the_host_name():
+    """`torch.distributed.run --standalone` sets MASTER_ADDR to the host's name (which resolves to 127.0.1.1 or a NIC address);
+    rank 0 listens on the loopback interface, so on a single-node job the other ranks must connect there as well."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    name = socket.getfqdn()
+    ps = [ctx.Process(target=_worker_env_addr, args=(r, 2, port, name, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=60) for _ in range(2))
+    for p in ps:
+        p.join(30)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [[0, 1], [0, 1]] and all(r[2] == "127.0.0.1" for r in res)
+
+
+def test_multi_node_master_addr_needs_an_explicit_bind(monkeypatch):
+    import pytest
+    monkeypatch.delenv("FCN_DP_BIND", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "203.0.113.7")      # (TEST-NET-3: never this host)
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    with pytest.raises(RuntimeError, match="FCN_DP_BIND"):
+        dp.ControlPlane(0, 2, timeout=1)

@@ -62,5 +62,26 @@ int main() {
     for (int i = 0; i < 128; ++i) in_ok += r[i] == 100.0f + 128 + i;
     for (int i = 128; i < 256; ++i) { z += r[i] == 0.0f; beyond += r[i] == 100.0f + 128 + i; }
     printf("soffset test: lanes whose sum stays in range correct: %d / 128; lanes pushed out of range by soffset: %d zeros, %d read beyond num_records (of 128)\n", in_ok, z, beyond);
+    // third question (round 3; csrc/train.hip prefetches chunks past a split's end with soffset = 0x7F000000 and in-range voffsets):
+    // a scalar offset LARGER than num_records - does `num_records - soffset` wrap in the range check and let the lanes through?
+    // Every lane's voffset is in range (0..1008 of 1024); expected: all zeros, nothing read.  Also with the largest offset the
+    // kernels use for "out of range" lanes (voffset 0x80000000, soffset small).
+    // (the allocation behind the 1024-byte descriptor is 1 MiB of non-zero pattern, so that a check that wrapped would read
+    // pattern bytes from inside the allocation: no fault either way, and zeros can only come from the range check)
+    float* d3;
+    const int big = 1 << 20;
+    hipMalloc(&d3, big);
+    std::vector<float> h3(big / 4);
+    for (int i = 0; i < big / 4; ++i) h3[i] = 5.0f + (i & 1023);
+    hipMemcpy(d3, h3.data(), big, hipMemcpyHostToDevice);
+    for (const int soff : {1024, 1040, 4096, 65536, 0x80000}) {
+        hipLaunchKernelGGL(probe_soffset, dim3(1), dim3(64), 0, 0, d3, 1024, soff, o);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("soffset %#x: the launch faulted\n", soff); return 1; }
+        hipMemcpy(r.data(), o, 1024, hipMemcpyDeviceToHost);
+        int zeros = 0, stale = 0, other = 0;
+        for (int i = 0; i < 256; ++i) { zeros += r[i] == 0.0f; stale += r[i] == -7.0f; other += r[i] != 0.0f && r[i] != -7.0f; }
+        printf("soffset %#8x > num_records 1024, voffsets in range: %d zeros, %d stale, %d pattern values read past the descriptor (of 256 floats)\n",
+               soff, zeros, stale, other);
+    }
     return 0;
 }

@@ -3,7 +3,7 @@
 # pass (separate runs with --kernel-trace only, as MI355X_MICROARCH.md prescribes), summarised into gpurun_out/<tag>_*.json / .csv;
 # copy the summaries into profiles/ afterwards.  usage: tools/profile_bench.sh <tag> [bench args]
 set -e -o pipefail
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
@@ -12,46 +12,44 @@ ARGS="--steps 50 --warmup 5 --no-cpu-baseline --no-secondary $*"
 cd "$ROOT"
 python3 bench.py $ARGS > "$OUT/${TAG}_bench_plain.json"            # fills the tune cache: profiled runs replay the plan
 export TMPDIR=/tmp
-# Round 1: under rocprofv3 (ROCm 7.2) a hipGraphLaunch of the plan replayed from the tune cache crashed, so every profiled run
-# issued the forward as ordinary launches (FCN_NO_GRAPH=1).  Round 2: ONE diagnostic run of the same command with graphs on and
-# PYTHONFAULTHANDLER=1 finished normally (gpurun_out/r2/graphprof: the crash does not reproduce with this round's kernels - the
-# group kernel's argument block changed - and its cause stays unknown).  The kernel-trace passes therefore profile the hipGraph
-# replay itself, the launch path `value` is measured on; the counter passes keep plain launches (per-kernel counters do not depend
-# on how a kernel was launched, and that combination was never tried).
+# Order (round 3, after the advisor's note): the plain-launch passes FIRST - they have never failed - and every pass guarded, so that a
+# failure of a later pass (the hipGraph replay under the profiler crashed once in round 1) cannot cost the data of
+# the others.  PYTHONFAULTHANDLER keeps a backtrace in $OUT/<pass>.err if one dies.
 prof() {      # prof <dir> <rocprofv3 options...> -- <program...>   (the program itself follows `--`: never a wrapper)
     local d=$1; shift
     rm -rf "$OUT/$d"
-    ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/$d" -o run "$@" )
+    ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/$d" -o run "$@" ) 2> "$OUT/$d.err" || { echo "pass $d FAILED:"; tail -5 "$OUT/$d.err"; return 0; }
 }
-# (1) ONE frame in flight: per-kernel durations (what `roofline` is computed from) only mean something when launches do not overlap
-ONE="$ARGS --in-flight 1"
+ONE="$ARGS --in-flight 1"      # ONE frame in flight: per-kernel durations only mean something when launches do not overlap
 export PYTHONFAULTHANDLER=1
-prof ${TAG}_stats --stats -- python3 "$ROOT/bench.py" $ONE --no-train > "$OUT/${TAG}_bench_under_rocprof.json"      # hipGraph replay
-export FCN_NO_GRAPH=1      # the training step and the counter passes: plain launches, as in round 1
+export FCN_NO_GRAPH=1          # plain launches: the training step, the counter passes, and a kernel trace of the forward
+prof ${TAG}_pstats --stats -- python3 "$ROOT/bench.py" $ONE --no-train --trace-clean > "$OUT/${TAG}_bench_plain_under_rocprof.json"
 prof ${TAG}_tstats --stats -- python3 "$ROOT/bench.py" $ONE > "$OUT/${TAG}_train_under_rocprof.json"
 prof ${TAG}_fetch --pmc FETCH_SIZE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
 prof ${TAG}_write --pmc WRITE_SIZE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
-# (2) matrix-core counters (SQ block, own pass): busy cycles of the MFMA pipes against the SQ's busy cycles, MFMA op counts
-prof ${TAG}_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null || echo "MFMA counter pass failed (counter names: rocprofv3 -L)"
-prof ${TAG}_tmfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/bench.py" $ONE > /dev/null || echo "MFMA counter pass (train) failed"
-# (2b) BASELINE configs[4]: batch-32 half-float forward, HBM bytes per forward
+# matrix-core counters (SQ block, own pass): busy cycles of the MFMA pipes against the SQ's busy cycles, MFMA op counts
+prof ${TAG}_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
+prof ${TAG}_tmfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/bench.py" $ONE > /dev/null
+# BASELINE configs[4]: batch-32 half-float forward - a CLEAN kernel trace first, then HBM bytes per forward and the matrix cores
 N32=20
 python3 tools/fwd_resident.py 32 f16 2 > /dev/null      # fills the tune cache for the batch-32 f16 plan
+prof ${TAG}_f16_stats --stats -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > "$OUT/${TAG}_infer32_f16_trace_run.json"
 prof ${TAG}_f16_fetch --pmc FETCH_SIZE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > "$OUT/${TAG}_infer32_f16_run.json"
 prof ${TAG}_f16_write --pmc WRITE_SIZE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > /dev/null
-prof ${TAG}_f16_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > /dev/null || echo "MFMA counter pass (f16) failed"
-# (3) the mode `value` is measured in: four frames in flight, four hipGraphs replayed side by side (last: never profiled before
-#     this round; a failure here must not cost the passes above)
+prof ${TAG}_f16_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -- python3 "$ROOT/tools/fwd_resident.py" 32 f16 $N32 > /dev/null
+# the hipGraph replay itself, the launch path `value` is measured on: one frame in flight (what `roofline` is computed from), then four
 unset FCN_NO_GRAPH
+prof ${TAG}_stats --stats -- python3 "$ROOT/bench.py" $ONE --no-train --trace-clean > "$OUT/${TAG}_bench_under_rocprof.json"
 rm -rf "$OUT/${TAG}_inflight"
 ( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_inflight" -o run -- python3 "$ROOT/bench.py" $ARGS --no-train \
-    > "$OUT/${TAG}_bench_inflight_under_rocprof.json" ) || echo "in-flight pass under rocprofv3 failed"
-for pair in stats:bench_kernel_stats tstats:train_kernel_stats fetch:bench_pmc_fetch write:bench_pmc_write mfma:bench_pmc_mfma tmfma:train_pmc_mfma \
-            inflight:bench_inflight_kernel_stats f16_fetch:infer32_f16_pmc_fetch f16_write:infer32_f16_pmc_write f16_mfma:infer32_f16_pmc_mfma; do
+    > "$OUT/${TAG}_bench_inflight_under_rocprof.json" ) 2> "$OUT/${TAG}_inflight.err" || echo "in-flight pass under rocprofv3 failed"
+[ -d "$OUT/${TAG}_stats" ] || { echo "graph-replay trace missing: using the plain-launch trace for the kernel statistics"; cp -r "$OUT/${TAG}_pstats" "$OUT/${TAG}_stats"; }
+for pair in stats:bench_kernel_stats pstats:bench_plain_kernel_stats tstats:train_kernel_stats fetch:bench_pmc_fetch write:bench_pmc_write mfma:bench_pmc_mfma tmfma:train_pmc_mfma \
+            inflight:bench_inflight_kernel_stats f16_stats:infer32_f16_kernel_stats f16_fetch:infer32_f16_pmc_fetch f16_write:infer32_f16_pmc_write f16_mfma:infer32_f16_pmc_mfma; do
     d=${pair%%:*}; o=${pair##*:}
     [ -d "$OUT/${TAG}_$d" ] && python3 tools/parse_rocprof.py "$OUT/${TAG}_$d" "$OUT/${TAG}_$o.json" || true
 done
-for pair in stats:bench_kernel_stats tstats:train_kernel_stats inflight:bench_inflight_kernel_stats; do
+for pair in stats:bench_kernel_stats tstats:train_kernel_stats inflight:bench_inflight_kernel_stats f16_stats:infer32_f16_kernel_stats; do
     d=${pair%%:*}; o=${pair##*:}
     f=$(find "$OUT/${TAG}_$d" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_$o.csv"
 done
@@ -73,5 +71,5 @@ except Exception as e:
     print("infer32 summary failed:", e)
 PY
 # the raw traces are large: keep the summaries only
-for d in stats tstats fetch write mfma tmfma inflight f16_fetch f16_write f16_mfma; do rm -rf "$OUT/${TAG}_$d"; done
+for d in stats pstats tstats fetch write mfma tmfma inflight f16_stats f16_fetch f16_write f16_mfma; do rm -rf "$OUT/${TAG}_$d"; done
 ls -la "$OUT" | grep "${TAG}_"

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Derive bench.py's `roofline.frac` for the f32 batch-1 convolution family from the committed rocprofv3 summaries ALONE.
+
+usage: roofline_from_profile.py <tag>            (reads profiles/<tag>_bench_kernel_stats.csv [+ <tag>_bench_pmc_mfma.json],
+                                                  writes profiles/<tag>_bench_roofline.json)
+
+  conv_us_per_frame = sum of TotalDurationNs of the forward convolution kernels (conv_fwd_group*, conv_fwd_one*, conv_first7*,
+                      conv_dot1x1*) / frames, frames = calls of the first-layer kernel (it runs once per forward)
+  achieved          = 15.608 GFLOP / conv_us_per_frame          frac = achieved / 157.3 TFLOP/s
+  mfma_busy_frac    = sum of SQ_VALU_MFMA_BUSY_CYCLES / 1024 (cycles the average matrix pipe of the chip was busy, per frame)
+                      / (conv_us_per_frame x clock); the clock is an ASSUMPTION written into the file (2.18 GHz: what the stamped
+                      build measured inside these kernels in round 2; 2.4 GHz is what the 157.3 TF peak assumes)
+rocprofv3's durations are in-sequence (each kernel in the cache state of a real forward); bench.py times its launches the same way
+(Engine.time_ops_in_sequence), so the two agree; the `warm` figure bench.py prints beside it repeats one launch back to back."""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FWD_GFLOP, PEAK_TF, CLOCK_GHZ = 15.608, 157.3, 2.18
+CONV = ("conv_fwd_group", "conv_fwd_one", "conv_first7", "conv_dot1x1")
+
+
+def main():
+    tag = sys.argv[1]
+    stats = os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv")
+    conv_ns, frames, rows = 0, 0, []
+    for r in csv.DictReader(open(stats)):
+        name = r["Name"]
+        if any(c in name for c in CONV) and "wgrad" not in name:
+            conv_ns += int(r["TotalDurationNs"])
+            rows.append({"kernel": name.replace("(anonymous namespace)::", "")[:90], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2)})
+            if "conv_first7" in name:
+                frames += int(r["Calls"])
+    if not frames:
+        raise SystemExit("no first-layer kernel in %s: cannot count the frames" % stats)
+    us = conv_ns / 1e3 / frames
+    out = {"source": "profiles/%s_bench_kernel_stats.csv" % tag, "frames": frames, "conv_us_per_frame": round(us, 2),
+           "achieved_tflops": round(FWD_GFLOP / us * 1e-3 * 1e3, 3), "peak_tflops": PEAK_TF, "frac": round(FWD_GFLOP / us / PEAK_TF, 4),
+           "kernels": rows, "clock_ghz_assumed": CLOCK_GHZ}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_pmc_mfma.json")))
+        busy, pframes = 0.0, 0
+        for k, v in pmc["counters"].items():
+            if any(k.startswith(c) for c in CONV):
+                busy += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+                if k.startswith("conv_first7"):
+                    pframes += v["calls"]
+        if pframes:
+            per_frame = busy / 1024.0 / pframes
+            out["mfma_busy_cycles_per_simd_per_frame"] = round(per_frame, 1)
+            out["mfma_busy_frac"] = round(per_frame / (us * CLOCK_GHZ * 1e3), 4)
+            out["mfma_busy_note"] = ("SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs per frame (profiles/%s_bench_pmc_mfma.json) over conv_us_per_frame x the assumed clock; "
+                                     "at 2.4 GHz the same cycles are %.4f of the time" % (tag, per_frame / (us * 2.4e3)))
+            out["kernel_source_hash"] = pmc.get("kernel_source_hash")
+    except (OSError, KeyError, ValueError):
+        pass
+    dst = os.path.join(ROOT, "profiles", tag + "_bench_roofline.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print("wrote", dst, "frac", out["frac"], "mfma_busy_frac", out.get("mfma_busy_frac"))
+
+
+if __name__ == "__main__":
+    main()
