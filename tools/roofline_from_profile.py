@@ -37,7 +37,7 @@ def main():
         raise SystemExit("no first-layer kernel in %s: cannot count the frames" % stats)
     us = conv_ns / 1e3 / frames
     out = {"source": "profiles/%s_bench_kernel_stats.csv" % tag, "frames": frames, "conv_us_per_frame": round(us, 2),
-           "achieved_tflops": round(FWD_GFLOP / us * 1e-3 * 1e3, 3), "peak_tflops": PEAK_TF, "frac": round(FWD_GFLOP / us / PEAK_TF, 4),
+           "achieved_tflops": round(FWD_GFLOP / us * 1e3, 3), "peak_tflops": PEAK_TF, "frac": round(FWD_GFLOP / us * 1e3 / PEAK_TF, 4),
            "kernels": rows, "clock_ghz_assumed": CLOCK_GHZ}
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_pmc_mfma.json")))
