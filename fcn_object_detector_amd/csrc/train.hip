@@ -51,7 +51,7 @@ struct WgradP {
     int M, K;
     int tiles_n, tiles_k, splits, chunks_per_split;   // chunk = 32 pixels
     int slab_floats;                                   // Cout*K + Cout
-    unsigned ow_magic, ohw_magic;                      // ceil(2^32 / OW), ceil(2^32 / (OH*OW)) for the pixel decode
+    unsigned ow_magic, oh_magic;                       // ceil(2^32 / OW), ceil(2^32 / OH) for the pixel decode (0: the extent is 1)
     int kw_magic;
 };
 
@@ -113,7 +113,7 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* sm
     if (nchunks > p.chunks_per_split) nchunks = p.chunks_per_split;
     if (nchunks < 0) nchunks = 0;
     const int chunk_end = chunk0 + nchunks;
-    const int ohw = p.OH * p.OW;
+
 
     // Both operands are fetched with `buffer_load ... lds`: 32-bit offsets, and lanes that must read zeros (rows past M,
     // columns past Cout, taps outside the image, chunks past this split's range) simply carry an out-of-range offset - the
@@ -144,10 +144,13 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* sm
         const int m = issue_chunk_idx * WG_BP + row;
         const bool m_ok = (int)(m < p.M) & (int)(issue_chunk_idx < chunk_end);
         const int mm = m_ok ? m : 0;
-        const int img = (int)__umulhi((unsigned)mm, p.ohw_magic);
-        const int rem = mm - img * ohw;
-        const int oy = (int)__umulhi((unsigned)rem, p.ow_magic);
-        const int ox = rem - oy * p.OW;
+        // m -> (img, oy, ox) by OW, then by OH: umulhi(m, ceil(2^32 / d)) is exact only while m * d < 2^32 (wgrad_validate).  Round 2
+        // divided by OH * OW in one step: at 448x448 and batch >= 2 conv1 has m * OH * OW > 2^32, the last ~5 pixels of every image
+        // decoded to the NEXT image and conv1's dW was off by 8e-4 (found by tests/test_gpu_fullsize.py's full-resolution backward).
+        const int t = p.ow_magic ? (int)__umulhi((unsigned)mm, p.ow_magic) : mm;
+        const int ox = mm - t * p.OW;
+        const int img = p.oh_magic ? (int)__umulhi((unsigned)t, p.oh_magic) : t;
+        const int oy = t - img * p.OH;
         const int iy = oy * p.stride - p.pad + kr;
         const int ix = ox * p.stride - p.pad + kq;
         const bool ok = (int)m_ok & (int)k_ok & (int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W);
@@ -160,7 +163,7 @@ __device__ __forceinline__ void wgrad_body(const WgradP& p, int block, float* sm
     auto issue_pre = [&](const int) {};
     auto issue_n = [&](const int) {};
     auto issue_k = [&](const int) {};
-    (void)OOB; (void)dy_col_ok; (void)k_ok; (void)kr; (void)kq; (void)kch; (void)ohw; (void)chunk_end; (void)n_row; (void)k_row;
+    (void)OOB; (void)dy_col_ok; (void)k_ok; (void)kr; (void)kq; (void)kch; (void)chunk_end; (void)n_row; (void)k_row;
     (void)NW; (void)RN; (void)RK; (void)issue_chunk_idx;
 #endif
     auto issue_chunk = [&](const int buf) {
@@ -880,6 +883,8 @@ static int wgrad_validate(const fcn_conv_desc* d) {
     FCN_REQUIRE((long long)d->N * d->OH * d->OW < (1ll << 31) && (long long)d->N * d->H * d->W * d->x_cstride < (1ll << 31), FCN_E_UNSUPPORTED,
                 "wgrad: tensor too large");
     FCN_REQUIRE(d->y_cstride >= d->y_coffset + d->Cout, FCN_E_ARG, "wgrad: gradient slice exceeds its channel stride");
+    FCN_REQUIRE((long long)d->N * d->OH * d->OW * (d->OW > d->OH ? d->OW : d->OH) < (1ll << 32), FCN_E_UNSUPPORTED,
+                "wgrad: N*OH*OW*max(OH,OW) must stay below 2^32 (multiply-high pixel decode): split the batch");
     FCN_REQUIRE((long long)d->N * d->OH * d->OW * d->y_cstride * 4 < (1ll << 31) && (long long)d->N * d->H * d->W * d->x_cstride * 4 < (1ll << 31),
                 FCN_E_UNSUPPORTED, "wgrad: x and dY must each stay below 2 GiB (32-bit buffer offsets): split the batch");
     return 0;
@@ -898,8 +903,8 @@ static void wgrad_fill(WgradP& p, const fcn_conv_desc* d, int cfg, int splits, f
     p.tiles_k = cdiv(p.K, kWgShapes[cfg].bk);
     p.splits = splits;
     p.chunks_per_split = cdiv(cdiv(p.M, WG_BP), splits);
-    p.ow_magic = magic32((unsigned)p.OW);
-    p.ohw_magic = magic32((unsigned)(p.OH * p.OW));
+    p.ow_magic = p.OW > 1 ? magic32((unsigned)p.OW) : 0u;
+    p.oh_magic = p.OH > 1 ? magic32((unsigned)p.OH) : 0u;
     p.kw_magic = (65536 + p.kw - 1) / p.kw;
     p.dw_part = slabs;
     p.slab_floats = (p.Cout * p.K + p.Cout + 3) / 4 * 4;      // slabs stay 16-byte aligned for the reduction's float4 loads

@@ -85,6 +85,81 @@ def test_config2_train_step_batch8_448(gpu):
     eng.close()
 
 
+def test_full_backward_448_to_conv1_and_an_independent_oracle_step(gpu, capsys):
+    """Two things the batch-8 test above leaves open:
+
+    (a) the WHOLE backward at full resolution: batch 2, 448x448, the oracle's backward down to conv1/7x7_s2 on the device's own
+        activations - every parameter gradient of the net (59 convolutions) and the stem's blob gradients at 1e-3;
+    (b) a fully INDEPENDENT oracle step (its own forward pass, its own ReLU masks and pooling argmaxes): how many mask / argmax
+        sites differ from the device's, and what that does to the gradients.  ReLU and MAX pooling are discontinuous, so two
+        independently rounded forward passes flip a few near-zero activations / near-tied windows; the bound asserted here is the
+        measured effect with a margin (the numbers are printed and quoted in DESIGN.md 2)."""
+    from oracle import caffe_ref as R
+    n, size = 2, 448
+    msg = proto.parse_text(models.googlenet_detectnet_train("m", "L", "unused", num_classes=1))
+    rng = np.random.default_rng(7)
+    rects = synth_boxes(rng, n, size)
+    shapes = {"data": (n, 3, size, size), "coverage-label": (n, 1, 28, 28)}
+    for k in LABELS[1:]:
+        shapes[k] = (n, 4, 28, 28)
+    spec = NetSpec(msg, "TRAIN")
+    spec.infer(shapes)
+    params = fill_params(spec, seed=1234)
+    eng = TrainEngine(NetSpec(msg, "TRAIN"), shapes, params={k: [a.copy() for a in v] for k, v in params.items()}, device=0,
+                      solver=SolverParams(base_lr=0.0, momentum=0.9, weight_decay=0.0, lr_policy="fixed"))
+    data = {"data": rng.random((n, 3, size, size), dtype=np.float32)}
+    eng.host_array("data")[...] = data["data"]
+    eng.set_targets(rects, [[0] * len(r) for r in rects], stride=16)
+    eng.step(seed=5)
+    lab = [D.bounding_box_parameterized_labels(size, size, r, [0] * len(r), 16, 1) for r in rects]
+    for j, name in enumerate(LABELS):
+        data[name] = np.stack([o[j] for o in lab]).astype(np.float32)
+    got = eng.download_grads()
+
+    # (b) first: the independent step
+    ref = RefNet(msg, "TRAIN", {k: [a.copy() for a in v] for k, v in params.items()})
+    ref.blobs.update(data)
+    ref.dropout_seed = 5
+    ref.forward()
+    ind = ref.backward()
+    relu_sites = relu_flips = 0
+    for l in spec.layers:
+        if l.type == "ReLU":
+            a, b = ref.blobs[l.tops[0]] > 0, eng.read_blob(l.tops[0]) > 0
+            relu_sites += a.size
+            relu_flips += int((a != b).sum())
+    pool_sites = pool_flips = 0
+    for l in spec.layers:
+        if l.type == "Pooling" and str(l.sub("pooling_param").get("pool", "MAX")) == "MAX":
+            k, s_, p_ = (int(l.sub("pooling_param").get(q, d)) for q, d in (("kernel_size", 0), ("stride", 1), ("pad", 0)))
+            dev_idx = R.max_pool(eng.read_blob(l.bottoms[0]), k, s_, p_, return_index=True)[1]
+            pool_sites += dev_idx.size
+            pool_flips += int((np.asarray(ref.aux[l.name]) != dev_idx).sum())
+    ind_err = {name: max(rel_err(g, r) for g, r in zip(got[name], ind[name])) for name in ind}
+    worst = max(ind_err, key=ind_err.get)
+    with capsys.disabled():
+        print("\nindependent oracle step, batch %d at %dx%d: ReLU mask flips %d of %d (%.2e), MAX-pool argmax flips %d of %d (%.2e); "
+              "parameter-gradient rel. error: median %.2e, max %.2e (%s)" % (
+                  n, size, size, relu_flips, relu_sites, relu_flips / relu_sites, pool_flips, pool_sites, pool_flips / pool_sites,
+                  float(np.median(list(ind_err.values()))), ind_err[worst], worst))
+    # measured (MI355X, round 3): 8 of 28.5 M ReLU sites (2.8e-7), 3587 of 13.0 M argmaxes (2.8e-4); gradients: median 2.9e-4, max 1.7e-3
+    assert relu_flips <= 1e-5 * relu_sites and pool_flips <= 1e-3 * pool_sites      # a handful of near-zero / near-tied sites ...
+    assert max(ind_err.values()) < 5e-3 and float(np.median(list(ind_err.values()))) < 1e-3      # ... and what they do to the gradients
+
+    # (a) the whole backward on the device's activations: identical masks and argmaxes, what is left is the backward arithmetic
+    adopt_device_activations(ref, eng, spec, keep=data)
+    grads = ref.backward()
+    assert set(grads) == set(got) and len(grads) == 59
+    for name in grads:
+        for g, r in zip(got[name], grads[name]):
+            assert g.shape == r.shape and rel_err(g, r) < 1e-3, name
+    # (blob gradients of the stem; a concatenation's gradient is not compared: the device applies the ReLU masks of the four
+    #  producing convolutions to it in place, the oracle keeps the gradient of the concatenated blob)
+    for name in ("conv1/7x7_s2", "pool1/3x3_s2", "pool1/norm1", "conv2/3x3_reduce", "conv2/3x3", "conv2/norm2", "pool2/3x3_s2"):
+        assert rel_err(eng.read_grad(name), ref.diffs[name]) < 1e-3, name
+    eng.close()
+
+
 def test_config4_batch32_f16_with_fused_decode(gpu):
     n, size, classes = 32, 448, 4
     msg = proto.parse_text(models.googlenet_detectnet_deploy(n, size, size, classes))
