@@ -56,9 +56,12 @@ def _train(rank, world, port, use_rccl, steps, q, devices=None):
             eng.host_array(k)[...] = v[rank * per:(rank + 1) * per]
         losses.append(eng.step(seed=50 + it)["loss"])
     out = eng.download_params()
+    grads = eng.download_grads()      # the last step's gradient buffer AFTER the all-reduce (summed over the ranks, before the 1/G of the update)
     eng.close()
     cp.close()
-    q.put((rank, losses, {k: [a.copy() for a in v] for k, v in out.items() if k in ("conv1/7x7_s2", "inception_4c/3x3", "bbox/regressor")}))
+    keep = ("conv1/7x7_s2", "inception_4c/3x3", "bbox/regressor")
+    q.put((rank, losses, {k: [a.copy() for a in v] for k, v in out.items() if k in keep},
+           {k: [a.copy() for a in v] for k, v in grads.items() if k in keep}))
 
 
 def _run(world, use_rccl, steps=2, devices=None):
@@ -121,3 +124,14 @@ def test_rccl_two_ranks_on_two_devices(gpu):
             assert rel_err(b, a) < 1e-3, k                      # and equal the undivided batch
     for it in range(len(single[1])):
         assert abs(0.5 * (two[0][1][it] + two[1][1][it]) - single[1][it]) < 1e-3 * abs(single[1][it])
+    # the same two ranks on the same two GPUs with the gradients summed through host memory in rank order: with two ranks a sum
+    # has one order (a + b = b + a in floating point), so ncclAllReduce over the fixed buckets must give the SAME bits - in the
+    # gradient buffer of the last step and in every weight after it
+    host = _run(2, use_rccl=False, devices=(0, 1))
+    for r in range(2):
+        assert two[r][1] == host[r][1]                          # losses, step by step
+        for k in host[r][3]:
+            for a, b in zip(two[r][3][k], host[r][3][k]):
+                assert np.array_equal(a, b), ("gradient", k)
+            for a, b in zip(two[r][2][k], host[r][2][k]):
+                assert np.array_equal(a, b), ("weights", k)

@@ -160,6 +160,48 @@ def test_conv_group_launch(gpu):
     assert rel_err(y, ref) < TOL
 
 
+def test_a_reused_workspace_address_gets_a_fresh_plan(gpu):
+    """The library keeps the host copy of a prepared launch group keyed by its device workspace.  Two prepares on the SAME address
+    (an engine closed, another one's workspace handed the address again): the second plan must be the one that runs, a handle of
+    the first plan must be refused when it no longer describes what is registered, and a released workspace launches nothing
+    (what the round-1 abort under rocprofv3 was - and was not - about)."""
+    rng = np.random.default_rng(21)
+    lib = L.load()
+    x = rng.standard_normal((1, 64, 12, 12)).astype(np.float32)
+    xd = dev_from(nhwc(x))
+    wsd = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(2)), zero=False)
+
+    def plan(couts, k):
+        keep, descs, refs = [], [], []
+        for co in couts:
+            wt = (rng.standard_normal((co, 64, k, k)) * 0.05).astype(np.float32)
+            b = rng.standard_normal(co).astype(np.float32)
+            wd, bd, yd = dev_from(pack_ohwi(wt)), dev_from(b), dev_from(np.zeros((1, 12, 12, co), np.float32))
+            keep += [wd, bd, yd]
+            descs.append(conv_desc(xd, wd, bd, yd, 1, 12, 12, 64, 64, co, k, k // 2, 1, 12, 12, co, 0, L.CONV_RELU))
+            refs.append((yd, co, R.relu(R.conv2d(x, wt, b, k // 2, 1))))
+        grp = L.ConvGroup()
+        L.call("fcn_conv2d_group_prepare", (L.ConvDesc * len(descs))(*descs), len(descs), wsd.ptr, -1, C.byref(grp))
+        return grp, refs, keep
+
+    def check(grp, refs):
+        L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+        for yd, co, ref in refs:
+            assert rel_err(nchw(dev_to(yd, (1, 12, 12, co)), co), ref) < TOL
+
+    first, refs1, keep1 = plan([32, 48], 1)
+    check(first, refs1)
+    second, refs2, keep2 = plan([40], 3)                     # same workspace address, another plan (one problem, 3x3)
+    assert second.d_probs == first.d_probs
+    check(second, refs2)                                     # the second plan is what runs
+    assert lib.fcn_conv2d_fwd_group_f32(C.byref(first), None) != 0      # the first handle (n = 2) no longer matches the registry (n = 1)
+    L.call("fcn_conv2d_group_release", wsd.ptr)
+    assert lib.fcn_conv2d_fwd_group_f32(C.byref(second), None) != 0     # released: nothing is registered behind the address
+    third, refs3, keep3 = plan([32, 48], 1)                  # and a prepare after the release registers a fresh plan again
+    check(third, refs3)
+    L.call("fcn_conv2d_group_release", wsd.ptr)
+
+
 @pytest.mark.parametrize("cfg", [23, 21, 18])      # 32 x 32 tiles: 588 / 744 workgroups
 @pytest.mark.parametrize("hw", [56, 61])
 def test_conv_group_many_rounds_of_workgroups(gpu, cfg, hw):

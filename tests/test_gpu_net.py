@@ -81,6 +81,43 @@ def test_batch_and_odd_sizes(gpu):
     eng.close()
 
 
+def test_first_launch_of_every_kernel_happens_outside_the_stream_capture(gpu, monkeypatch, tmp_path):
+    """An engine whose plan comes from the tune cache (no autotuning launches) must still run its launches ONCE eagerly before it
+    captures them: code objects load lazily on a kernel's first launch, and a first launch inside a stream capture is what
+    aborted under rocprofv3 in round 1.  Recorded: the order of graph begin and the first pass of every launch."""
+    import json
+    from fcn_object_detector_amd import lib as L
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(batch=1, height=96, width=128, num_classes=2))
+    spec = NetSpec(msg, "TEST")
+    spec.infer()
+    params = fill_params(spec, seed=3)
+    cache = tmp_path / "tune.json"
+    monkeypatch.setenv("FCN_TUNE_CACHE", str(cache))
+    eng = Engine(NetSpec(msg, "TEST"), params=params, device=0)      # fills the cache (autotuned)
+    eng.close()
+    assert len(json.load(open(cache))) > 5
+    eng = Engine(NetSpec(msg, "TEST"), params=params, device=0)      # replays the cached plan: not a single launch so far
+    events = []
+    real_call = L.call
+
+    def spy(name, *a):
+        if name in ("fcn_graph_begin", "fcn_graph_end"):
+            events.append(name)
+        return real_call(name, *a)
+
+    for i, op in enumerate(eng.ops):
+        op.run = (lambda st, f=op.run, i=i: (events.append(("op", i)), f(st))[1])
+    monkeypatch.setattr(L, "call", spy)
+    eng.host_array("data")[...] = np.random.default_rng(0).random((1, 3, 96, 128), dtype=np.float32)
+    out = eng.forward()
+    begin = events.index("fcn_graph_begin")
+    assert [e for e in events[:begin] if e != "fcn_graph_end"] == [("op", i) for i in range(len(eng.ops))]      # one eager pass first
+    assert events[begin + 1:begin + 1 + len(eng.ops)] == [("op", i) for i in range(len(eng.ops))]                # then the captured one
+    assert np.isfinite(out["coverage"]).all()
+    monkeypatch.setattr(L, "call", real_call)
+    eng.close()
+
+
 def test_forward_pipeline_equals_lone_engine(gpu):
     """ForwardPipeline: three replicas (own stream and activations), frames handed out round-robin: every frame's result is
     the lone engine's, bit for bit and in submission order; the replicas take over the first one's tile plan."""
