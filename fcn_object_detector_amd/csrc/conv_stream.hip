@@ -42,7 +42,7 @@ namespace {
 __device__ unsigned long long* g_stream_stamps = nullptr;
 __device__ int g_stream_stamps_cap = 0;
 #define SNOW() __builtin_amdgcn_s_memrealtime()
-#define SSTAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0_ = SNOW(), st_t_ = st_t0_
+#define SSTAMP_DECL unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t0_ = SNOW(), st_t_ = st_t0_, st_c0_ = __builtin_amdgcn_s_memtime()
 #define SSTAMP(i)                                         \
     do {                                                  \
         const unsigned long long n_ = SNOW();             \
@@ -62,6 +62,11 @@ __device__ int g_stream_stamps_cap = 0;
 #define SSTAMP_FLUSH(role) do { } while (0)
 #endif
 
+#ifdef FCN_EXP_NOPRIO
+constexpr bool getenv_free_noprio = true;
+#else
+constexpr bool getenv_free_noprio = false;
+#endif
 constexpr int kBM = 256;          // pixels per tile
 constexpr int kChunkK = 64;       // halves of K per chunk (128-byte LDS rows)
 
@@ -173,23 +178,29 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         int ti = v, r = 0, cc = 0, q = 0, kh = 1, kw = 1, ncc = 1, cin = 0;
         bool live = true;
         const f16_t* pw = nullptr;
-        int w_bytes = 0;
+        int w_bytes = 0, cur_pi = -1, p_cout = 0, p_K = 0, p_tiles_n = 1;
+        unsigned p_tiles_n_magic = 0;
         auto setup = [&]() __attribute__((always_inline)) {
             int pi, begin;
             find_problem(ti, pi, begin);
-            const ConvP p = load_problem(pi);
+            if (pi != cur_pi) {      // (the problem changes at most a few times per launch: no scalar reload otherwise - every
+                                     //  s_barrier needs all eight waves, so a load latency here stalls the multipliers)
+                const ConvP p = load_problem(pi);
+                cur_pi = pi;
+                pw = reinterpret_cast<const f16_t*>(p.w);
+                w_bytes = p.Cout * p.K * 2;
+                kh = p.kh; kw = p.kw; cin = p.Cin;
+                ncc = (p.Cin + kChunkK - 1) / kChunkK;
+                p_cout = p.Cout; p_K = p.K; p_tiles_n = p.tiles_n; p_tiles_n_magic = p.tiles_n_magic;
+            }
             const int lt = ti - begin;
-            const int tile_m = fast_div(lt, p.tiles_n_magic);
-            const int n0 = (lt - tile_m * p.tiles_n) * BN;
+            const int tile_m = fast_div(lt, p_tiles_n_magic);
+            const int n0 = (lt - tile_m * p_tiles_n) * BN;
 #pragma unroll
             for (int t = 0; t < NPB; ++t) {
                 const int n = n0 + 8 * (wb + 2 * t) + (lane >> 3);
-                b_vo[t] = n < p.Cout ? (n * p.K + lane_c) * 2 : OOB;
+                b_vo[t] = n < p_cout ? (n * p_K + lane_c) * 2 : OOB;
             }
-            pw = reinterpret_cast<const f16_t*>(p.w);
-            w_bytes = p.Cout * p.K * 2;
-            kh = p.kh; kw = p.kw; cin = p.Cin;
-            ncc = (p.Cin + kChunkK - 1) / kChunkK;
             r = cc = q = 0;
         };
         auto issue_chunk = [&](const int slot) __attribute__((always_inline)) {
@@ -254,58 +265,95 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         const int lseg = (lane & 7) ^ ((4 * wa + (lane >> 4)) & 7);      // as for the weight pieces: piece p = wa + 2 t, row 8 p + lane / 8
         const int lane_c = lseg * 8;
         char* const lds_wave = smem + wa * 1024;
-        int off_c[NPA], vmask[NPA];      // byte offset of the lane's segment in the CENTRE row (r = pad); bit r: row r exists for it
-        int ti = v, r = 0, cc = 0, kh = 1, ncc = 1, cin = 0, pad = 0, row_bytes = 0;
-        bool live = true;
-        const f16_t* px = nullptr;
-        int x_bytes = 0;
-        auto setup = [&]() __attribute__((always_inline)) {
-            int pi, begin;
-            find_problem(ti, pi, begin);
+        // what the loader keeps of a problem
+        struct SlabP {
+            const f16_t* px;
+            int x_bytes, H, W, pad, kh, cin, ncc, row_bytes, xcs, PW, rows_total, tiles_n, pi;
+            unsigned ow_magic, oh_magic, pw_magic, tiles_n_magic;
+        };
+        auto slab_problem = [&](const int pi) __attribute__((always_inline)) {
             const ConvP p = load_problem(pi);
-            const int lt = ti - begin;
-            const int tile_m = fast_div(lt, p.tiles_n_magic);
-            const int m0 = tile_m * BM;
-            // padded raster: P(img, y, x) = (img H + y) PW + x + pad, PW = W + 2 pad; the slab starts pad entries in front of P(m0)
-            const int PW = p.W + 2 * p.pad;
-            const int t0 = fast_div(m0, p.ow_magic);
-            const int pbase = t0 * PW + (m0 - t0 * p.W);      // = P(m0) - pad
-            const int rows_total = p.N * p.H;
-            // The wave's pieces are 16 slab rows apart: ONE division for its first row, then a step of 16 entries with a wrap at the
-            // end of an image row (PW >= 16, plan_tiles_cfg) - this runs once per tile on the critical path of the slab that follows.
-            const int pj = pbase + 8 * wa + (lane >> 3);
-            int t1 = fast_div(pj, p.cin_magic24);      // (stream problems: ceil(2^32 / PW), plan_tiles_cfg)
-            int xp = pj - t1 * PW;                      // 0 .. PW - 1: entry inside the padded image row
-            int y = t1 - fast_div(t1, p.oh_magic) * p.H;
-            int off = ((t1 * p.W + xp - p.pad) * p.x_cstride + lane_c) * 2;
-            const int step_off = 16 * p.x_cstride * 2, wrap_off = 2 * p.pad * p.x_cstride * 2;
+            SlabP q;
+            q.px = reinterpret_cast<const f16_t*>(p.x);
+            q.x_bytes = (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * 2);
+            q.H = p.H; q.W = p.W; q.pad = p.pad; q.kh = p.kh; q.cin = p.Cin;
+            q.ncc = (p.Cin + kChunkK - 1) / kChunkK;
+            q.row_bytes = p.W * p.x_cstride * 2;
+            q.xcs = p.x_cstride;
+            q.PW = p.W + 2 * p.pad;
+            q.rows_total = p.N * p.H;
+            q.tiles_n = p.tiles_n; q.pi = pi;
+            q.ow_magic = p.ow_magic; q.oh_magic = p.oh_magic; q.pw_magic = p.cin_magic24; q.tiles_n_magic = p.tiles_n_magic;
+            return q;
+        };
+        // Per tile and piece: byte offset of the lane's segment in the CENTRE row (r = pad) and a bit per filter row whose input row
+        // exists.  The wave's pieces are 16 slab rows apart: ONE division for its first row, then steps of 16 entries with a wrap at the
+        // end of an image row (PW >= 16, plan_tiles_cfg).  Every s_barrier needs all eight waves, so a wave that spends a microsecond
+        // on a tile's set-up stalls the multipliers for that long whatever the rings' lead: the NEXT tile's table is therefore built
+        // in slices of kSlice pieces, one slice per chunk iteration, into a second register set, and swapped in at the tile boundary.
+        constexpr int kSlice = 4, kSlices = (NPA + kSlice - 1) / kSlice;
+        int off_c[NPA], vmask[NPA], off_n[NPA], vmask_n[NPA];
+        SlabP cur, nxt;
+        int prep = 0, prep_tile = 0;          // slices of the next tile's table that are built; the tile it is for
+        int w_t1 = 0, w_xp = 0, w_y = 0, w_off = 0;      // the walk's state between slices
+        auto prep_slice = [&]() __attribute__((always_inline)) {
+            if (prep == 0) {
+                int pi, begin;
+                find_problem(prep_tile, pi, begin);
+                if (pi != nxt.pi) nxt = slab_problem(pi);      // (the problem changes at most a few times per launch: no reload otherwise)
+                const int lt = prep_tile - begin;
+                const int tile_m = fast_div(lt, nxt.tiles_n_magic);
+                const int m0 = tile_m * BM;
+                // padded raster: P(img, y, x) = (img H + y) PW + x + pad; the slab starts pad entries in front of P(m0)
+                const int t0 = fast_div(m0, nxt.ow_magic);
+                const int pj = t0 * nxt.PW + (m0 - t0 * nxt.W) + 8 * wa + (lane >> 3);
+                w_t1 = fast_div(pj, nxt.pw_magic);
+                w_xp = pj - w_t1 * nxt.PW;                    // 0 .. PW - 1: entry inside the padded image row
+                w_y = w_t1 - fast_div(w_t1, nxt.oh_magic) * nxt.H;
+                w_off = ((w_t1 * nxt.W + w_xp - nxt.pad) * nxt.xcs + lane_c) * 2;
+            }
+            const int step_off = 16 * nxt.xcs * 2, wrap_off = 2 * nxt.pad * nxt.xcs * 2;
+#pragma unroll
+            for (int sl = 0; sl < kSlices; ++sl) {
+                if (prep == sl) {      // (a scalar branch per slice: the register arrays are indexed statically inside it)
+#pragma unroll
+                    for (int t = sl * kSlice; t < (sl + 1) * kSlice && t < NPA; ++t) {
+                        const bool okx = (unsigned)(w_xp - nxt.pad) < (unsigned)nxt.W && w_t1 < nxt.rows_total;
+                        const int lo = max(nxt.pad - w_y, 0), hi = min(nxt.H + nxt.pad - w_y, nxt.kh);      // filter rows whose input row exists
+                        vmask_n[t] = (okx && hi > lo) ? (1 << hi) - (1 << lo) : 0;
+                        off_n[t] = w_off;
+                        w_xp += 16;
+                        w_off += step_off;
+                        const bool wrap = w_xp >= nxt.PW;
+                        w_xp -= wrap ? nxt.PW : 0;
+                        w_off -= wrap ? wrap_off : 0;
+                        w_t1 += wrap ? 1 : 0;
+                        w_y += wrap ? 1 : 0;
+                        w_y -= w_y >= nxt.H ? nxt.H : 0;
+                    }
+                }
+            }
+            ++prep;
+        };
+        int ti = v, r = 0, cc = 0;
+        bool live = true;
+        auto next_tile = [&]() __attribute__((always_inline)) {      // the table built for prep_tile becomes the current one
+            while (prep < kSlices) prep_slice();
 #pragma unroll
             for (int t = 0; t < NPA; ++t) {
-                const bool okx = (unsigned)(xp - p.pad) < (unsigned)p.W && t1 < rows_total;
-                const int lo = max(p.pad - y, 0), hi = min(p.H + p.pad - y, p.kh);      // filter rows whose input row exists: lo .. hi - 1
-                vmask[t] = (okx && hi > lo) ? (1 << hi) - (1 << lo) : 0;
-                off_c[t] = off;
-                xp += 16;
-                off += step_off;
-                const bool wrap = xp >= PW;
-                xp -= wrap ? PW : 0;
-                off -= wrap ? wrap_off : 0;
-                t1 += wrap ? 1 : 0;
-                y += wrap ? 1 : 0;
-                y -= y >= p.H ? p.H : 0;
+                off_c[t] = off_n[t];
+                vmask[t] = vmask_n[t];
             }
-            px = reinterpret_cast<const f16_t*>(p.x);
-            x_bytes = (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * 2);
-            kh = p.kh; cin = p.Cin; pad = p.pad;
-            ncc = (p.Cin + kChunkK - 1) / kChunkK;
-            row_bytes = p.W * p.x_cstride * 2;
+            cur = nxt;
             r = cc = 0;
+            prep = 0;
+            prep_tile = ti + G;
         };
         auto issue_slab = [&](const int buf) __attribute__((always_inline)) {
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(px), 0, x_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(cur.px), 0, cur.x_bytes, 0x00020000);
             const int soff = cc * kChunkK * 2;
-            const int roff = (r - pad) * row_bytes;
-            const bool cvalid = live && lane_c < cin - cc * kChunkK;
+            const int roff = (r - cur.pad) * cur.row_bytes;
+            const bool cvalid = live && lane_c < cur.cin - cc * kChunkK;
             const int bit = 1 << r;
             char* const dst = lds_wave + buf * SLAB;
 #pragma unroll
@@ -317,18 +365,20 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
 #endif
             }
             if (live) {
-                if (++cc == ncc) {
+                if (++cc == cur.ncc) {
                     cc = 0;
-                    if (++r == kh) {
+                    if (++r == cur.kh) {
                         ti += G;
-                        if (ti < total) setup();
+                        if (ti < total) next_tile();
                         else live = false;
                     }
                 }
             }
         };
         SSTAMP_DECL;
-        setup();
+        nxt.pi = -1;
+        prep_tile = v;
+        next_tile();
         Walk wk;
         walk_begin(wk, v);
         int buf = 0;
@@ -359,6 +409,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 issue_slab(buf);
                 buf = next(buf);
             }
+            if (prep < kSlices && prep_tile < total) prep_slice();      // one slice of the next tile's table per chunk
             walk_step(wk);
         }
         wait_vmcnt<0>();
@@ -367,6 +418,9 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         if (wa == 0) SSTAMP_FLUSH(1);
     } else {
         // ---- multiplying waves -----------------------------------------------------------------------------------------------------
+        // Every SIMD hosts one multiplying and one loading wave; vector issue between the two is arbitrated by priority, then age.
+        // The loaders have slack (they wait at the barriers most of the time), the multipliers are the critical path: static priority.
+        if (!getenv_free_noprio) __builtin_amdgcn_s_setprio(3);
         const int wm = wid_all >> 1, wn = wid_all & 1;
         const int fi = lane & 31, kh_ = lane >> 5;
         // MFMA row i of a 32-channel tile multiplies weight row tau(i): register r of half-wave kh then holds channel
@@ -412,6 +466,9 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         // loop.  The fragment registers are pinned across the wait and a scheduling barrier follows: hipcc moves register-only
         // MFMAs past a bare inline-asm s_waitcnt.
         auto frag_landed = [&](const int par, const int i, auto pending) __attribute__((always_inline)) {
+#ifdef FCN_EXP_NOWAIT      // elimination build: no fragment waits at all (wrong results: what do the waits cost?)
+            return;
+#endif
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(pending)::value) : "memory");
             asm volatile("" : "+v"(xf[i]));
 #pragma unroll
@@ -443,22 +500,29 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             int M, Cout, y_cstride, y_coffset, relu, m0, n0, kw, nch, W, PW;
             unsigned ow_magic;
         };
+        int mul_pi = -1, mul_tiles_n = 1;
+        unsigned mul_tiles_n_magic = 0;
+        MulP mul_const;      // the problem's constants (m0 / n0 are the tile's)
         auto mul_problem = [&](const int tile) __attribute__((always_inline)) {
             int pi, begin;
             find_problem(tile, pi, begin);
-            const ConvP p = load_problem(pi);
+            if (pi != mul_pi) {      // (no scalar reload - and no lgkmcnt(0) in the middle of the fragment pipeline - while the problem stays)
+                const ConvP p = load_problem(pi);
+                mul_pi = pi;
+                mul_const.y = reinterpret_cast<f16_t*>(p.y);
+                mul_const.bias = p.bias;
+                mul_const.M = p.M; mul_const.Cout = p.Cout; mul_const.y_cstride = p.y_cstride; mul_const.y_coffset = p.y_coffset;
+                mul_const.relu = p.flags & FCN_CONV_RELU;
+                mul_const.kw = p.kw;
+                mul_const.nch = p.kh * ((p.Cin + kChunkK - 1) / kChunkK) * p.kw;
+                mul_const.W = p.W; mul_const.PW = p.W + 2 * p.pad; mul_const.ow_magic = p.ow_magic;
+                mul_tiles_n = p.tiles_n; mul_tiles_n_magic = p.tiles_n_magic;
+            }
             const int lt = tile - begin;
-            const int tile_m = fast_div(lt, p.tiles_n_magic);
-            MulP q;
-            q.y = reinterpret_cast<f16_t*>(p.y);
-            q.bias = p.bias;
-            q.M = p.M; q.Cout = p.Cout; q.y_cstride = p.y_cstride; q.y_coffset = p.y_coffset;
-            q.relu = p.flags & FCN_CONV_RELU;
+            const int tile_m = fast_div(lt, mul_tiles_n_magic);
+            MulP q = mul_const;
             q.m0 = tile_m * BM;
-            q.n0 = (lt - tile_m * p.tiles_n) * BN;
-            q.kw = p.kw;
-            q.nch = p.kh * ((p.Cin + kChunkK - 1) / kChunkK) * p.kw;
-            q.W = p.W; q.PW = p.W + 2 * p.pad; q.ow_magic = p.ow_magic;
+            q.n0 = (lt - tile_m * mul_tiles_n) * BN;
             return q;
         };
         // slab row of this lane's pixel in MFMA tile i: P(m) - P(m0); the tap offset q is added per chunk
@@ -622,6 +686,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         asm volatile("" ::: "memory");
 #ifdef FCN_STREAM_STAMPS
         st_[7] = SNOW() - st_t0_;
+        st_[6] = __builtin_amdgcn_s_memtime() - st_c0_;      // shader cycles of the same span: the clock the chip held
         if (wid_all == 0) SSTAMP_FLUSH(0);
 #endif
     }

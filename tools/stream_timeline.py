@@ -66,9 +66,11 @@ def main():
             us = raw.astype(np.float64) / 100.0
             ok = us[:, 0, 7] > 0
             m = np.median(us[ok], axis=0)
+            m[0, 6] = 0.0
             print("== %s cfg %d  %d tiles, %d workgroups stamped" % (name, cfg, grp.total_tiles, int(ok.sum())))
-            print("   multiplier: chunks %.1f  barrier %.1f  epilogue %.1f  bookkeeping %.1f  next-tile %.1f  | kernel %.1f us (max %.1f)" % (
-                m[0, 0], m[0, 1], m[0, 2], m[0, 3], m[0, 4], m[0, 7], us[ok, 0, 7].max()))
+            clk = raw[ok, 0, 6].astype(np.float64) / np.maximum(raw[ok, 0, 7].astype(np.float64) * 10.0, 1.0)      # shader cycles / ns
+            print("   multiplier: chunks %.1f  barrier %.1f  epilogue %.1f  bookkeeping %.1f  next-tile %.1f  | kernel %.1f us (max %.1f)  shader clock %.2f GHz" % (
+                m[0, 0], m[0, 1], m[0, 2], m[0, 3], m[0, 4], m[0, 7], us[ok, 0, 7].max(), float(np.median(clk))))
             print("   slab wave : issue %.1f  load wait %.1f  barrier %.1f" % (m[1, 0], m[1, 1], m[1, 2]))
             print("   weight wave: issue %.1f  load wait %.1f  barrier %.1f" % (m[2, 0], m[2, 1], m[2, 2]), flush=True)
 
