@@ -251,6 +251,25 @@ def _round16(a):
     return a.astype(np.float16).astype(np.float32)
 
 
+@pytest.mark.parametrize("shape", [(2, 72, 28, 28), (1, 64, 56, 56), (3, 40, 30, 45), (1, 528, 28, 28), (2, 16, 37, 9)])
+def test_f16_lds_pooling_3x3_s1(gpu, shape):
+    """The LDS-staged 3x3 / stride 1 / pad 1 MAX pooling (the inception poolings at batch 32) against the oracle, bit for bit:
+    NEGATIVE values included (pixels outside the image are replaced by the nearest pixel inside it, never by zeros), channel
+    counts that are not multiples of 64, image extents that do not divide into tiles, output as a slice of a wider blob."""
+    n, c, h, w = shape
+    rng = np.random.default_rng(c * h + w)
+    x = _round16(rng.standard_normal((n, c, h, w)) * 3 - 1.0)
+    xh = np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16)
+    xd = dev_from(xh)
+    ref = R.max_pool(x, 3, 1, 1)
+    ycs, yco = c + 24, 16
+    yd = dev_from(np.full((n, h, w, ycs), -3.0, np.float16))
+    L.call("fcn_maxpool_fwd_f16", xd.ptr, yd.ptr, n, h, w, c, c, 3, 1, 1, h, w, ycs, yco, None)
+    y = dev_to(yd, (n, h, w, ycs), np.float16)
+    assert np.array_equal(y[..., yco:yco + c].astype(np.float32).transpose(0, 3, 1, 2), ref)
+    assert np.all(y[..., :yco] == np.float16(-3.0)) and np.all(y[..., yco + c:] == np.float16(-3.0))
+
+
 def test_f16_pointwise_kernels(gpu):
     rng = np.random.default_rng(6)
     x = _round16(rng.standard_normal((2, 24, 9, 7)) * 3)
