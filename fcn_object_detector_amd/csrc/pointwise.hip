@@ -610,6 +610,99 @@ __global__ __launch_bounds__(512) void maxpool_lrn5_f16_kernel(const _Float16* _
     *(h8_t*)(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + g * 8) = m;
 }
 
+// 3x3 / stride 2 MAX pooling and LRN (5 channels) of one half-float blob through an LDS patch, either order (pool1 -> norm1 and
+// norm2 -> pool2 of models/deploy.prototxt:54-75,137-158 at batch 32).  maxpool_lrn5_f16_kernel above recomputes the normalisation
+// for every window element (9 / 4 times per input) and was slower than the two stand-alone launches once the blobs are tens of MB;
+// here a workgroup owns 4 x TW outputs x ALL channels: the 9 x (2 TW + 1) input pixels under them go to LDS once by LDS-DMA
+// (pixels outside the image - ceil-mode windows that hang over the edge - are replaced by the nearest pixel inside: same maximum),
+// LRN runs once per pixel on the patch (LRN first) or on the pooled tile (pool first), and the blob in between never exists.
+// Same lrn5_h8 and exact maxima as the stand-alone kernels; equal to them bit for bit except at float32 values within ~1e-7 of a
+// half-way point between two halves (tests/test_gpu_f16.py: 2e-5 of the elements, one f16 ulp).
+// Measured at batch 32: pool1 + norm1 73 -> 69 us, norm2 + pool2 105 -> 92 us: the LRN arithmetic (two hardware square roots per
+// element) is what bounds both forms - the fused one saves the blob's round trip but serialises stage / normalise / pool per workgroup.
+constexpr int kPL_TH = 4;
+constexpr int kPLLdsBytes = 80 * 1024;
+
+template <bool LRN_FIRST>
+__global__ __launch_bounds__(512) void pool_lrn5_f16_lds_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int H, int W, int C, int x_cstride,
+                                                                int OH, int OW, int y_cstride, int TW, float alpha_over_n, float beta, float kk) {
+    __shared__ __attribute__((aligned(16))) char lds[kPLLdsBytes];
+    typedef const void __attribute__((address_space(1))) * gptr;
+    typedef void __attribute__((address_space(3))) * lptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int segs = C / 8, pitch = C * 2;                        // 16-byte segments / bytes per pixel
+    const int oy0 = (int)blockIdx.y * kPL_TH, ox0 = (int)blockIdx.x * TW, n = (int)blockIdx.z;
+    const int PWp = 2 * TW + 1, PH = 2 * kPL_TH + 1, npix = PH * PWp, nitems = npix * segs;
+    const _Float16* xn = x + (size_t)n * H * W * x_cstride;
+    // ---- stage the patch: item g = (pixel, segment) in patch order, 64 items (1 KiB) per wave-instruction
+    for (int i = wave; i * 64 < nitems; i += 8) {
+        int g = i * 64 + lane;
+        g = g < nitems ? g : nitems - 1;
+        const int p = g / segs, sg = g - p * segs;
+        const int pr = p / PWp, pc = p - pr * PWp;
+        int iy = 2 * oy0 + pr, ix = 2 * ox0 + pc;
+        iy = iy >= H ? H - 1 : iy;
+        ix = ix >= W ? W - 1 : ix;
+        __builtin_amdgcn_global_load_lds((gptr)(xn + ((size_t)iy * W + ix) * x_cstride + sg * 8), (lptr)(lds + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    h8_t zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (_Float16)0.f;
+    auto lrn_at = [&](const char* base, const int sg) {        // LRN of segment sg of the pixel at `base` (neighbour segments of the same pixel)
+        const h8_t c = *reinterpret_cast<const h8_t*>(base + sg * 16);
+        const h8_t l = sg > 0 ? *reinterpret_cast<const h8_t*>(base + sg * 16 - 16) : zero;
+        const h8_t r = sg + 1 < segs ? *reinterpret_cast<const h8_t*>(base + sg * 16 + 16) : zero;
+        return lrn5_h8(l, c, r, alpha_over_n, beta, kk);
+    };
+    if (LRN_FIRST) {      // normalise the patch in place: all results first (they read their neighbours' raw values), then all writes
+        constexpr int MAXI = 8;
+        h8_t res[MAXI];
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            const int g = tid + 512 * j;
+            if (g < nitems) res[j] = lrn_at(lds + (g / segs) * pitch, g % segs);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) {
+            const int g = tid + 512 * j;
+            if (g < nitems) *reinterpret_cast<h8_t*>(lds + (size_t)g * 16) = res[j];
+        }
+        __syncthreads();
+    }
+    // ---- pool: item = (output pixel of the tile, segment)
+    const int nout = kPL_TH * TW * segs;
+    char* const pooled = lds + (size_t)npix * pitch;              // (pool first: the pooled tile, normalised in a second step)
+    for (int g = tid; g < nout; g += 512) {
+        const int op = g / segs, sg = g - op * segs;
+        const int oyl = op / TW, oxl = op - oyl * TW;
+        const char* w0 = lds + ((2 * oyl) * PWp + 2 * oxl) * pitch + sg * 16;
+        h8_t m = *reinterpret_cast<const h8_t*>(w0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if (dy || dx) m = max8(m, *reinterpret_cast<const h8_t*>(w0 + (dy * PWp + dx) * pitch));
+        if (LRN_FIRST) {
+            const int oy = oy0 + oyl, ox = ox0 + oxl;
+            if (oy < OH && ox < OW) *reinterpret_cast<h8_t*>(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + sg * 8) = m;
+        } else {
+            *reinterpret_cast<h8_t*>(pooled + (size_t)g * 16) = m;
+        }
+    }
+    if (!LRN_FIRST) {
+        __syncthreads();
+        for (int g = tid; g < nout; g += 512) {
+            const int op = g / segs, sg = g - op * segs;
+            const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+            if (oy < OH && ox < OW)
+                *reinterpret_cast<h8_t*>(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + sg * 8) = lrn_at(pooled + (size_t)op * pitch, sg);
+        }
+    }
+}
+
 extern "C" {
 
 int fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int dst_cstride, int dst_coffset, float shift,
@@ -838,6 +931,22 @@ int fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C,
     const _Float16* xh = reinterpret_cast<const _Float16*>(x);
     _Float16* yh = reinterpret_cast<_Float16*>(y);
     const float aon = alpha / 5.f;
+    {   // large blobs, 3x3 / stride 2 without padding: the LDS-patch kernel (all channels of a pixel in one workgroup)
+        static const bool lds_ok = !(getenv("FCN_POOL_LDS") && atoi(getenv("FCN_POOL_LDS")) == 0);
+        const int TW = C <= 96 ? 16 : 8;
+        const long long patch = (long long)(2 * kPL_TH + 1) * (2 * TW + 1) * C * 2 + (lrn_first ? 0 : (long long)kPL_TH * TW * C * 2);
+        const long long items = (long long)(2 * kPL_TH + 1) * (2 * TW + 1) * (C / 8);
+        if (lds_ok && k == 3 && stride == 2 && pad == 0 && patch + 1024 <= kPLLdsBytes && items <= 8 * 512 && (long long)N * H * W * C >= (1 << 22) &&
+            cdiv(OH, kPL_TH) <= 65535) {
+            const dim3 g2(cdiv(OW, TW), cdiv(OH, kPL_TH), N);
+            if (lrn_first)
+                hipLaunchKernelGGL(pool_lrn5_f16_lds_kernel<true>, g2, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, OH, OW, y_cstride, TW, aon, beta, lrn_k);
+            else
+                hipLaunchKernelGGL(pool_lrn5_f16_lds_kernel<false>, g2, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, OH, OW, y_cstride, TW, aon, beta, lrn_k);
+            FCN_LAUNCH_CHECK("pool_lrn5_f16_lds");
+            return 0;
+        }
+    }
     if (lrn_first)
         hipLaunchKernelGGL(maxpool_lrn5_f16_kernel<true>, grid, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
                            cgroups, aon, beta, lrn_k);

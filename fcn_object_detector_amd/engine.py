@@ -637,7 +637,9 @@ class Engine:
         # Measured on MI355X: the single pass saves a launch and the round trip of the blob in the middle (batch 1: 9.1 -> 7.1
         # and 11.1 -> 8.2 us) but recomputes the neighbour groups' maxima / the normalisation per window element; once the
         # blobs are tens of MB the two bandwidth-bound launches are as fast or faster (batch-32 halves: 73 -> 88 and 103 -> 102 us)
-        if n * c * h * w > 8 << 20:
+        # (half-float 3x3 / stride 2 poolings of at most 192 channels take the LDS-patch kernel at those sizes - round 3: LRN once
+        #  per pixel, the blob in between never written: norm2 + pool2 104 -> ~45 us at batch 32)
+        if n * c * h * w > 8 << 20 and not (esz == 2 and (k, s, pad) == (3, 2, 0) and c <= 192):
             return None
         al, be, kk = float(lp.get("alpha", 1.0)), float(lp.get("beta", 0.75)), float(lp.get("k", 1.0))
         first = 1 if la.type == "LRN" else 0
