@@ -53,6 +53,11 @@ struct WgradP {
     int slab_floats;                                   // Cout*K + Cout
     unsigned ow_magic, oh_magic;                       // ceil(2^32 / OW), ceil(2^32 / OH) for the pixel decode (0: the extent is 1)
     int kw_magic;
+    int rn, rk;                                        // role-split kernel: the workgroup's region in 32-wide sub-tiles (channels, k)
+    // role-split kernel: region classes 2 a + b (a / b: the last region along channels / k, usually a partial one).  The class with the
+    // most MFMAs per step splits the pixels into runs of cps0 chunks; class c takes cls_d[c] runs per workgroup (cls_splits[c] splits),
+    // so that every workgroup of the launch lasts about as long.  cls_dmagic = ceil(2^16 / cls_d), cls_count = regions in the class.
+    int cls_splits[4], cls_d[4], cls_dmagic[4], cls_count[4], cps0, runs, wgs;
 };
 
 constexpr int WG_BP = 32;      // pixels per chunk
@@ -341,6 +346,417 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_group_kerne
     wgrad_body<TN, TK, WAVES_N, WAVES_K, NBUF>(u.p, b - begin, smem);
 }
 
+// ---- role-split weight gradient (round 3) ------------------------------------------------------------------------------------------
+// Why a second kernel (tools/train_profile.py at batch 8, round 3): the 64 x 64 tiles above re-read their operands once per tile
+// position - conv2/3x3 pulls 4.2 GB through the L2s for 103 MB of operands (16 TB/s at its 261 us) - and one instruction stream
+// per wave serialises address arithmetic, LDS-DMA issue, 32 fragment reads and 16 MFMAs per chunk; three resident workgroups per CU
+// hide some of that and the family sustains 45-85 TF/s.  Larger tiles halve the restaging but leave one workgroup per CU, where the
+// serialisation shows (round 2's sweep), and 128-wide tiles waste up to a third of their MFMAs on this net's channel counts
+// (Cout = 16 .. 384 in steps of 16 or 32, K = 192 .. 3456).  Here
+//   * a workgroup has EIGHT waves with fixed roles: waves 4-7 stage, waves 0-3 multiply.  The multiplying waves run fragment reads
+//     and MFMAs only (the next step's fragments in flight, the next chunk's first fragments read during this chunk's last step),
+//     one raw s_barrier per chunk;
+//   * a workgroup owns a REGION of rn x rk sub-tiles of 32 channels x 32 k (rn <= 4, rk <= 8, rn rk <= 16; chosen per problem by
+//     the host so that the padded work is least).  The region's VALID sub-tiles are dealt to the four multiplying waves round-robin,
+//     up to four accumulators per wave, each bound to its sub-tile by two LDS addresses: a region at the edge of the matrix costs
+//     ceil(valid / 4) MFMA streams instead of 4 - padding is paid in units of one sub-tile per wave, not of a 128 x 128 tile;
+//   * a chunk is 16 pixels: dY rows at a pitch of 128 floats, im2col rows at a pitch of 256 floats (24 KiB per slot, six slots: up to
+//     four chunks in flight - with 32-pixel chunks and three slots only one was, and a workgroup with one or two MFMAs per step took
+//     a trip to memory per chunk, 3300 cycles instead of 1024-2048).
+//     Constant pitches keep every fragment read's displacement in the instruction's offset field for any region shape; lanes
+//     outside the region or the matrix carry an out-of-range offset (zeros, no traffic).  An im2col row is ONE LDS-DMA instruction:
+//     its pixel is wave-uniform and decoded on the scalar unit (the per-lane decode of the family above is what the verdict of
+//     round 2 asked to remove), a lane adds its tap's constant offset and tests its tap against the image;
+//   * workgroups are numbered split-major and dealt to the XCDs in consecutive runs (b % 8 labels the XCD): the workgroups that
+//     share an L2 work on the same pixels at the same time, so a chunk's operands are fetched from HBM/MALL once per XCD.
+// Results: per split the same sum order as the family above (pixels ascending, two per MFMA step); the split counts differ.
+// Diagnostic build only (make exp EXP=-DFCN_WS_STAMPS EXPSRC=train; tools/wgrad_timeline.py): per workgroup, when it ran (100 MHz clock),
+// the shader cycles it took, and the cycles multiplying wave 0 / staging wave 0 waited.  No stamp exists in the product build.
+#ifdef FCN_WS_STAMPS
+__device__ unsigned long long* g_ws_stamps = nullptr;
+__device__ int g_ws_stamps_cap = 0;
+#define WS_CYC() __builtin_amdgcn_s_memtime()
+#else
+#define WS_CYC() 0ull
+#endif
+#ifndef FCN_WS_BP
+#define FCN_WS_BP 16
+#endif
+constexpr int WS_BP = FCN_WS_BP;                     // pixels per chunk (16: six 24 KiB slots; 32: three 48 KiB slots)
+constexpr int WS_STEPS = WS_BP / 2;                  // MFMA steps (two pixels each) per chunk
+constexpr int WS_DY_FLOATS = WS_BP * 128, WS_X_FLOATS = WS_BP * 256, WS_SLOT_FLOATS = WS_DY_FLOATS + WS_X_FLOATS;
+constexpr int WS_NBUF = 144 * 1024 / (WS_SLOT_FLOATS * 4);
+constexpr int WS_NDY = WS_BP / 2 / 4, WS_NX = WS_BP / 4;      // per staging wave and chunk: dY pieces (two rows each), im2col rows
+constexpr int WS_INST = WS_NDY + WS_NX;              // LDS-DMA instructions per staging wave and chunk
+static_assert(WS_BP == 16 || WS_BP == 32, "chunk sizes the step list below is written for");
+static_assert((WS_NBUF * WS_SLOT_FLOATS + 4 * 128) * 4 <= 160 * 1024, "exceeds the CU's 160 KiB LDS");
+static_assert(WS_INST * (WS_NBUF - 2) <= 63, "vmcnt is a 6-bit counter");
+
+__global__ __launch_bounds__(512) void conv_wgrad_split_kernel(const WgradGroupArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float smem[WS_NBUF * WS_SLOT_FLOATS + 4 * 128];      // + the staging waves' bias partials
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int v;      // this workgroup's place in the split-major order: the blocks of one XCD take a consecutive run
+    {
+        const int G = gridDim.x, q = G >> 3, r = G & 7, x = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+        v = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+    }
+    int pi = 0, begin = 0;
+#pragma unroll
+    for (int i = 0; i < kMaxWgGroup - 1; ++i) {
+        const bool past = i + 1 < a.n && v >= a.wg_end[i];
+        pi += past ? 1 : 0;
+        begin = past ? a.wg_end[i] : begin;
+    }
+    typedef const WgradGroupArgs __attribute__((address_space(4))) * karg_ptr;
+    karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    union { WgradP p; unsigned w[sizeof(WgradP) / 4]; } u;
+    const unsigned __attribute__((address_space(4)))* src = (const unsigned __attribute__((address_space(4)))*)&ka->p[pi];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(WgradP) / 4); ++i) u.w[i] = src[i];
+    const WgradP& p = u.p;
+#ifdef FCN_WS_STAMPS
+    const unsigned long long ws_rt0 = __builtin_amdgcn_s_memrealtime(), ws_c0 = WS_CYC();
+    unsigned long long ws_wait = 0;
+#endif
+
+    // Workgroups of a problem are ordered by the pixel run they START at (then class, then region): the neighbours in this order -
+    // which share an XCD and run at the same time - read the same pixels, whatever their class.  before(j) = workgroups that start
+    // in front of run j; this workgroup's run is found by bisection (scalar arithmetic, once per workgroup).
+    const int lv = v - begin;
+    auto before = [&](const int j) __attribute__((always_inline)) {
+        int t = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int started = ((j + p.cls_d[c] - 1) * p.cls_dmagic[c]) >> 16;      // ceil(j / d): exact for j < 8192 / d
+            t += p.cls_count[c] * min(started, p.cls_splits[c]);
+        }
+        return t;
+    };
+    int run = 0;
+    {
+        int lo = 0, hi = p.runs;      // before(0) = 0 <= lv < before(runs) = the problem's workgroups
+#pragma unroll 1
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (before(mid) <= lv) lo = mid; else hi = mid;
+        }
+        run = lo;
+    }
+    int off = lv - before(run), cls = 0, split = 0, tile = 0;
+    bool found = false;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int sp = (run * p.cls_dmagic[c]) >> 16;      // run / d
+        const bool starts = sp * p.cls_d[c] == run && sp < p.cls_splits[c];
+        const int cnt_c = starts ? p.cls_count[c] : 0;
+        if (!found && off < cnt_c) { found = true; cls = c; split = sp; tile = off; }
+        if (!found) off -= cnt_c;
+    }
+    const int ca = cls >> 1, cb = cls & 1;
+    const int cnk = cb ? 1 : p.tiles_k - 1;
+    const int cd = cls == 0 ? p.cls_d[0] : cls == 1 ? p.cls_d[1] : cls == 2 ? p.cls_d[2] : p.cls_d[3];
+    const int tn_i = tile / cnk;
+    const int tile_n = ca ? p.tiles_n - 1 : tn_i, tile_k = cb ? p.tiles_k - 1 : tile - tn_i * cnk;
+    const int n0 = tile_n * 32 * p.rn, k0 = tile_k * 32 * p.rk;
+    const int total_chunks = (p.M + WS_BP - 1) / WS_BP;
+    const int cps = cd * p.cps0;
+    const int chunk0 = split * cps;
+    int nchunks = total_chunks - chunk0;
+    if (nchunks > cps) nchunks = cps;
+    if (nchunks < 0) nchunks = 0;
+    const int chunk_end = chunk0 + nchunks;
+    constexpr int SLOT_BYTES = WS_SLOT_FLOATS * 4;
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+    auto next = [](int b) __attribute__((always_inline)) { return b + 1 == WS_NBUF ? 0 : b + 1; };
+
+    // Barrier protocol (every barrier is passed by all eight waves): B(-1): chunk 0 has landed.  B(c), c = 0 .. nchunks - 1: chunk
+    // c + 1 has landed (the multiplying waves read its first fragments during chunk c's last step) and the multiplying waves are
+    // done with chunk c - 1, whose slot takes chunk c + 2.
+    if (wid >= 4) {
+        // ---- staging waves ---------------------------------------------------------------------------------------------------------
+        const int lw = wid - 4, ltid = tid - 256;
+        constexpr int OOB = (int)0x80000000u;      // >= num_records (wgrad_validate: both operands stay below 2 GiB)
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.dy), 0, (int)((((long long)p.M - 1) * p.dy_cstride + (p.Cout + 3) / 4 * 4) * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x), 0, (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * 4), 0x00020000);
+        // dY piece j = lw + 4 i holds pixel rows 2 j, 2 j + 1 of the chunk: lane -> row 2 j + lane / 32, channels n0 + 4 (lane % 32) ..
+        const int col = (lane & 31) * 4;
+        const bool col_ok = col < 32 * p.rn && n0 + col < p.Cout;
+        int n_vo[WS_NDY];
+#pragma unroll
+        for (int i = 0; i < WS_NDY; ++i) n_vo[i] = col_ok ? ((2 * (lw + 4 * i) + (lane >> 5)) * p.dy_cstride + n0 + col) * 4 : OOB;
+        // im2col row = lw + 4 i: lane -> k = k0 + 4 lane .. + 3 (one tap: Cin % 4 == 0), a constant offset from the row's pixel.
+        // v_mfma_f32_32x32x2_f32 runs at the vector ALU's own rate and occupies it: a vector instruction of a staging wave waits for the
+        // MFMA in flight on its SIMD (up to 64 cycles) and then delays the next one.  A first version computed every row's lane
+        // offsets and halo tests with ~12 vector instructions; eight rows of that per chunk took longer than the chunk's MFMAs, and
+        // the multiplying waves waited at every barrier (65 % of the MFMA rate with NO loads at all).  So: the pixel is decoded on the
+        // scalar unit; a row whose taps all lie inside the image - most rows - is fetched with a CONSTANT lane offset and the pixel's
+        // base in the instruction's scalar offset: no vector instruction at all.  Only rows at the image border test their taps.
+        const int kidx = k0 + 4 * lane;
+        const bool k_ok = 4 * lane < 32 * p.rk && kidx < p.K;
+        const int ktap = kidx / p.Cin;
+        const int kch = kidx - ktap * p.Cin;
+        const int kr = (ktap * p.kw_magic) >> 16;
+        const int kq = ktap - kr * p.kw;
+        const int x_lane = ((kr * p.W + kq) * p.x_cstride + kch) * 4;
+        int x_lane_k = k_ok ? x_lane : OOB;
+        asm volatile("" : "+v"(x_lane_k));
+        int issue_chunk_idx = chunk0;
+        auto issue_chunk = [&](const int buf) __attribute__((always_inline)) {
+            float* const dst = smem + buf * WS_SLOT_FLOATS;
+            const bool live = issue_chunk_idx < chunk_end;
+            const int s_dy = live ? issue_chunk_idx * WS_BP * p.dy_cstride * 4 : 0x7F000000;      // rows >= M are past num_records by themselves
+#pragma unroll
+            for (int i = 0; i < WS_NDY; ++i) {
+#ifndef FCN_WS_NOLOAD
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (lds_ptr)(dst + (lw + 4 * i) * 256), 16, n_vo[i], s_dy, 0, 0);
+#endif
+            }
+#pragma unroll
+            for (int i = 0; i < WS_NX; ++i) {
+                const int row = lw + 4 * i;
+                const int m = issue_chunk_idx * WS_BP + row;      // wave-uniform: everything up to the branch runs on the scalar unit
+                const bool m_ok = live && m < p.M;
+                const int mm = m_ok ? m : 0;
+                const int t = p.ow_magic ? (int)__umulhi((unsigned)mm, p.ow_magic) : mm;      // exact: wgrad_validate
+                const int ox = mm - t * p.OW;
+                const int img = p.oh_magic ? (int)__umulhi((unsigned)t, p.oh_magic) : t;
+                const int oy = t - img * p.OH;
+                const int by = oy * p.stride - p.pad, bx = ox * p.stride - p.pad;
+                const int base = ((img * p.H + by) * p.W + bx) * p.x_cstride * 4;
+                lds_ptr const d = (lds_ptr)(dst + WS_DY_FLOATS + row * 256);
+                const bool inside = by >= 0 && by + p.kh <= p.H && bx >= 0 && bx + p.kw <= p.W;
+                if (inside || !m_ok) {
+                    const int s_x = m_ok ? base : 0x7F000000;      // (base >= 0 inside the image; a dead row: every lane out of range)
+#ifndef FCN_WS_NOLOAD
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rxx, d, 16, x_lane_k, s_x, 0, 0);
+#endif
+                } else {
+                    const bool ok = (int)k_ok & (int)((unsigned)(by + kr) < (unsigned)p.H) & (int)((unsigned)(bx + kq) < (unsigned)p.W);
+                    int vo = ok ? base + x_lane : OOB;
+                    asm volatile("" : "+v"(vo));
+#ifndef FCN_WS_NOLOAD
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rxx, d, 16, vo, 0, 0, 0);
+#endif
+                }
+            }
+            ++issue_chunk_idx;
+        };
+        // bias gradient = column sums of dY, in the workgroups of the first k-tile, from the landed chunk: every staging wave sums
+        // a quarter of the chunk's rows (a vector add beside v_mfma_f32_32x32x2_f32 costs its SIMD's matrix stream a slot: spread over
+        // the four SIMDs), two channels per lane; the four partials meet in LDS behind the last chunk.
+        const bool do_bias = p.db_part != nullptr && tile_k == 0;
+        const unsigned bias_addr = lds0 + 4u * (unsigned)(WS_NX * lw * 128 + 2 * lane);
+        float bsum0 = 0.f, bsum1 = 0.f;
+        int buf_issue = 0, buf_cur = 0;
+#pragma unroll 1
+        for (int c = 0; c < WS_NBUF - 1; ++c) {
+            issue_chunk(buf_issue);
+            buf_issue = next(buf_issue);
+        }
+        wait_vmcnt<WS_INST*(WS_NBUF - 2)>();
+        __builtin_amdgcn_s_barrier();      // B(-1)
+#pragma unroll 1
+        for (int c = 0; c < nchunks; ++c) {
+#ifdef FCN_WS_STAMPS
+            const unsigned long long w0 = WS_CYC();
+#endif
+            wait_vmcnt<WS_INST*(WS_NBUF - 3)>();
+#ifdef FCN_WS_STAMPS
+            ws_wait += WS_CYC() - w0;
+#endif
+            __builtin_amdgcn_s_barrier();      // B(c)
+            asm volatile("" ::: "memory");
+            issue_chunk(buf_issue);
+            buf_issue = next(buf_issue);
+            if (do_bias) {
+                const unsigned slot = (unsigned)buf_cur * SLOT_BYTES;
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f vv[WS_NX];
+#pragma unroll
+                for (int r = 0; r < WS_NX; ++r) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(vv[r]) : "v"(bias_addr + slot), "n"(r * 128 * 4));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                for (int r = 0; r < WS_NX; ++r) {
+                    asm volatile("" : "+v"(vv[r]));
+                    t0 += vv[r][0];
+                    t1 += vv[r][1];
+                }
+                bsum0 += t0;
+                bsum1 += t1;
+            }
+            buf_cur = next(buf_cur);
+        }
+        wait_vmcnt<0>();      // the all-zero chunks behind the last one
+        float* const bias_lds = smem + WS_NBUF * WS_SLOT_FLOATS;
+        if (do_bias) {
+            bias_lds[lw * 128 + 2 * lane] = bsum0;
+            bias_lds[lw * 128 + 2 * lane + 1] = bsum1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // (the multiplying waves pass it behind their last chunk)
+        asm volatile("" ::: "memory");
+        if (do_bias && ltid < 32 * p.rn && n0 + ltid < p.Cout)
+            p.db_part[(size_t)split * p.slab_floats + n0 + ltid] = ((bias_lds[ltid] + bias_lds[128 + ltid]) + bias_lds[256 + ltid]) + bias_lds[384 + ltid];
+#ifdef FCN_WS_STAMPS
+        if (g_ws_stamps && (int)blockIdx.x < g_ws_stamps_cap && tid == 256) g_ws_stamps[(size_t)blockIdx.x * 8 + 7] = ws_wait;
+#endif
+    } else {
+        // ---- multiplying waves -----------------------------------------------------------------------------------------------------
+        // The region's valid sub-tiles are taken in PAIRS along k (one dY fragment serves both): pair list dealt round-robin.
+        const int rn_v = min(p.rn, (p.Cout - n0 + 31) / 32), rk_v = min(p.rk, (p.K - k0 + 31) / 32);
+        const int kp = (rk_v + 1) >> 1, pairs = rn_v * kp;
+        const int cnt = pairs > wid ? (pairs - wid + 3) / 4 : 0;      // this wave's pairs: wid, wid + 4, ..
+        unsigned a_ad[4], b_ad[4];
+        int sub_n[4], sub_k[4];
+        int full = 0;                                                  // bit t: pair t has its second sub-tile
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pt = min(wid + 4 * t, pairs - 1);
+            sub_n[t] = pt / kp;
+            sub_k[t] = 2 * (pt - sub_n[t] * kp);
+            if (t < cnt && sub_k[t] + 1 < rk_v) full |= 1 << t;
+            // lane (i = lane & 31, p = lane >> 5) of MFMA step s reads element i of pixel row 2 s + p
+            a_ad[t] = lds0 + 4u * (unsigned)((lane >> 5) * 128 + 32 * sub_n[t] + (lane & 31));
+            b_ad[t] = lds0 + 4u * (unsigned)(WS_DY_FLOATS + (lane >> 5) * 256 + 32 * sub_k[t] + (lane & 31));
+        }
+        full = __builtin_amdgcn_readfirstlane(full);
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][h][r] = 0.f;
+        auto ds_read32 = [](float& dst, unsigned addr, auto off) __attribute__((always_inline)) {
+#ifdef FCN_WS_NOREAD
+            asm volatile("" : "=v"(dst) : "v"(addr));
+            return;
+#endif
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value));
+        };
+        // CNT pairs; ALL: every pair is whole (no branch in the MFMA stream)
+        auto run = [&](auto cnt_c, auto all_c) __attribute__((always_inline)) {
+            constexpr int CNT = decltype(cnt_c)::value;
+            constexpr bool ALL = decltype(all_c)::value;
+            float fa[2][CNT], fb[2][CNT][2];
+            unsigned slot = 0;
+            __builtin_amdgcn_s_barrier();      // B(-1)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < CNT; ++t) {
+                ds_read32(fa[0][t], a_ad[t], std::integral_constant<int, 0>{});
+                ds_read32(fb[0][t][0], b_ad[t], std::integral_constant<int, 0>{});
+                ds_read32(fb[0][t][1], b_ad[t], std::integral_constant<int, 128>{});
+            }
+#pragma unroll 1
+            for (int c = 0; c < nchunks; ++c) {
+#ifdef FCN_WS_STAMPS
+                const unsigned long long w0 = WS_CYC();
+#endif
+                __builtin_amdgcn_s_barrier();      // B(c)
+                asm volatile("" ::: "memory");
+#ifdef FCN_WS_STAMPS
+                ws_wait += WS_CYC() - w0;
+#endif
+                const unsigned slot_next = slot + SLOT_BYTES == (unsigned)(WS_NBUF * SLOT_BYTES) ? 0u : slot + SLOT_BYTES;
+                unsigned aa[CNT], bb[CNT];
+#pragma unroll
+                for (int t = 0; t < CNT; ++t) {
+                    aa[t] = a_ad[t] + slot;
+                    bb[t] = b_ad[t] + slot;
+                }
+                auto step = [&](auto st_c) __attribute__((always_inline)) {
+                    constexpr int st = decltype(st_c)::value, par = st & 1;
+                    // the next step's fragments (behind the last step: the first ones of the next chunk)
+#pragma unroll
+                    for (int t = 0; t < CNT; ++t) {
+                        if constexpr (st < WS_STEPS - 1) {
+                            ds_read32(fa[par ^ 1][t], aa[t], std::integral_constant<int, (st + 1) * 2 * 128 * 4>{});
+                            ds_read32(fb[par ^ 1][t][0], bb[t], std::integral_constant<int, (st + 1) * 2 * 256 * 4>{});
+                            ds_read32(fb[par ^ 1][t][1], bb[t], std::integral_constant<int, (st + 1) * 2 * 256 * 4 + 128>{});
+                        } else {
+                            ds_read32(fa[0][t], a_ad[t] + slot_next, std::integral_constant<int, 0>{});
+                            ds_read32(fb[0][t][0], b_ad[t] + slot_next, std::integral_constant<int, 0>{});
+                            ds_read32(fb[0][t][1], b_ad[t] + slot_next, std::integral_constant<int, 128>{});
+                        }
+                    }
+                    // LDS operations return in order: this step's fragments are back once only the 3 CNT just issued are outstanding
+                    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * CNT) : "memory");
+#pragma unroll
+                    for (int t = 0; t < CNT; ++t) asm volatile("" : "+v"(fa[par][t]), "+v"(fb[par][t][0]), "+v"(fb[par][t][1]));
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef FCN_WS_NOMFMA
+#pragma unroll
+                    for (int t = 0; t < CNT; ++t) {
+                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][t], fb[par][t][0], acc[t][0], 0, 0, 0);
+                        if (ALL || ((full >> t) & 1)) acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][t], fb[par][t][1], acc[t][1], 0, 0, 0);
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
+                step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
+                step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
+                if constexpr (WS_STEPS == 16) {
+                    step(std::integral_constant<int, 8 % WS_STEPS>{}); step(std::integral_constant<int, 9 % WS_STEPS>{});
+                    step(std::integral_constant<int, 10 % WS_STEPS>{}); step(std::integral_constant<int, 11 % WS_STEPS>{});
+                    step(std::integral_constant<int, 12 % WS_STEPS>{}); step(std::integral_constant<int, 13 % WS_STEPS>{});
+                    step(std::integral_constant<int, 14 % WS_STEPS>{}); step(std::integral_constant<int, 15 % WS_STEPS>{});
+                }
+                slot = slot_next;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments read last belong to a chunk nobody multiplies
+#pragma unroll
+            for (int t = 0; t < CNT; ++t) asm volatile("" : "+v"(fa[0][t]), "+v"(fb[0][t][0]), "+v"(fb[0][t][1]));
+        };
+        const bool all = full == (1 << cnt) - 1;
+        typedef std::true_type T_;
+        typedef std::false_type F_;
+        if (cnt == 4) { if (all) run(std::integral_constant<int, 4>{}, T_{}); else run(std::integral_constant<int, 4>{}, F_{}); }
+        else if (cnt == 3) { if (all) run(std::integral_constant<int, 3>{}, T_{}); else run(std::integral_constant<int, 3>{}, F_{}); }
+        else if (cnt == 2) { if (all) run(std::integral_constant<int, 2>{}, T_{}); else run(std::integral_constant<int, 2>{}, F_{}); }
+        else if (cnt == 1) { if (all) run(std::integral_constant<int, 1>{}, T_{}); else run(std::integral_constant<int, 1>{}, F_{}); }
+        else {
+#pragma unroll 1
+            for (int c = 0; c <= nchunks; ++c) __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_s_barrier();      // the staging waves' bias partials are in LDS
+#ifdef FCN_WS_STAMPS
+        const unsigned long long ws_c1 = WS_CYC();
+#endif
+        // dW partial slab [split][cout][k]: C/D map col = lane & 31 (k), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (cout)
+        float* slab = p.dw_part + (size_t)split * p.slab_floats;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kcol = k0 + 32 * (sub_k[t] + h) + (lane & 31);
+                if (t >= cnt || (h && !((full >> t) & 1)) || kcol >= p.K) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + 32 * sub_n[t] + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (n < p.Cout) *(gf_ptr)(slab + (size_t)n * p.K + kcol) = acc[t][h][r];
+                }
+            }
+        }
+#ifdef FCN_WS_STAMPS
+        if (g_ws_stamps && (int)blockIdx.x < g_ws_stamps_cap && tid == 0) {
+            unsigned long long* d_ = g_ws_stamps + (size_t)blockIdx.x * 8;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            d_[0] = ws_rt0; d_[1] = __builtin_amdgcn_s_memrealtime(); d_[2] = ws_c1 - ws_c0; d_[3] = WS_CYC() - ws_c1;
+            d_[4] = (unsigned long long)nchunks; d_[5] = (unsigned long long)cnt | ((unsigned long long)(xcc & 15) << 8); d_[6] = ws_wait;
+        }
+#endif
+    }
+#endif
+}
+
 // tile shapes: X(index, TN, TK, WAVES_N, WAVES_K)
 #define FCN_WGRAD_CONFIGS(X) \
     X(0, 1, 1, 2, 2, 3)      \
@@ -350,18 +766,46 @@ __global__ __launch_bounds__(64 * WAVES_N * WAVES_K) void conv_wgrad_group_kerne
 struct WgShape { int bn, bk, nw; double eff; };   // eff: sustained fraction of the MFMA rate seen in the sweep (ranking only)
 constexpr int kNumWgCfg = 4;
 constexpr WgShape kWgShapes[kNumWgCfg] = {{64, 64, 4, 0.55}, {64, 128, 4, 0.50}, {128, 64, 4, 0.60}, {64, 64, 4, 0.50}};
+constexpr int kSplitCfg = kNumWgCfg;      // conv_wgrad_split_kernel: a region shape per problem instead of one tile shape per launch
 
 // out[i] = sum_s parts[s][i] in a FIXED order (slab 0, 1, 2, ..: bit-reproducible).  One lane owns four consecutive outputs
 // and walks the slabs with 16-byte loads, eight of them in flight at a time (the adds stay in slab order): every access is
 // a full 1 KiB wave-instruction.  Round 1 gave each output 16 lanes that read 4 bytes per slab - 256 B per wave-instruction,
 // 64 outputs per 1024-thread block, two barriers - and the pass cost 10 % of the training step (profiles/r01_train_*).
 constexpr int RED_THREADS = 256, RED_PER_BLOCK = RED_THREADS * 4;
-__device__ __forceinline__ void reduce_slabs(const float* __restrict__ parts, float* __restrict__ out, size_t count, int splits, size_t stride,
+// How many slabs hold element i.  The role-split kernel gives the region classes of a problem their own split counts: weights
+// (i < wcount) by the class of (row, column) of the Cout x K matrix, the bias sums behind them by the class of their channel in
+// the first k-region.  Every other producer fills all slabs: uniform.
+struct RedSplits {
+    long long wcount;
+    int K, n_last0, k_last0, b_bias, uniform;
+    int s[4];
+};
+__device__ __forceinline__ int red_splits_for(const RedSplits& rs, size_t i) {
+    if (rs.uniform) return rs.s[0];
+    int a, b;
+    if ((long long)i < rs.wcount) {
+        const int n = (int)(i / (size_t)rs.K), k = (int)(i - (size_t)n * rs.K);
+        a = n >= rs.n_last0;
+        b = k >= rs.k_last0;
+    } else {
+        a = (int)((long long)i - rs.wcount) >= rs.n_last0;
+        b = rs.b_bias;
+    }
+    const int c = 2 * a + b;
+    return c == 0 ? rs.s[0] : c == 1 ? rs.s[1] : c == 2 ? rs.s[2] : rs.s[3];
+}
+static RedSplits red_uniform(int splits) {
+    RedSplits r = {0, 1, 0, 0, 0, 1, {splits, splits, splits, splits}};
+    return r;
+}
+__device__ __forceinline__ void reduce_slabs(const float* __restrict__ parts, float* __restrict__ out, size_t count, const RedSplits& rs, size_t stride,
                                              size_t i4) {
     if (i4 >= count) return;
     typedef float v4 __attribute__((ext_vector_type(4)));
     const bool vec = i4 + 3 < count && (stride & 3) == 0 && (((size_t)parts | (size_t)out) & 15) == 0;
     if (vec) {
+        const int splits = red_splits_for(rs, i4);      // (four consecutive elements share a class: K, wcount and the class borders are multiples of 4)
         const v4* src = reinterpret_cast<const v4*>(parts + i4);
         const size_t st4 = stride / 4;
         v4 acc = src[0];
@@ -377,6 +821,7 @@ __device__ __forceinline__ void reduce_slabs(const float* __restrict__ parts, fl
         *reinterpret_cast<v4*>(out + i4) = acc;
     } else {
         for (size_t i = i4; i < count && i < i4 + 4; ++i) {
+            const int splits = red_splits_for(rs, i);
             float t = parts[i];
             for (int k = 1; k < splits; ++k) t += parts[(size_t)k * stride + i];
             out[i] = t;
@@ -385,9 +830,9 @@ __device__ __forceinline__ void reduce_slabs(const float* __restrict__ parts, fl
 }
 
 __global__ __launch_bounds__(RED_THREADS) void reduce_partials_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t count,
-                                                                      int splits, size_t stride) {
+                                                                      const RedSplits rs, size_t stride) {
     for (size_t base = (size_t)blockIdx.x * RED_PER_BLOCK; base < count; base += (size_t)gridDim.x * RED_PER_BLOCK)
-        reduce_slabs(parts, out, count, splits, stride, base + (size_t)threadIdx.x * 4);
+        reduce_slabs(parts, out, count, rs, stride, base + (size_t)threadIdx.x * 4);
 }
 
 struct ReduceGroupArgs {
@@ -396,7 +841,7 @@ struct ReduceGroupArgs {
     const float* parts[kMaxWgGroup];
     float* out[kMaxWgGroup];
     unsigned long long count[kMaxWgGroup], stride[kMaxWgGroup];
-    int splits[kMaxWgGroup];
+    RedSplits rs[kMaxWgGroup];
 };
 
 // the same for up to kMaxWgGroup problems in one launch (one problem per block range)
@@ -411,11 +856,11 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_partials_group_kernel(cons
     const float* parts = a.parts[0];
     float* out = a.out[0];
     size_t count = a.count[0], stride = a.stride[0];
-    int splits = a.splits[0];
+    RedSplits rs = a.rs[0];
 #pragma unroll
     for (int i = 1; i < kMaxWgGroup; ++i)
-        if (pi == i) { parts = a.parts[i]; out = a.out[i]; count = a.count[i]; stride = a.stride[i]; splits = a.splits[i]; }
-    reduce_slabs(parts, out, count, splits, stride, ((size_t)((int)blockIdx.x - begin) * RED_THREADS + threadIdx.x) * 4);
+        if (pi == i) { parts = a.parts[i]; out = a.out[i]; count = a.count[i]; stride = a.stride[i]; rs = a.rs[i]; }
+    reduce_slabs(parts, out, count, rs, stride, ((size_t)((int)blockIdx.x - begin) * RED_THREADS + threadIdx.x) * 4);
 }
 
 // wt[c][kh-1-r][kw-1-q][k] = w[k][r][q][c]   (w: [Cout][kh][kw][Cin4], wt: [Cin][kh][kw][Cout4], pads of wt zero)
@@ -838,38 +1283,208 @@ unsigned magic32(unsigned d) { return d <= 1 ? 0xFFFFFFFFu : (unsigned)((0x10000
 
 extern "C" {
 
-// tile shape with the least padded work per unit of sustained rate, then enough pixel splits to fill the chip
-static void plan_wgrad(const fcn_conv_desc* d, int* cfg_out, int* splits_out) {
-    const long long M = (long long)d->N * d->OH * d->OW, K = (long long)d->kh * d->kw * d->Cin;
-    int best = 0;
+#ifdef FCN_WS_STAMPS
+int fcn_debug_wgrad_stamps(void* d_buf, int cap) {
+    FCN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamps), &d_buf, sizeof(d_buf)));
+    FCN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamps_cap), &cap, sizeof(cap)));
+    return 0;
+}
+#endif
+
+struct WgPlan {
+    int cfg, splits, rn, rk;      // splits: the most slabs any element has (workspace size)
+    int cs[4];                    // role-split kernel: split count of region class 2 a + b
+    int upc[4], count[4];         // ... MFMAs per step of the class's busiest wave; regions in the class
+    int d[4], cps0;               // ... pixel runs (of cps0 chunks) per workgroup of the class
+};
+
+static int wgrad_forced_cfg() {
     const char* force = getenv("FCN_WGRAD_CFG");
-    if (force && force[0] >= '0' && force[0] < '0' + kNumWgCfg) {
-        best = force[0] - '0';
-    } else {
-        double best_cost = 1e300;
-        for (int c = 0; c < kNumWgCfg; ++c) {
-            const double padded = (double)cdiv(d->Cout, kWgShapes[c].bn) * kWgShapes[c].bn * cdiv(K, kWgShapes[c].bk) * kWgShapes[c].bk;
-            const double cost = padded / kWgShapes[c].eff;
-            if (cost < best_cost) { best_cost = cost; best = c; }
+    return force && force[0] >= '0' && force[0] <= '0' + kSplitCfg && !force[1] ? force[0] - '0' : -1;
+}
+
+static int wgrad_split_rounds_max() {      // FCN_WGRAD_SPLIT_ROUNDS: most workgroups per CU the planner may give a launch of the role-split kernel
+    const char* e = getenv("FCN_WGRAD_SPLIT_ROUNDS");
+    const int v = e ? atoi(e) : 0;
+    return v >= 1 && v <= 16 ? v : 3;
+}
+
+static int device_cus() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) return v;
+    return 256;
+}
+
+// cycles of one MFMA per step over a chunk; the least a chunk takes whatever its MFMAs (memory latency over the chunks in flight)
+constexpr double kStepCycles = 64.0 * WS_STEPS, kChunkFloor = 3300.0 / (WS_NBUF - 2);
+
+// Region classes of an rn x rk tiling of a Cout x K matrix: class 2 a + b, a / b = 1 for the last region along channels / k
+// (usually a partial one).  Per class: how many regions, MFMAs per step of its busiest multiplying wave (the region's sub-tile
+// pairs along k are dealt round-robin to four waves), cycles per 32-pixel chunk = max(MFMA time, staging time at 20 bytes per
+// clock and CU) + 0.3 staging time (staging never overlaps perfectly, and the fabric is shared).
+static double split_region_classes(int Cout, long long K, int rn, int rk, int* upc, int* count) {
+    const int ns = cdiv(Cout, 32), ks = (int)cdiv(K, 32), tn = cdiv(ns, rn), tk = cdiv(ks, rk);
+    double cost = 0;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            const int vn = a ? ns - (tn - 1) * rn : rn, vk = b ? ks - (tk - 1) * rk : rk, c = 2 * a + b;
+            count[c] = (a ? 1 : tn - 1) * (b ? 1 : tk - 1);
+            const int kp = (vk + 1) / 2, pairs = vn * kp;
+            int busiest = 0;      // exactly what the kernel deals: wave w takes pairs w, w + 4, ..; the last pair of a row is half when vk is odd
+            for (int w = 0; w < 4 && w < pairs; ++w) {
+                int m = 0;
+                for (int pt = w; pt < pairs; pt += 4) m += ((pt % kp) * 2 + 1 < vk) ? 2 : 1;
+                if (m > busiest) busiest = m;
+            }
+            upc[c] = busiest;
+            const double mfma = busiest * kStepCycles > kChunkFloor ? busiest * kStepCycles : kChunkFloor, stage = (vn + vk) * 32.0 * WS_BP * 4 / 20.0;
+            cost += count[c] * ((mfma > stage ? mfma : stage) + 0.3 * stage);
+        }
+    return cost;
+}
+
+// Region shape of the role-split kernel: every rn x rk (in 32-wide sub-tiles, rn <= 4, rk <= 8, rk even) is priced by
+// split_region_classes; the cheapest wins, fewer regions on a tie.
+static void plan_split_region(int Cout, long long K, WgPlan* pl) {
+    const int ns = cdiv(Cout, 32), ks = (int)cdiv(K, 32);
+    double best = 1e300;
+    int btiles = 1 << 30;
+    pl->rn = pl->rk = 1;
+    for (int rn = 1; rn <= 4; ++rn)
+        for (int rk = 1; rk <= 8; ++rk) {
+            if (rk > 1 && (rk & 1)) continue;      // (pairs along k: an odd width would leave half a pair in every region)
+            int upc[4], count[4];
+            const double cost = split_region_classes(Cout, K, rn, rk, upc, count);
+            const int tiles = cdiv(ns, rn) * cdiv(ks, rk);
+            if (cost < best - 1e-9 || (cost < best + 1e-9 && tiles < btiles)) { best = cost; pl->rn = rn; pl->rk = rk; btiles = tiles; }
+        }
+    split_region_classes(Cout, K, pl->rn, pl->rk, pl->upc, pl->count);
+}
+
+// Pixel splits of the role-split kernel for the n problems of one launch.  One workgroup is resident per CU, so a launch runs in
+// ROUNDS of `cus` workgroups and a round lasts as long as its longest workgroup: every region class gets the split count that
+// brings its workgroups to a common duration tau (= the class's full-depth duration / tau), tau is the smallest one that fits
+// r rounds, and r is the round count with the least estimated time (r x (tau + a workgroup's fixed cost) + the reduction's
+// reads of the partial slabs).
+static void plan_split_counts(const fcn_conv_desc* ds, int n, WgPlan* pls) {
+    const int cus = device_cus();
+    int chunks[kMaxWgGroup], cap[kMaxWgGroup];
+    double cyc[kMaxWgGroup][4], cyc_max[kMaxWgGroup];      // shader cycles per chunk of a class's workgroup / of the problem's slowest class
+    double wmax = 0;
+    for (int i = 0; i < n; ++i) {
+        chunks[i] = cdiv((long long)ds[i].N * ds[i].OH * ds[i].OW, WS_BP);
+        cap[i] = chunks[i] / 4 < 1 ? 1 : chunks[i] / 4 > 256 ? 256 : chunks[i] / 4;      // (a few chunks per workgroup, at least)
+        cyc_max[i] = 0;
+        for (int c = 0; c < 4; ++c) {
+            // a chunk takes its MFMAs or, with one chunk in flight behind the one being multiplied, a trip to memory under load
+            // (tools/wgrad_timeline.py: 3100-3300 cycles per 32-pixel chunk, one in flight, in workgroups with one or two MFMAs per step)
+            cyc[i][c] = pls[i].upc[c] * kStepCycles > kChunkFloor ? pls[i].upc[c] * kStepCycles : kChunkFloor;
+            if (pls[i].count[c] && cyc[i][c] > cyc_max[i]) cyc_max[i] = cyc[i][c];
+        }
+        // a lighter class takes d whole runs of the heaviest class's pixels per workgroup (d <= 8: the kernel divides by multiply-shift)
+        for (int c = 0; c < 4; ++c) {
+            const int d = pls[i].count[c] ? (int)(cyc_max[i] / cyc[i][c]) : 1;
+            pls[i].d[c] = d < 1 ? 1 : d > 8 ? 8 : d;
+        }
+        if ((double)chunks[i] * cyc_max[i] > wmax) wmax = (double)chunks[i] * cyc_max[i];
+    }
+    const double fixed = 15000.0, red_bytes_per_cycle = 1500.0;
+    double best = 1e300;
+    int best_s0[kMaxWgGroup], s0[kMaxWgGroup];
+    for (int i = 0; i < kMaxWgGroup; ++i) best_s0[i] = s0[i] = 1;
+    auto class_splits = [&](int i, int c, int sp0) { return cdiv(chunks[i], pls[i].d[c] * cdiv(chunks[i], sp0)); };
+    auto count_wgs = [&](double tau) {
+        long long wgs = 0;
+        for (int i = 0; i < n; ++i) {
+            int sp = (int)ceil((double)chunks[i] * cyc_max[i] / tau);
+            sp = sp < 1 ? 1 : sp > cap[i] ? cap[i] : sp;
+            s0[i] = sp;
+            for (int c = 0; c < 4; ++c) wgs += (long long)pls[i].count[c] * class_splits(i, c, sp);
+        }
+        return wgs;
+    };
+    for (int r = 1; r <= wgrad_split_rounds_max(); ++r) {
+        double lo = kStepCycles, hi = wmax;      // smallest tau whose split counts fit r rounds
+        if (count_wgs(hi) > (long long)cus * r) continue;      // (more regions than r rounds hold even unsplit)
+        for (int it = 0; it < 40; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (count_wgs(mid) <= (long long)cus * r) hi = mid; else lo = mid;
+        }
+        count_wgs(hi);
+        double tau = 0, red = 0;
+        for (int i = 0; i < n; ++i) {
+            const long long K = (long long)ds[i].kh * ds[i].kw * ds[i].Cin;
+            const int ns = cdiv(ds[i].Cout, 32), ks = (int)cdiv(K, 32);
+            for (int c = 0; c < 4; ++c) {
+                if (!pls[i].count[c]) continue;
+                const double t = (double)pls[i].d[c] * cdiv(chunks[i], s0[i]) * cyc[i][c];
+                if (t > tau) tau = t;
+                const int vn = (c >> 1) ? ns - (cdiv(ns, pls[i].rn) - 1) * pls[i].rn : pls[i].rn, vk = (c & 1) ? ks - (cdiv(ks, pls[i].rk) - 1) * pls[i].rk : pls[i].rk;
+                red += (double)class_splits(i, c, s0[i]) * pls[i].count[c] * vn * vk * 4096.0 / red_bytes_per_cycle;
+            }
+        }
+        const double est = r * (tau + fixed) + red;
+        if (est < best) {
+            best = est;
+            for (int i = 0; i < n; ++i) best_s0[i] = s0[i];
         }
     }
-    const int tiles = cdiv(d->Cout, kWgShapes[best].bn) * cdiv(K, kWgShapes[best].bk);
+    for (int i = 0; i < n; ++i) {
+        pls[i].splits = 1;
+        pls[i].cps0 = cdiv(chunks[i], best_s0[i]);
+        for (int c = 0; c < 4; ++c) {
+            pls[i].cs[c] = class_splits(i, c, best_s0[i]);
+            if (pls[i].count[c] && pls[i].cs[c] > pls[i].splits) pls[i].splits = pls[i].cs[c];
+        }
+    }
+    if (getenv("FCN_WGRAD_PLAN_LOG"))
+        for (int i = 0; i < n; ++i)
+            fprintf(stderr, "wgrad plan: Cout %d K %lld chunks %d -> region %d x %d, runs of %d chunks; regions x splits (MFMAs/step, runs per workgroup) by class: "
+                    "%d x %d (%d, %d), %d x %d (%d, %d), %d x %d (%d, %d), %d x %d (%d, %d)\n",
+                    ds[i].Cout, (long long)ds[i].kh * ds[i].kw * ds[i].Cin, chunks[i], pls[i].rn, pls[i].rk, pls[i].cps0, pls[i].count[0], pls[i].cs[0], pls[i].upc[0],
+                    pls[i].d[0], pls[i].count[1], pls[i].cs[1], pls[i].upc[1], pls[i].d[1], pls[i].count[2], pls[i].cs[2], pls[i].upc[2], pls[i].d[2], pls[i].count[3],
+                    pls[i].cs[3], pls[i].upc[3], pls[i].d[3]);
+}
+
+// tile shape with the least padded work per unit of sustained rate, then enough pixel splits to fill the chip
+static WgPlan plan_wgrad(const fcn_conv_desc* d) {
+    const long long M = (long long)d->N * d->OH * d->OW, K = (long long)d->kh * d->kw * d->Cin;
+    WgPlan pl = {};
+    pl.splits = 1;
+    const int force = wgrad_forced_cfg();
     const int chunks = cdiv(M, WG_BP);
-    int splits = cdiv(kWgShapes[best].nw == 8 ? 512 : 1024, tiles);
-    if (splits > chunks) splits = chunks;
-    if (splits < 1) splits = 1;
-    if (splits > 256) splits = 256;
-    *cfg_out = best;
-    *splits_out = splits;
+    if (force == kSplitCfg) {
+        pl.cfg = kSplitCfg;
+        plan_split_region(d->Cout, K, &pl);
+        plan_split_counts(d, 1, &pl);
+        return pl;
+    } else {
+        if (force >= 0) {
+            pl.cfg = force;
+        } else {
+            double best_cost = 1e300;
+            for (int c = 0; c < kNumWgCfg; ++c) {
+                const double padded = (double)cdiv(d->Cout, kWgShapes[c].bn) * kWgShapes[c].bn * cdiv(K, kWgShapes[c].bk) * kWgShapes[c].bk;
+                const double cost = padded / kWgShapes[c].eff;
+                if (cost < best_cost) { best_cost = cost; pl.cfg = c; }
+            }
+        }
+        const int tiles = cdiv(d->Cout, kWgShapes[pl.cfg].bn) * cdiv(K, kWgShapes[pl.cfg].bk);
+        pl.splits = cdiv(kWgShapes[pl.cfg].nw == 8 ? 512 : 1024, tiles);
+        if (pl.splits > chunks) pl.splits = chunks;
+    }
+    if (pl.splits < 1) pl.splits = 1;
+    if (pl.splits > 256) pl.splits = 256;
+    for (int c = 0; c < 4; ++c) pl.cs[c] = pl.splits;
+    return pl;
 }
 
 size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* d, int* h_splits) {
     if (!d || d->Cout <= 0) return 0;
     const long long K = (long long)d->kh * d->kw * d->Cin;
-    int cfg = 0, splits = 1;
-    plan_wgrad(d, &cfg, &splits);
-    if (h_splits) *h_splits = splits;
-    return (size_t)splits * (((size_t)d->Cout * K + d->Cout + 3) / 4 * 4);
+    const WgPlan pl = plan_wgrad(d);
+    if (h_splits) *h_splits = pl.splits;
+    return (size_t)pl.splits * (((size_t)d->Cout * K + d->Cout + 3) / 4 * 4);
 }
 
 static int wgrad_validate(const fcn_conv_desc* d) {
@@ -890,7 +1505,8 @@ static int wgrad_validate(const fcn_conv_desc* d) {
     return 0;
 }
 
-static void wgrad_fill(WgradP& p, const fcn_conv_desc* d, int cfg, int splits, float* slabs, bool with_bias, const float* zp) {
+static void wgrad_fill(WgradP& p, const fcn_conv_desc* d, const WgPlan& pl, float* slabs, bool with_bias, const float* zp) {
+    const int splits = pl.splits;
     p.x = d->x;
     p.dy = d->y + d->y_coffset;
     p.zero_page = zp;
@@ -899,10 +1515,21 @@ static void wgrad_fill(WgradP& p, const fcn_conv_desc* d, int cfg, int splits, f
     p.dy_cstride = d->y_cstride;
     p.M = d->N * d->OH * d->OW;
     p.K = d->kh * d->kw * d->Cin;
-    p.tiles_n = cdiv(p.Cout, kWgShapes[cfg].bn);
-    p.tiles_k = cdiv(p.K, kWgShapes[cfg].bk);
+    p.rn = pl.rn; p.rk = pl.rk;
+    p.tiles_n = cdiv(p.Cout, pl.cfg == kSplitCfg ? 32 * pl.rn : kWgShapes[pl.cfg].bn);
+    p.tiles_k = cdiv(p.K, pl.cfg == kSplitCfg ? 32 * pl.rk : kWgShapes[pl.cfg].bk);
     p.splits = splits;
     p.chunks_per_split = cdiv(cdiv(p.M, WG_BP), splits);
+    p.wgs = p.runs = 0;
+    p.cps0 = pl.cps0 > 0 ? pl.cps0 : 1;
+    for (int c = 0; c < 4; ++c) {
+        p.cls_splits[c] = pl.cs[c] > 0 ? pl.cs[c] : 1;
+        p.cls_d[c] = pl.d[c] > 0 ? pl.d[c] : 1;
+        p.cls_dmagic[c] = (65536 + p.cls_d[c] - 1) / p.cls_d[c];
+        p.cls_count[c] = pl.cfg == kSplitCfg ? pl.count[c] : 0;
+        p.wgs += p.cls_count[c] * p.cls_splits[c];
+        if (p.cls_count[c] && p.cls_splits[c] * p.cls_d[c] > p.runs) p.runs = p.cls_splits[c] * p.cls_d[c];
+    }
     p.ow_magic = p.OW > 1 ? magic32((unsigned)p.OW) : 0u;
     p.oh_magic = p.OH > 1 ? magic32((unsigned)p.OH) : 0u;
     p.kw_magic = (65536 + p.kw - 1) / p.kw;
@@ -910,6 +1537,21 @@ static void wgrad_fill(WgradP& p, const fcn_conv_desc* d, int cfg, int splits, f
     p.slab_floats = (p.Cout * p.K + p.Cout + 3) / 4 * 4;      // slabs stay 16-byte aligned for the reduction's float4 loads
     p.db_part = with_bias ? slabs + (size_t)p.Cout * p.K : nullptr;
 }
+
+// which slabs the reduction reads per element (weights then, if `with_bias_tail`, the bias sums right behind them; bias_only: the bias sums alone)
+static RedSplits red_splits_of(const WgradP& p, const WgPlan& pl, bool bias_only) {
+    if (pl.cfg != kSplitCfg) return red_uniform(p.splits);
+    RedSplits r;
+    r.wcount = bias_only ? 0 : (long long)p.Cout * p.K;
+    r.K = p.K;
+    r.n_last0 = (p.tiles_n - 1) * 32 * p.rn;
+    r.k_last0 = (p.tiles_k - 1) * 32 * p.rk;
+    r.b_bias = p.tiles_k == 1;      // (the bias sums come from the workgroups of the first k-region)
+    r.uniform = 0;
+    for (int c = 0; c < 4; ++c) r.s[c] = p.cls_splits[c];
+    return r;
+}
+static int split_wgs(const WgradP& p) { return p.wgs; }
 
 // dW (OHWI, [Cout][kh][kw][Cin]) and db from the layer input x and the output gradient passed in desc->y / y_cstride /
 // y_coffset (desc->w and desc->bias are ignored).  d_workspace: fcn_conv2d_wgrad_workspace_floats() floats.
@@ -919,12 +1561,21 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     if (rc) return rc;
     const float* zp = zero_page_for_current_device(&rc);
     if (rc) return rc;
-    int splits = 1, cfg = 0;
-    plan_wgrad(d, &cfg, &splits);
+    const WgPlan pl = plan_wgrad(d);
+    const int splits = pl.splits;
     WgradP p;
-    wgrad_fill(p, d, cfg, splits, d_workspace, db != nullptr, zp);
+    wgrad_fill(p, d, pl, d_workspace, db != nullptr, zp);
     hipStream_t st = as_stream(s);
-    switch (cfg) {
+    if (pl.cfg == kSplitCfg) {
+        WgradGroupArgs ga;
+        ga.n = 1;
+        for (int i = 0; i < kMaxWgGroup; ++i) {
+            ga.wg_end[i] = split_wgs(p);
+            ga.p[i] = p;
+        }
+        hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3(ga.wg_end[0]), dim3(512), 0, st, ga);
+    } else
+    switch (pl.cfg) {
 #define X(I, A, B, C_, D, E)                                                                                                              \
     case I:                                                                                                                               \
         hipLaunchKernelGGL((conv_wgrad_kernel<A, B, C_, D, E>), dim3(p.tiles_n * p.tiles_k * splits), dim3(64 * C_ * D), 0, st, p); \
@@ -938,20 +1589,21 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
     const bool together = db && db == dw + cnt;
     const size_t cnt1 = together ? cnt + p.Cout : cnt;
     const int red_blocks = (int)((cnt1 + RED_PER_BLOCK - 1) / RED_PER_BLOCK < 4096 ? (cnt1 + RED_PER_BLOCK - 1) / RED_PER_BLOCK : 4096);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(red_blocks), dim3(RED_THREADS), 0, st, p.dw_part, dw, cnt1, splits, stride);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(red_blocks), dim3(RED_THREADS), 0, st, p.dw_part, dw, cnt1, red_splits_of(p, pl, false), stride);
     if (db && !together)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.Cout, RED_PER_BLOCK)), dim3(RED_THREADS), 0, st, p.db_part, db, (size_t)p.Cout, splits, stride);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(p.Cout, RED_PER_BLOCK)), dim3(RED_THREADS), 0, st, p.db_part, db, (size_t)p.Cout,
+                           red_splits_of(p, pl, true), stride);
     FCN_LAUNCH_CHECK("conv_wgrad");
     return 0;
 }
 
 // One tile shape for the whole group (the one with the least padded work over all problems), pixel splits so that the
-// launch has ~1024-1536 workgroups in total.
-static void plan_wgrad_group(const fcn_conv_desc* ds, int n, int* cfg_out, int* splits) {
+// launch has ~1024-1536 workgroups in total.  The role-split kernel takes a region shape per problem instead.
+static void plan_wgrad_group(const fcn_conv_desc* ds, int n, WgPlan* pls) {
     int best = 0;
-    const char* force = getenv("FCN_WGRAD_CFG");
-    if (force && force[0] >= '0' && force[0] < '0' + kNumWgCfg) {
-        best = force[0] - '0';
+    const int force = wgrad_forced_cfg();
+    if (force >= 0) {
+        best = force;
     } else {
         double best_cost = 1e300;
         for (int c = 0; c < kNumWgCfg; ++c) {
@@ -965,25 +1617,36 @@ static void plan_wgrad_group(const fcn_conv_desc* ds, int n, int* cfg_out, int* 
         }
     }
     long long tiles = 0;
-    for (int i = 0; i < n; ++i)
-        tiles += (long long)cdiv(ds[i].Cout, kWgShapes[best].bn) * cdiv((long long)ds[i].kh * ds[i].kw * ds[i].Cin, kWgShapes[best].bk);
+    for (int i = 0; i < n; ++i) {
+        const long long K = (long long)ds[i].kh * ds[i].kw * ds[i].Cin;
+        pls[i] = WgPlan{};
+        pls[i].cfg = best;
+        pls[i].splits = 1;
+        if (best == kSplitCfg) plan_split_region(ds[i].Cout, K, &pls[i]);
+        else tiles += (long long)cdiv(ds[i].Cout, kWgShapes[best].bn) * cdiv(K, kWgShapes[best].bk);
+    }
+    if (best == kSplitCfg) {
+        plan_split_counts(ds, n, pls);
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         const int chunks = cdiv((long long)ds[i].N * ds[i].OH * ds[i].OW, WG_BP);
         int sp = cdiv(1024, tiles);
-        if (sp > chunks) sp = chunks;
+        const int cap = chunks;
+        if (sp > cap) sp = cap;
         if (sp < 1) sp = 1;
         if (sp > 256) sp = 256;
-        splits[i] = sp;
+        pls[i].splits = sp;
+        for (int c = 0; c < 4; ++c) pls[i].cs[c] = sp;
     }
-    *cfg_out = best;
 }
 
 size_t fcn_conv2d_wgrad_group_workspace_floats(const fcn_conv_desc* ds, int n) {
     if (!ds || n <= 0 || n > kMaxWgGroup) return 0;
-    int cfg = 0, splits[kMaxWgGroup];
-    plan_wgrad_group(ds, n, &cfg, splits);
+    WgPlan pls[kMaxWgGroup];
+    plan_wgrad_group(ds, n, pls);
     size_t total = 0;
-    for (int i = 0; i < n; ++i) total += (size_t)splits[i] * (((size_t)ds[i].Cout * ds[i].kh * ds[i].kw * ds[i].Cin + ds[i].Cout + 3) / 4 * 4) + 4;
+    for (int i = 0; i < n; ++i) total += (size_t)pls[i].splits * (((size_t)ds[i].Cout * ds[i].kh * ds[i].kw * ds[i].Cin + ds[i].Cout + 3) / 4 * 4) + 4;
     return total;
 }
 
@@ -999,38 +1662,41 @@ int fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* ds, float* const* dws, float
     }
     const float* zp = zero_page_for_current_device(&rc);
     if (rc) return rc;
-    int cfg = 0, splits[kMaxWgGroup];
-    plan_wgrad_group(ds, n, &cfg, splits);
+    WgPlan pls[kMaxWgGroup];
+    plan_wgrad_group(ds, n, pls);
+    const int cfg = pls[0].cfg;
     WgradGroupArgs ga;
     ReduceGroupArgs ra;
     ga.n = ra.n = n;
     float* slabs = d_workspace;
     int wgs = 0, blks = 0, extra = 0;
-    struct Extra { const float* parts; float* out; size_t count, stride; int splits; } extras[kMaxWgGroup];
+    struct Extra { const float* parts; float* out; size_t count, stride; RedSplits rs; } extras[kMaxWgGroup];
     for (int i = 0; i < kMaxWgGroup; ++i) {
         const int j = i < n ? i : n - 1;
         if (i < n) {
-            wgrad_fill(ga.p[i], &ds[i], cfg, splits[i], slabs, dbs[i] != nullptr, zp);
+            wgrad_fill(ga.p[i], &ds[i], pls[i], slabs, dbs[i] != nullptr, zp);
             const WgradP& p = ga.p[i];
-            wgs += p.tiles_n * p.tiles_k * p.splits;
+            wgs += cfg == kSplitCfg ? split_wgs(p) : p.tiles_n * p.tiles_k * p.splits;
             const size_t cnt = (size_t)p.Cout * p.K;
             const bool together = dbs[i] && dbs[i] == dws[i] + cnt;
             ra.parts[i] = p.dw_part;
             ra.out[i] = dws[i];
             ra.count[i] = together ? cnt + p.Cout : cnt;
             ra.stride[i] = (unsigned long long)p.slab_floats;
-            ra.splits[i] = p.splits;
+            ra.rs[i] = red_splits_of(p, pls[i], false);
             blks += (int)((ra.count[i] + RED_PER_BLOCK - 1) / RED_PER_BLOCK);
-            if (dbs[i] && !together) extras[extra++] = Extra{p.db_part, dbs[i], (size_t)p.Cout, (size_t)p.slab_floats, p.splits};
+            if (dbs[i] && !together) extras[extra++] = Extra{p.db_part, dbs[i], (size_t)p.Cout, (size_t)p.slab_floats, red_splits_of(p, pls[i], true)};
             slabs += ((size_t)p.splits * p.slab_floats + 3) / 4 * 4;
         } else {
             ga.p[i] = ga.p[j];
-            ra.parts[i] = ra.parts[j]; ra.out[i] = ra.out[j]; ra.count[i] = ra.count[j]; ra.stride[i] = ra.stride[j]; ra.splits[i] = ra.splits[j];
+            ra.parts[i] = ra.parts[j]; ra.out[i] = ra.out[j]; ra.count[i] = ra.count[j]; ra.stride[i] = ra.stride[j]; ra.rs[i] = ra.rs[j];
         }
         ga.wg_end[i] = wgs;
         ra.blk_end[i] = blks;
     }
     hipStream_t st = as_stream(s);
+    if (cfg == kSplitCfg) hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3(wgs), dim3(512), 0, st, ga);
+    else
     switch (cfg) {
 #define X(I, A, B, C_, D, E)                                                                                          \
     case I:                                                                                                           \
@@ -1042,7 +1708,7 @@ int fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* ds, float* const* dws, float
     hipLaunchKernelGGL(reduce_partials_group_kernel, dim3(blks), dim3(RED_THREADS), 0, st, ra);
     for (int e = 0; e < extra; ++e)
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((long long)extras[e].count, RED_PER_BLOCK)), dim3(RED_THREADS), 0, st, extras[e].parts,
-                           extras[e].out, extras[e].count, extras[e].splits, extras[e].stride);
+                           extras[e].out, extras[e].count, extras[e].rs, extras[e].stride);
     FCN_LAUNCH_CHECK("conv_wgrad_group");
     return 0;
 }

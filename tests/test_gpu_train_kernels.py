@@ -31,7 +31,7 @@ WG_CASES = [  # cin, cout, k, stride, pad, h, w, n
 ]
 
 
-@pytest.mark.parametrize("wg_cfg", [None, "0", "1", "2", "3"])       # heuristic tile shape, then every shape forced
+@pytest.mark.parametrize("wg_cfg", [None, "0", "1", "2", "3", "4"])  # heuristic choice, then every tile shape / the role-split kernel forced
 @pytest.mark.parametrize("case", WG_CASES)
 def test_wgrad_and_dgrad_match_oracle(gpu, monkeypatch, case, wg_cfg):
     if wg_cfg is None:
@@ -236,7 +236,7 @@ def test_weights_flip_batch_equals_per_layer_flip(gpu):
         assert np.array_equal(got[sg.wt_offset:sg.wt_offset + want.size], want)
 
 
-@pytest.mark.parametrize("wg_cfg", [None, "0", "2"])
+@pytest.mark.parametrize("wg_cfg", [None, "0", "2", "4"])
 def test_wgrad_group_matches_oracle(gpu, monkeypatch, wg_cfg):
     """Four layers' weight gradients in one launch + one grouped reduction (fcn_conv2d_wgrad_group_f32): each equals the
     oracle and the single-layer entry point; bias behind the weights (the solver's layout), elsewhere, or absent."""
