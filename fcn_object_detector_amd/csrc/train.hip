@@ -1447,11 +1447,11 @@ static void plan_split_counts(const fcn_conv_desc* ds, int n, WgPlan* pls) {
 }
 
 // tile shape with the least padded work per unit of sustained rate, then enough pixel splits to fill the chip
-static WgPlan plan_wgrad(const fcn_conv_desc* d) {
+static WgPlan plan_wgrad(const fcn_conv_desc* d, int cfg_request = -1) {
     const long long M = (long long)d->N * d->OH * d->OW, K = (long long)d->kh * d->kw * d->Cin;
     WgPlan pl = {};
     pl.splits = 1;
-    const int force = wgrad_forced_cfg();
+    const int force = cfg_request >= 0 && cfg_request <= kSplitCfg ? cfg_request : wgrad_forced_cfg();
     const int chunks = cdiv(M, WG_BP);
     if (force == kSplitCfg) {
         pl.cfg = kSplitCfg;
@@ -1479,13 +1479,17 @@ static WgPlan plan_wgrad(const fcn_conv_desc* d) {
     return pl;
 }
 
-size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* d, int* h_splits) {
+int fcn_conv2d_wgrad_num_configs(void) { return kSplitCfg + 1; }
+int fcn_conv2d_wgrad_split_config(void) { return kSplitCfg; }
+
+size_t fcn_conv2d_wgrad_workspace_floats_cfg(const fcn_conv_desc* d, int cfg_request, int* h_splits) {
     if (!d || d->Cout <= 0) return 0;
     const long long K = (long long)d->kh * d->kw * d->Cin;
-    const WgPlan pl = plan_wgrad(d);
+    const WgPlan pl = plan_wgrad(d, cfg_request);
     if (h_splits) *h_splits = pl.splits;
     return (size_t)pl.splits * (((size_t)d->Cout * K + d->Cout + 3) / 4 * 4);
 }
+size_t fcn_conv2d_wgrad_workspace_floats(const fcn_conv_desc* d, int* h_splits) { return fcn_conv2d_wgrad_workspace_floats_cfg(d, -1, h_splits); }
 
 static int wgrad_validate(const fcn_conv_desc* d) {
     FCN_REQUIRE(d && d->x && d->y, FCN_E_ARG, "wgrad: null");
@@ -1556,12 +1560,17 @@ static int split_wgs(const WgradP& p) { return p.wgs; }
 // dW (OHWI, [Cout][kh][kw][Cin]) and db from the layer input x and the output gradient passed in desc->y / y_cstride /
 // y_coffset (desc->w and desc->bias are ignored).  d_workspace: fcn_conv2d_wgrad_workspace_floats() floats.
 int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_workspace, fcn_stream_t s) {
+    return fcn_conv2d_wgrad_cfg_f32(d, dw, db, d_workspace, -1, s);
+}
+
+int fcn_conv2d_wgrad_cfg_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_workspace, int cfg_request, fcn_stream_t s) {
     FCN_REQUIRE(d && dw && d_workspace, FCN_E_ARG, "wgrad: null");
+    FCN_REQUIRE(cfg_request >= -1 && cfg_request <= kSplitCfg, FCN_E_ARG, "wgrad: configuration %d (have -1 .. %d)", cfg_request, kSplitCfg);
     int rc = wgrad_validate(d);
     if (rc) return rc;
     const float* zp = zero_page_for_current_device(&rc);
     if (rc) return rc;
-    const WgPlan pl = plan_wgrad(d);
+    const WgPlan pl = plan_wgrad(d, cfg_request);
     const int splits = pl.splits;
     WgradP p;
     wgrad_fill(p, d, pl, d_workspace, db != nullptr, zp);
@@ -1599,9 +1608,9 @@ int fcn_conv2d_wgrad_f32(const fcn_conv_desc* d, float* dw, float* db, float* d_
 
 // One tile shape for the whole group (the one with the least padded work over all problems), pixel splits so that the
 // launch has ~1024-1536 workgroups in total.  The role-split kernel takes a region shape per problem instead.
-static void plan_wgrad_group(const fcn_conv_desc* ds, int n, WgPlan* pls) {
+static void plan_wgrad_group(const fcn_conv_desc* ds, int n, WgPlan* pls, int cfg_request = -1) {
     int best = 0;
-    const int force = wgrad_forced_cfg();
+    const int force = cfg_request >= 0 && cfg_request <= kSplitCfg ? cfg_request : wgrad_forced_cfg();
     if (force >= 0) {
         best = force;
     } else {
@@ -1641,10 +1650,12 @@ static void plan_wgrad_group(const fcn_conv_desc* ds, int n, WgPlan* pls) {
     }
 }
 
-size_t fcn_conv2d_wgrad_group_workspace_floats(const fcn_conv_desc* ds, int n) {
+size_t fcn_conv2d_wgrad_group_workspace_floats(const fcn_conv_desc* ds, int n) { return fcn_conv2d_wgrad_group_workspace_floats_cfg(ds, n, -1); }
+
+size_t fcn_conv2d_wgrad_group_workspace_floats_cfg(const fcn_conv_desc* ds, int n, int cfg_request) {
     if (!ds || n <= 0 || n > kMaxWgGroup) return 0;
     WgPlan pls[kMaxWgGroup];
-    plan_wgrad_group(ds, n, pls);
+    plan_wgrad_group(ds, n, pls, cfg_request);
     size_t total = 0;
     for (int i = 0; i < n; ++i) total += (size_t)pls[i].splits * (((size_t)ds[i].Cout * ds[i].kh * ds[i].kw * ds[i].Cin + ds[i].Cout + 3) / 4 * 4) + 4;
     return total;
@@ -1653,7 +1664,13 @@ size_t fcn_conv2d_wgrad_group_workspace_floats(const fcn_conv_desc* ds, int n) {
 // n <= 4 layers in one launch + one grouped reduction.  dbs[i] may be NULL; when dbs[i] == dws[i] + Cout*K (the solver's
 // layout) weight and bias partials are reduced together.
 int fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* ds, float* const* dws, float* const* dbs, int n, float* d_workspace, fcn_stream_t s) {
+    return fcn_conv2d_wgrad_group_cfg_f32(ds, dws, dbs, n, d_workspace, -1, s);
+}
+
+int fcn_conv2d_wgrad_group_cfg_f32(const fcn_conv_desc* ds, float* const* dws, float* const* dbs, int n, float* d_workspace, int cfg_request,
+                                   fcn_stream_t s) {
     FCN_REQUIRE(ds && dws && dbs && d_workspace && n > 0 && n <= kMaxWgGroup, FCN_E_ARG, "wgrad group: need 1..%d problems", kMaxWgGroup);
+    FCN_REQUIRE(cfg_request >= -1 && cfg_request <= kSplitCfg, FCN_E_ARG, "wgrad group: configuration %d (have -1 .. %d)", cfg_request, kSplitCfg);
     int rc = 0;
     for (int i = 0; i < n; ++i) {
         rc = wgrad_validate(&ds[i]);
@@ -1663,7 +1680,7 @@ int fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* ds, float* const* dws, float
     const float* zp = zero_page_for_current_device(&rc);
     if (rc) return rc;
     WgPlan pls[kMaxWgGroup];
-    plan_wgrad_group(ds, n, pls);
+    plan_wgrad_group(ds, n, pls, cfg_request);
     const int cfg = pls[0].cfg;
     WgradGroupArgs ga;
     ReduceGroupArgs ra;

@@ -143,6 +143,12 @@ PROTOTYPES = {
     "fcn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp]),
     "fcn_conv2d_wgrad_group_workspace_floats": (_sz, [C.POINTER(ConvDesc), _i]),
     "fcn_conv2d_wgrad_group_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _vp]),
+    "fcn_conv2d_wgrad_num_configs": (_i, []),
+    "fcn_conv2d_wgrad_split_config": (_i, []),
+    "fcn_conv2d_wgrad_workspace_floats_cfg": (_sz, [C.POINTER(ConvDesc), _i, C.POINTER(_i)]),
+    "fcn_conv2d_wgrad_cfg_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _i, _vp]),
+    "fcn_conv2d_wgrad_group_workspace_floats_cfg": (_sz, [C.POINTER(ConvDesc), _i, _i]),
+    "fcn_conv2d_wgrad_group_cfg_f32": (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _vp, _i, _vp]),
     "fcn_conv_weights_flip_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fcn_nchw_f32_to_nhwc_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "fcn_nhwc_f16_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

@@ -299,19 +299,22 @@ class TrainEngine(Engine):
                 chunk = todo[base:base + 4]
                 its = [wgrad_item(l_, g_) for l_, g_ in chunk]
                 names = [l_.name for l_, _ in chunk]
+                sel = {"cfg": -1}      # -1: the library's heuristic; _tune_wgrads() replaces it once the workspace exists
+                cfgs = [-1] + (list(range(int(lib.fcn_conv2d_wgrad_num_configs()))) if self.autotune else [])
                 if len(its) == 1:
                     d, dw, db, fl = its[0]
-                    ws_floats = max(ws_floats, int(lib.fcn_conv2d_wgrad_workspace_floats(C.byref(d), None)))
-                    op = Op("wgrad", names[0], lambda st, d=d, dw=dw, db=db: L.check(lib.fcn_conv2d_wgrad_f32(
-                        C.byref(d), dw.ptr, db.ptr if db else None, self._ws.ptr, st)), fl)
+                    ws_floats = max([ws_floats] + [int(lib.fcn_conv2d_wgrad_workspace_floats_cfg(C.byref(d), c, None)) for c in cfgs])
+                    op = Op("wgrad", names[0], lambda st, d=d, dw=dw, db=db, sel=sel: L.check(lib.fcn_conv2d_wgrad_cfg_f32(
+                        C.byref(d), dw.ptr, db.ptr if db else None, self._ws.ptr, sel["cfg"], st)), fl)
                 else:
                     arr = (L.ConvDesc * len(its))(*[it[0] for it in its])
                     pdw = (C.c_void_p * len(its))(*[it[1].ptr for it in its])
                     pdb = (C.c_void_p * len(its))(*[(it[2].ptr if it[2] is not None else None) for it in its])
-                    ws_floats = max(ws_floats, int(lib.fcn_conv2d_wgrad_group_workspace_floats(arr, len(its))))
+                    ws_floats = max([ws_floats] + [int(lib.fcn_conv2d_wgrad_group_workspace_floats_cfg(arr, len(its), c)) for c in cfgs])
                     self._keep.extend([arr, pdw, pdb])
-                    op = Op("wgrad", "+".join(names), lambda st, arr=arr, pdw=pdw, pdb=pdb, m=len(its): L.check(lib.fcn_conv2d_wgrad_group_f32(
-                        arr, pdw, pdb, m, self._ws.ptr, st)), sum(it[3] for it in its))
+                    op = Op("wgrad", "+".join(names), lambda st, arr=arr, pdw=pdw, pdb=pdb, m=len(its), sel=sel: L.check(
+                        lib.fcn_conv2d_wgrad_group_cfg_f32(arr, pdw, pdb, m, self._ws.ptr, sel["cfg"], st)), sum(it[3] for it in its))
+                op.sel = sel
                 op.layers = names
                 ops.append(op)
                 wgrad_done.update(names)
@@ -522,7 +525,56 @@ class TrainEngine(Engine):
         finish_dgrads()
         self._ws = DeviceBuffer(ws_floats * 4, zero=False)
         self.bwd_ops = ops
+        if self.autotune:
+            self._tune_wgrads()
         self._plan_buckets()
+
+    def _tune_wgrads(self) -> None:
+        """Plan-time choice of every weight-gradient launch's configuration (the 64-wide tile shapes and the role-split kernel of
+        csrc/train.hip): each is timed on the buffers the step will use, the fastest is kept - and remembered in $FCN_TUNE_CACHE
+        beside the forward plan.  Gradient buffers hold garbage until the first real backward pass, which overwrites them."""
+        lib = L.load()
+        ncfg = int(lib.fcn_conv2d_wgrad_num_configs())
+        cache = self._load_tune_cache()
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        L.call("fcn_event_create", C.byref(e0))
+        L.call("fcn_event_create", C.byref(e1))
+        dirty = False
+        for op in self.bwd_ops:
+            if op.kind != "wgrad":
+                continue
+            key = self._tune_key("wgrad:" + "+".join(op.layers))
+            if self._tune_from is not None and key in self._tune_from._chosen_cfgs:
+                op.sel["cfg"] = self._chosen_cfgs[key] = self._tune_from._chosen_cfgs[key]
+                continue
+            if cache is not None and key in cache and 0 <= int(cache[key]) < ncfg:
+                op.sel["cfg"] = self._chosen_cfgs[key] = int(cache[key])
+                continue
+            best, best_ms = -1, 1e30
+            for cfg in range(ncfg):
+                op.sel["cfg"] = cfg
+                for _ in range(2):
+                    op.run(self.stream)
+                L.call("fcn_event_record", e0, self.stream)
+                for _ in range(5):
+                    op.run(self.stream)
+                L.call("fcn_event_record", e1, self.stream)
+                L.call("fcn_event_sync", e1)
+                ms = C.c_float()
+                L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+                if ms.value < best_ms:
+                    best, best_ms = cfg, ms.value
+            op.sel["cfg"] = self._chosen_cfgs[key] = best
+            if cache is not None:
+                cache[key] = best
+                dirty = True
+        if dirty:
+            self._save_tune_cache()
+        for op in self.bwd_ops:
+            if op.kind == "wgrad":
+                op.name += " [cfg%d]" % op.sel["cfg"]
+        L.call("fcn_event_destroy", e0)
+        L.call("fcn_event_destroy", e1)
 
     def _plan_buckets(self, bucket_floats: int = 1536 * 1024) -> None:
         """Gradient buckets for the overlapped all-reduce: contiguous ranges of the flat gradient buffer (forward layer

@@ -342,6 +342,20 @@ int  fcn_conv2d_wgrad_f32(const fcn_conv_desc* h_d, float* dw, float* db, float*
 size_t fcn_conv2d_wgrad_group_workspace_floats(const fcn_conv_desc* h_ds, int n);
 int  fcn_conv2d_wgrad_group_f32(const fcn_conv_desc* h_ds, float* const* h_dws, float* const* h_dbs, int n, float* d_workspace,
                                 fcn_stream_t s);
+/* The same four calls with the launch configuration named by the caller (the training engine times every configuration once per
+ * launch at plan time and keeps the fastest, as the forward engine does): cfg_request -1 = the built-in heuristic (what the calls
+ * above use), 0 .. fcn_conv2d_wgrad_num_configs() - 1 = that configuration.  The last one, fcn_conv2d_wgrad_split_config(), is
+ * the role-split kernel (eight waves with fixed staging / multiplying roles, a region shape per problem); the others are tile
+ * shapes of the 64-wide family.  The workspace of a launch depends on its configuration: size it with the SAME cfg_request (or
+ * with the maximum over the ones that may be used).  Every configuration is bit-reproducible; two configurations differ in the
+ * last bits (their pixel split counts differ). */
+int  fcn_conv2d_wgrad_num_configs(void);
+int  fcn_conv2d_wgrad_split_config(void);
+size_t fcn_conv2d_wgrad_workspace_floats_cfg(const fcn_conv_desc* h_d, int cfg_request, int* h_splits);
+int  fcn_conv2d_wgrad_cfg_f32(const fcn_conv_desc* h_d, float* dw, float* db, float* d_workspace, int cfg_request, fcn_stream_t s);
+size_t fcn_conv2d_wgrad_group_workspace_floats_cfg(const fcn_conv_desc* h_ds, int n, int cfg_request);
+int  fcn_conv2d_wgrad_group_cfg_f32(const fcn_conv_desc* h_ds, float* const* h_dws, float* const* h_dbs, int n, float* d_workspace,
+                                    int cfg_request, fcn_stream_t s);
 /* Filter bank of the data-gradient pass: wt[c][kh-1-r][kw-1-q][k] = w[k][r][q][c] (w: [Cout][kh][kw][Cin4],
  * wt: [Cin][kh][kw][Cout4], zero padded).  dX = fcn_conv2d_fwd_f32(dY, wt) with pad' = k-1-pad for stride-1 layers. */
 int  fcn_conv_weights_flip_f32(const float* w, float* wt, int Cout, int kh, int kw, int Cin, int Cin4, int Cout4, fcn_stream_t s);

@@ -290,3 +290,58 @@ def test_wgrad_group_matches_oracle(gpu, monkeypatch, wg_cfg):
     L.call("fcn_conv2d_wgrad_group_f32", arr, pdw, pdb, 4, ws.ptr, None)             # bit-reproducible
     for (flat, cout, k, cin, cin4, *_), f in zip(refs, first):
         assert np.array_equal(dev_to(flat, f.shape), f)
+
+
+def test_wgrad_configuration_named_by_the_caller(gpu, monkeypatch):
+    """fcn_conv2d_wgrad_group_cfg_f32 / fcn_conv2d_wgrad_cfg_f32: every configuration the library offers matches the oracle, is
+    the launch FCN_WGRAD_CFG would force (bit for bit), and an index outside -1 .. num_configs - 1 is refused."""
+    monkeypatch.delenv("FCN_WGRAD_CFG", raising=False)
+    rng = np.random.default_rng(5)
+    lib = L.load()
+    ncfg = int(lib.fcn_conv2d_wgrad_num_configs())
+    assert int(lib.fcn_conv2d_wgrad_split_config()) == ncfg - 1
+    n, h, w = 2, 13, 9
+    cases = [(32, 40, 3, 1), (64, 24, 1, 0)]
+    descs, refs, keep, dws, dbs = [], [], [], [], []
+    for cin, cout, k, pad in cases:
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        dy = rng.standard_normal((n, cout, h, w)).astype(np.float32)
+        dw_ref, db_ref, _ = R.conv2d_backward(x, np.zeros((cout, cin, k, k), np.float32), dy, pad, 1, need_dx=False)
+        xd, dyd = dev_from(nhwc(x, cin)), dev_from(nhwc(dy, r4(cout)))
+        descs.append(conv_desc(xd, xd, None, dyd, n, h, w, cin, cin, cout, k, pad, 1, h, w, r4(cout), 0))
+        flat = dev_from(np.zeros(cout * k * k * cin + cout, np.float32))
+        dws.append(flat.ptr)
+        dbs.append(flat.ptr + 4 * cout * k * k * cin)
+        keep += [xd, dyd, flat]
+        refs.append((flat, cout, k, cin, dw_ref, db_ref))
+    arr = (L.ConvDesc * 2)(*descs)
+    pdw, pdb = (C.c_void_p * 2)(*dws), (C.c_void_p * 2)(*dbs)
+
+    def read():
+        return [dev_to(flat, (cout * k * k * cin + cout,)).copy() for flat, cout, k, cin, _, _ in refs]
+
+    for cfg in range(ncfg):
+        ws = DeviceBuffer(int(lib.fcn_conv2d_wgrad_group_workspace_floats_cfg(arr, 2, cfg)) * 4, zero=False)
+        L.call("fcn_conv2d_wgrad_group_cfg_f32", arr, pdw, pdb, 2, ws.ptr, cfg, None)
+        named = read()
+        for got, (flat, cout, k, cin, dw_ref, db_ref) in zip(named, refs):
+            nw = cout * k * k * cin
+            assert rel_err(got[:nw].reshape(cout, k, k, cin).transpose(0, 3, 1, 2), dw_ref) < TOL, cfg
+            assert rel_err(got[nw:], db_ref) < TOL, cfg
+        monkeypatch.setenv("FCN_WGRAD_CFG", str(cfg))
+        L.call("fcn_conv2d_wgrad_group_f32", arr, pdw, pdb, 2, ws.ptr, None)
+        monkeypatch.delenv("FCN_WGRAD_CFG")
+        for a, b in zip(named, read()):
+            assert np.array_equal(a, b), cfg
+        # the single-problem entry point with the same configuration
+        ws1 = DeviceBuffer(int(lib.fcn_conv2d_wgrad_workspace_floats_cfg(C.byref(descs[0]), cfg, None)) * 4, zero=False)
+        L.call("fcn_conv2d_wgrad_cfg_f32", C.byref(descs[0]), dws[0], dbs[0], ws1.ptr, cfg, None)
+        flat, cout, k, cin, dw_ref, db_ref = refs[0]
+        got = read()[0]
+        assert rel_err(got[:cout * k * k * cin].reshape(cout, k, k, cin).transpose(0, 3, 1, 2), dw_ref) < TOL, cfg
+        ws.free()
+        ws1.free()
+    ws = DeviceBuffer(1 << 20, zero=False)
+    for bad in (-2, ncfg):
+        assert lib.fcn_conv2d_wgrad_group_cfg_f32(arr, pdw, pdb, 2, ws.ptr, bad, None) != 0
+        assert lib.fcn_conv2d_wgrad_cfg_f32(C.byref(descs[0]), dws[0], dbs[0], ws.ptr, bad, None) != 0
