@@ -61,13 +61,26 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__
     }
 }
 
+// Source windows of fcn_preprocess_bgr8_rois (detection_window_roi :257-277): x, y, w, h per image of the batch, by value in the
+// kernel arguments.  n = 0: every image is its whole frame (blockIdx.y-th frame of the batch, own min/max).
+constexpr int kMaxRois = 32;
+struct RoiTable { int n; int r[kMaxRois][4]; };
+
 template <typename D>
 __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restrict__ frame, int h, int w, D* __restrict__ dst, int H,
                                                           int W, int cstride, float shift, const int* __restrict__ mm, long long frame_stride,
-                                                          long long dst_stride) {
-    frame += (size_t)blockIdx.y * frame_stride;
+                                                          long long dst_stride, const RoiTable rois) {
     dst += (size_t)blockIdx.y * dst_stride;
-    mm += 8 * blockIdx.y;
+    const int pitch = w;      // pixels per frame row
+    if (rois.n > 0) {         // a window of the ONE frame, normalised by the frame's min/max (the node demeans before it crops, :198-200)
+        const int* r = rois.r[blockIdx.y];
+        frame += ((size_t)r[1] * pitch + r[0]) * 3;
+        w = r[2];
+        h = r[3];
+    } else {
+        frame += (size_t)blockIdx.y * frame_stride;
+        mm += 8 * blockIdx.y;
+    }
     double gmin = 1e300, gmax = -1e300;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -95,10 +108,10 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const double m = kMeanBGR[c];
-            const double s00 = ((double)frame[((size_t)sy * w + sx) * 3 + c] - m - gmin) / range;
-            const double s01 = ((double)frame[((size_t)sy * w + sx1) * 3 + c] - m - gmin) / range;
-            const double s10 = ((double)frame[((size_t)sy1 * w + sx) * 3 + c] - m - gmin) / range;
-            const double s11 = ((double)frame[((size_t)sy1 * w + sx1) * 3 + c] - m - gmin) / range;
+            const double s00 = ((double)frame[((size_t)sy * pitch + sx) * 3 + c] - m - gmin) / range;
+            const double s01 = ((double)frame[((size_t)sy * pitch + sx1) * 3 + c] - m - gmin) / range;
+            const double s10 = ((double)frame[((size_t)sy1 * pitch + sx) * 3 + c] - m - gmin) / range;
+            const double s11 = ((double)frame[((size_t)sy1 * pitch + sx1) * 3 + c] - m - gmin) / range;
             const double r0 = s00 * a0 + s01 * a1;
             const double r1 = s10 * a0 + s11 * a1;
             dst[(size_t)t * cstride + c] = (D)((float)(r0 * b0 + r1 * b1) + shift);   // blob value rounded to f32 first, as Caffe's Power layer sees it
@@ -111,24 +124,36 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
 extern "C" {
 
 static int preprocess_any(const uint8_t* frame, int n, int h, int w, void* dst, bool f16, int H, int W, int dst_cstride, float shift,
-                          float* d_minmax, fcn_stream_t s) {
+                          float* d_minmax, fcn_stream_t s, const int32_t* h_rois = nullptr) {
     FCN_REQUIRE(frame && dst && d_minmax && n > 0 && n <= 65535 && h > 0 && w > 0 && H > 0 && W > 0 && dst_cstride >= 3, FCN_E_ARG,
                 "preprocess: bad args");
+    RoiTable rois = {};
+    if (h_rois) {
+        FCN_REQUIRE(n <= kMaxRois, FCN_E_ARG, "preprocess: at most %d windows per frame", kMaxRois);
+        for (int i = 0; i < n; ++i) {
+            const int32_t* r = h_rois + 4 * i;
+            FCN_REQUIRE(r[0] >= 0 && r[1] >= 0 && r[2] > 0 && r[3] > 0 && (long long)r[0] + r[2] <= w && (long long)r[1] + r[3] <= h, FCN_E_ARG,
+                        "preprocess: window %d (%d, %d, %d x %d) leaves the %d x %d frame", i, r[0], r[1], r[2], r[3], w, h);
+            for (int k = 0; k < 4; ++k) rois.r[i][k] = r[k];
+        }
+        rois.n = n;
+    }
     hipStream_t st = as_stream(s);
     int* mm = reinterpret_cast<int*>(d_minmax);
     const long long fstride = (long long)h * w * 3, dstride = (long long)H * W * dst_cstride;
-    hipLaunchKernelGGL(minmax_init_kernel, dim3(1, n), dim3(64), 0, st, mm);
+    const int frames = h_rois ? 1 : n;      // windows share their frame's min/max
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1, frames), dim3(64), 0, st, mm);
     int mm_blocks = stream_grid((long long)h * w, 256 * 16);      // >= 16 pixels per lane: a few hundred workgroups at most
     if (mm_blocks > 256) mm_blocks = 256;
-    hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks, n), dim3(256), 0, st, frame, (long long)h * w, mm, fstride);
+    hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks, frames), dim3(256), 0, st, frame, (long long)h * w, mm, fstride);
     int rn_blocks = stream_grid((long long)H * W, 256);
     if (rn_blocks > 8192) rn_blocks = 8192;
     if (f16)
         hipLaunchKernelGGL(resize_norm_kernel<_Float16>, dim3(rn_blocks, n), dim3(256), 0, st, frame, h, w, reinterpret_cast<_Float16*>(dst), H, W,
-                           dst_cstride, shift, mm, fstride, dstride);
+                           dst_cstride, shift, mm, fstride, dstride, rois);
     else
         hipLaunchKernelGGL(resize_norm_kernel<float>, dim3(rn_blocks, n), dim3(256), 0, st, frame, h, w, reinterpret_cast<float*>(dst), H, W,
-                           dst_cstride, shift, mm, fstride, dstride);
+                           dst_cstride, shift, mm, fstride, dstride, rois);
     FCN_LAUNCH_CHECK("preprocess_bgr8");
     return 0;
 }
@@ -141,6 +166,12 @@ int fcn_preprocess_bgr8(const uint8_t* frame, int h, int w, float* dst, int H, i
 int fcn_preprocess_bgr8_f16(const uint8_t* frame, int h, int w, void* dst, int H, int W, int dst_cstride, float shift, float* d_minmax,
                             fcn_stream_t s) {
     return preprocess_any(frame, 1, h, w, dst, true, H, W, dst_cstride, shift, d_minmax, s);
+}
+
+int fcn_preprocess_bgr8_rois(const uint8_t* frame, int h, int w, const int32_t* h_rois, int n, void* dst, int dst_f16, int H, int W,
+                             int dst_cstride, float shift, float* d_minmax, fcn_stream_t s) {
+    FCN_REQUIRE(h_rois, FCN_E_ARG, "preprocess_rois: null window list");
+    return preprocess_any(frame, n, h, w, dst, dst_f16 != 0, H, W, dst_cstride, shift, d_minmax, s, h_rois);
 }
 
 int fcn_preprocess_bgr8_batch(const uint8_t* frames, int n, int h, int w, void* dst, int dst_f16, int H, int W, int dst_cstride, float shift,

@@ -196,6 +196,19 @@ def resize_detection(in_size: Sequence[int], boxes: np.ndarray, net_w: int, net_
     return boxes
 
 
+def detection_window_roi(im_shape: Sequence[int], stride: int = 2) -> np.ndarray:
+    """Window geometry of fcn_object_detector.py:257-277: stride x stride windows in raster order, then the central one; rows are
+    (x, y, w, h) int32.  Python-2 integer division throughout (im_x / stride, w / 2)."""
+    im_y, im_x = int(im_shape[0]), int(im_shape[1])
+    stride = int(stride)
+    if stride < 1 or im_x < stride or im_y < stride:
+        raise ValueError("detection_window_roi: stride %d does not divide a %d x %d frame into windows" % (stride, im_x, im_y))
+    w, h = im_x // stride, im_y // stride
+    rects = [(i * w, j * h, w, h) for j in range(stride) for i in range(stride)]
+    rects.append((im_x // 2 - w // 2, im_y // 2 - h // 2, w, h))
+    return np.asarray(rects, dtype=np.int32)
+
+
 class FCNObjectDetector:
     """ROS-free mirror of the reference node: ``run_detector(frame_bgr_uint8) -> (boxes (D,5) int, labels (D,) int)``."""
 
@@ -273,6 +286,50 @@ class FCNObjectDetector:
         self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
         self.decoder.fetch_begin(eng.stream)
         data.host_valid = False
+
+    def run_detector2(self, frame: np.ndarray, stride: int = 2) -> Tuple[np.ndarray, List[Tuple[np.ndarray, np.ndarray]]]:
+        """The node's multi-window path without ROS (run_detector2 :178-211): the frame is demeaned and normalised as a whole,
+        cut into stride x stride windows plus the central one (detection_window_roi :257-277), every window resized to the net's
+        input, and ALL windows go through ONE batched forward (`net.blobs['data'].reshape(batch_size, ...)`; here the engine's
+        batch must equal stride^2 + 1) and one fused decode + groupRectangles launch.  Returns (rects (n, 4) int32 x y w h,
+        [(boxes (D, 5) int in FRAME coordinates, labels (D,))] per window); `net.blobs[...]` hold the windows' maps afterwards
+        (the node reads 'score' there).  What the node does with its score maps next (cv.resize to the window, findContours,
+        publishing) needs OpenCV / ROS and is not part of the tensor path."""
+        eng = self.engine
+        frame = np.ascontiguousarray(frame, np.uint8)
+        if frame.ndim != 3 or frame.shape[2] != 3:
+            raise ValueError("expected a BGR uint8 frame")
+        rects = detection_window_roi(frame.shape, stride)
+        if len(rects) != self.batch:
+            raise ValueError("stride %d makes %d windows; the engine's batch is %d" % (stride, len(rects), self.batch))
+        if getattr(self, "_outstanding", None) is not None:
+            raise RuntimeError("a batch is already in flight: collect it first")
+        h, w, _c = frame.shape
+        with eng.lock:
+            L.call("fcn_init", eng.device)
+            if self._frame_dev is None or self._frame_dev.nbytes < frame.nbytes:
+                self._frame_dev = DeviceBuffer(frame.nbytes, zero=False)
+                self._frame_pinned = PinnedArray(((frame.nbytes + 3) // 4,))
+            stage = self._frame_pinned.array.view(np.uint8)[:frame.nbytes]
+            stage[...] = frame.reshape(-1)
+            data = eng.blobs["data"]
+            L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, stage.ctypes.data, frame.nbytes, eng.stream)
+            L.call("fcn_preprocess_bgr8_rois", self._frame_dev.ptr, h, w, rects.ctypes.data, len(rects), data.ptr, 1 if data.esize == 2 else 0,
+                   self.im_height, self.im_width, data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
+            eng.forward_enqueue()
+            self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
+            self.decoder.fetch_begin(eng.stream)
+            data.host_valid = False
+            res = self.decoder.fetch(eng.stream, begun=True)
+        out = []
+        for (x, y, rw, rh), (dets, labels) in zip(rects.tolist(), res):
+            boxes = np.asarray(dets, dtype=np.int64).reshape(-1, 5)
+            if len(boxes):
+                boxes = resize_detection((rh, rw), boxes, self.im_width, self.im_height)
+                boxes[:, 0] += x; boxes[:, 2] += x
+                boxes[:, 1] += y; boxes[:, 3] += y
+            out.append((boxes, labels))
+        return rects, out
 
     def collect_batch(self) -> List[Tuple[np.ndarray, np.ndarray]]:
         if getattr(self, "_outstanding", None) is None:

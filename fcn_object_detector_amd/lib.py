@@ -155,6 +155,7 @@ PROTOTYPES = {
     "fcn_maxpool_fwd_f16": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
     "fcn_lrn_fwd_f16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),
     "fcn_preprocess_bgr8_batch": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "fcn_preprocess_bgr8_rois": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "fcn_preprocess_bgr8_f16": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp]),
     "fcn_compose_scene_bgr8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp]),
     "fcn_mask_to_label_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),

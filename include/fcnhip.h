@@ -218,6 +218,13 @@ int  fcn_lrn_fwd_f16(const void* x, void* y, int pixels, int C, int x_cstride, i
 /* the half twin of fcn_maxpool_lrn5_fwd_f32 (8-channel groups); bit-identical to fcn_maxpool_fwd_f16 + fcn_lrn_fwd_f16 in either order */
 int  fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
                               int OH, int OW, int y_cstride, int lrn_first, float alpha, float beta, float lrn_k, fcn_stream_t s);
+/* n windows of ONE frame -> the n images of an N x H x W x dst_cstride blob: the node's multi-window path
+ * (scripts/fcn_object_detector.py run_detector2 :198-211 with detection_window_roi :257-277) demeans and normalises the WHOLE frame
+ * (min / max over the frame), crops stride x stride windows plus a central one, and resizes each to the net's input.  h_rois: n x
+ * (x, y, w, h) int32 on the HOST, every window inside the frame, n <= 32; d_minmax: 32 bytes.  Same arithmetic as
+ * fcn_preprocess_bgr8 (float64, float resize coefficients). */
+int  fcn_preprocess_bgr8_rois(const uint8_t* frame, int h, int w, const int32_t* h_rois, int n, void* dst, int dst_f16, int H, int W,
+                              int dst_cstride, float shift, float* d_minmax, fcn_stream_t s);
 /* n equally sized frames (h*w*3 bytes apart) -> the n images of an N x H x W x dst_cstride blob in three launches;
  * each frame is normalised with its own min / max.  d_minmax: 32 bytes per frame. */
 int  fcn_preprocess_bgr8_batch(const uint8_t* frames, int n, int h, int w, void* dst, int dst_f16, int H, int W, int dst_cstride,

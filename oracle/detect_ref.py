@@ -276,6 +276,45 @@ def preprocess_frame(frame_bgr: np.ndarray, W: int, H: int) -> np.ndarray:
     return im.transpose(2, 0, 1).astype(np.float32)
 
 
+def detection_window_roi(image: np.ndarray, net_size: Tuple[int, int], stride: int = 2):
+    """scripts/fcn_object_detector.py:257-277 - stride x stride windows of the (already demeaned) image in raster order plus a
+    central one of the same size, each cv.resize'd to net_size = (W, H) and transposed to CHW; rects are (x, y, w, h).  The
+    reference is Python 2: `/` on ints floors (w/2, h/2 of the central crop)."""
+    im_y, im_x = image.shape[:2]
+    w, h = int(im_x // stride), int(im_y // stride)
+    im_rois, rects = [], []
+    for j in range(stride):
+        for i in range(stride):
+            roi = image[j * h:j * h + h, i * w:i * w + w]
+            im_rois.append(resize_bilinear_cv(roi, net_size[0], net_size[1]).transpose(2, 0, 1))
+            rects.append(np.array([i * w, j * h, w, h]))
+    cx, cy = int(im_x // 2) - w // 2, int(im_y // 2) - h // 2
+    roi = image[cy:cy + h, cx:cx + w]
+    im_rois.append(resize_bilinear_cv(roi, net_size[0], net_size[1]).transpose(2, 0, 1))
+    rects.append(np.array([cx, cy, w, h]))
+    return im_rois, rects
+
+
+def run_detector2_inputs(frame_bgr: np.ndarray, W: int, H: int, stride: int = 2):
+    """run_detector2 :198-211 up to net.forward(): the whole frame is demeaned and normalised FIRST (its min / max, not a
+    window's), then cut into windows; blob.data[...] = in_datum rounds float64 to float32.  -> ((n, 3, H, W) float32, rects)."""
+    im = demean_rgb_image(frame_bgr, np.float64)
+    im_rois, rects = detection_window_roi(im, (W, H), stride)
+    return np.stack(im_rois).astype(np.float32), rects
+
+
+def window_boxes_to_frame(rect, boxes: np.ndarray, net_w: int, net_h: int) -> np.ndarray:
+    """Detections of one window (net coordinates, integer rows x1 y1 x2 y2 score) in frame coordinates: resize_detection
+    (:396-405) with the window's size as the input size, then the window's origin added, as run_detector2 moves its boxes by
+    rect[0], rect[1] (:232-233; its 10-pixel padding belongs to the mask path and is not applied)."""
+    out = np.asarray(boxes, dtype=np.int64).reshape(-1, 5).copy()
+    if len(out):
+        out = resize_detection((int(rect[3]), int(rect[2])), out, net_w, net_h)
+        out[:, 0] += int(rect[0]); out[:, 2] += int(rect[0])
+        out[:, 1] += int(rect[1]); out[:, 3] += int(rect[1])
+    return out
+
+
 # ---------------------------------------------------------------------------
 # A4: target generation
 # ---------------------------------------------------------------------------

@@ -5,7 +5,7 @@ import pytest
 from fcn_object_detector_amd import lib as L
 from fcn_object_detector_amd import models, proto
 from fcn_object_detector_amd.detector import FCNObjectDetector, HeadMapping, detect_from_maps, generate_targets
-from fcn_object_detector_amd.engine import Engine
+from fcn_object_detector_amd.engine import DeviceBuffer, Engine
 from fcn_object_detector_amd.netspec import NetSpec, fill_params
 from oracle import detect_ref as D
 
@@ -263,3 +263,47 @@ def test_detect_sizes_outside_the_margin_table(gpu):
         base = np.array([40, 30, 5200, 4700], np.float32) if big else np.array([-300, -200, -90, -70], np.float32)
         bb[0, :, cy, cx] = base - np.array([cx * 16, cy * 16, cx * 16, cy * 16], np.float32) + rng.integers(-3, 4, 4)
     assert check(cvg, bb, 448, 16, min_boxes=2) >= 1          # the large boxes group; negative sizes never do (delta < 0)
+
+
+@pytest.mark.parametrize("h,w,stride", [(480, 640, 2), (301, 517, 2), (240, 330, 1), (448, 448, 3)])
+def test_run_detector2_windows_match_oracle(gpu, h, w, stride):
+    """run_detector2's batch (fcn_object_detector.py:178-211, :257-277): stride^2 windows + the central one, cut from the frame
+    AFTER whole-frame normalisation, resized to the net input, one batched forward, one decode + groupRectangles launch.  Window
+    geometry bit-exact; blob contents as the single-frame path (f64 arithmetic, one f32 rounding); boxes bit-exact on the
+    maps the GPU produced, in frame coordinates."""
+    batch = stride * stride + 1
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(batch, 160, 192, 2))
+    spec = NetSpec(msg, "TEST"); spec.infer()
+    params = fill_params(spec, seed=3)
+    rng = np.random.default_rng(h + stride)
+    params["cvg/classifier"][1][...] = 1.5
+    params["bbox/regressor"][0][...] = 0
+    params["bbox/regressor"][1][...] = np.tile(np.array([-30, -25, 35, 40], np.float32), 2) + rng.normal(0, 0.5, 8).astype(np.float32)
+    eng = Engine(NetSpec(msg, "TEST"), params=params, device=0, autotune=False)
+    det = FCNObjectDetector(eng, 0.5, 3, 0.2, HeadMapping.detectnet_deploy())
+    frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rects, res = det.run_detector2(frame, stride)
+    want, rrects = D.run_detector2_inputs(frame, 192, 160, stride)
+    assert np.array_equal(rects, np.asarray(rrects, dtype=np.int32))
+    assert np.abs(eng.read_blob("data") - want).max() <= 4e-6
+    cvg, bb = eng.read_blob("coverage"), eng.read_blob("bboxes")
+    total = 0
+    for i, (boxes, labels) in enumerate(res):
+        rdet, rlab = D.detect(cvg[i], bb[i], 192, 160, 16, 0.5, 3, 0.2, fast=True)
+        assert np.array_equal(boxes, D.window_boxes_to_frame(rrects[i], rdet, 192, 160)) and np.array_equal(labels, rlab), i
+        total += len(boxes)
+    assert total > 0
+    with pytest.raises(ValueError):
+        det.run_detector2(frame, stride + 1)                  # window count != the engine's batch
+    eng.close()
+
+
+def test_roi_preprocessing_refuses_windows_outside_the_frame(gpu):
+    lib = L.load()
+    L.call("fcn_init", 0)
+    frame, dst, mm = DeviceBuffer(64 * 48 * 3), DeviceBuffer(2 * 32 * 32 * 4 * 4), DeviceBuffer(32)
+    for bad in ([0, 0, 65, 10], [-1, 0, 10, 10], [10, 40, 10, 9], [0, 0, 0, 5]):
+        rois = np.asarray([[0, 0, 64, 48], bad], np.int32)
+        assert lib.fcn_preprocess_bgr8_rois(frame.ptr, 48, 64, rois.ctypes.data, 2, dst.ptr, 0, 32, 32, 4, 0.0, mm.ptr, None) == 1      # FCN_E_ARG
+    too_many = np.tile(np.asarray([[0, 0, 8, 8]], np.int32), (33, 1))
+    assert lib.fcn_preprocess_bgr8_rois(frame.ptr, 48, 64, too_many.ctypes.data, 33, dst.ptr, 0, 32, 32, 4, 0.0, mm.ptr, None) == 1      # FCN_E_ARG

@@ -279,3 +279,24 @@ def test_c_lrn_equals_numpy(monkeypatch, c, n, alpha, beta):
     ry, rsc = R.lrn_across(x, n, alpha, beta, 1.0, return_scale=True)
     assert np.array_equal(sc, rsc) and np.array_equal(y, ry)      # same additions in the same order, no fused multiply-add; numpy's power
     assert np.allclose(y_only, ry, rtol=3e-7, atol=0)             # TEST phase: powf against numpy's float32 power, a last-bit difference at most
+
+
+def test_detection_window_geometry_by_hand():
+    """detection_window_roi (fcn_object_detector.py:257-277): oracle restatement == the product's host mirror == the rectangles
+    worked out by hand for a 480 x 640 frame, and for odd sizes (Python-2 integer division)."""
+    from fcn_object_detector_amd.detector import detection_window_roi
+    from oracle import detect_ref as D
+    frame = np.random.default_rng(1).integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    rois, rects = D.detection_window_roi(D.demean_rgb_image(frame), (32, 24), 2)
+    assert [tuple(int(v) for v in r) for r in rects] == [(0, 0, 320, 240), (320, 0, 320, 240), (0, 240, 320, 240), (320, 240, 320, 240),
+                                                         (160, 120, 320, 240)]
+    assert all(r.shape == (3, 24, 32) for r in rois)
+    assert np.array_equal(detection_window_roi(frame.shape, 2), np.asarray(rects, np.int32))
+    # the node calls it with stride 1: the whole frame twice (the central crop of a full-size window starts at 0)
+    assert detection_window_roi((301, 517, 3), 1).tolist() == [[0, 0, 517, 301], [0, 0, 517, 301]]
+    assert detection_window_roi((301, 517, 3), 2).tolist()[-1] == [517 // 2 - 258 // 2, 301 // 2 - 150 // 2, 258, 150]
+    with pytest.raises(ValueError):
+        detection_window_roi((1, 5, 3), 2)
+    # a window's boxes in frame coordinates: scaled by window / net size (truncating), moved by the window's origin
+    b = D.window_boxes_to_frame((160, 120, 320, 240), np.array([[10, 20, 100, 80, 2]]), 192, 160)
+    assert b.tolist() == [[160 + int(10 * 320 / 192), 120 + int(20 * 240 / 160), 160 + int(100 * 320 / 192), 120 + int(80 * 240 / 160), 2]]
