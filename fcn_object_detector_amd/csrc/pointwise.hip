@@ -482,7 +482,7 @@ constexpr int kP3LdsBytes = ((kP3MaxTH + 2) * (kP3MaxTW + 2) * 128 + 1023) / 102
 
 __global__ __launch_bounds__(256) void maxpool3s1_f16_lds_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int H, int W, int C, int x_cstride,
                                                                  int y_cstride, int y_coffset, int cgroups, int TH, int TW) {
-    __shared__ __attribute__((aligned(16))) char patch[kP3LdsBytes];
+    extern __shared__ __attribute__((aligned(16))) char patch[];      // (TH + 2) x (TW + 2) pixels in whole 1 KiB pieces: sized by the launch
     typedef const void __attribute__((address_space(1))) * gptr;
     typedef void __attribute__((address_space(3))) * lptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -525,8 +525,38 @@ __global__ __launch_bounds__(256) void maxpool3s1_f16_lds_kernel(const _Float16*
 }
 
 // LRN across channels, local_size 5: the window of 8 channels lives in the 24 halves c-8..c+15 of the pixel
-// LRN of the 8 channels in `c` given their neighbour groups (zeros outside the blob), f32 arithmetic, one rounding to half
+// LRN of the 8 channels in `c` given their neighbour groups (zeros outside the blob), f32 arithmetic, one rounding to half.
+// Round 3: at batch 32 the two LRN layers are bound by the vector ALU, not by HBM (77 M elements at ~20 instructions each), so the
+// arithmetic is trimmed: the window sums come from v_dot2_f32_f16 (exact products, f32 accumulation; pair sums P are shared between
+// neighbouring windows: 27 instructions per 8 channels instead of 56), the scale is one fma, and B075 (beta == 0.75, every LRN layer
+// of the reference's nets: models/deploy.prototxt:66-75,127-136) is a template argument - the general powf expansion used to sit in
+// the middle of the unrolled loop (a 60 KB kernel, jumped over 64 times per workgroup).  A window sum differs from the plain
+// left-to-right f32 sum in its last bit at most: far below the half ulp the result is rounded to.
+#ifndef FCN_LRN_DOT2
+#define FCN_LRN_DOT2 1
+#endif
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+template <bool B075>
 __device__ __forceinline__ h8_t lrn5_h8(const h8_t l, const h8_t c, const h8_t r, float alpha_over_n, float beta, float kk) {
+    float S[8];      // sum of squares over channels e-2 .. e+2
+#if FCN_LRN_DOT2
+    const _Float16 z = (_Float16)0.f;
+    const h2_t l3 = {l[6], l[7]}, c0 = {c[0], c[1]}, c1 = {c[2], c[3]}, c2 = {c[4], c[5]}, c3 = {c[6], c[7]}, r0 = {r[0], r[1]};
+    auto lo = [&](const h2_t p) __attribute__((always_inline)) { return h2_t{p[0], z}; };
+    auto hi = [&](const h2_t p) __attribute__((always_inline)) { return h2_t{z, p[1]}; };
+    const float Pl = __builtin_amdgcn_fdot2(l3, l3, 0.f, false), P0 = __builtin_amdgcn_fdot2(c0, c0, 0.f, false),
+                P1 = __builtin_amdgcn_fdot2(c1, c1, 0.f, false), P2 = __builtin_amdgcn_fdot2(c2, c2, 0.f, false),
+                P3 = __builtin_amdgcn_fdot2(c3, c3, 0.f, false), Pr = __builtin_amdgcn_fdot2(r0, r0, 0.f, false);
+    const float Tl0 = Pl + P0, T01 = P0 + P1, T12 = P1 + P2, T23 = P2 + P3, T3r = P3 + Pr;
+    S[0] = __builtin_amdgcn_fdot2(c1, lo(c1), Tl0, false);      // l6 l7 c0 c1 | c2
+    S[1] = __builtin_amdgcn_fdot2(l3, hi(l3), T01, false);      // l7 | c0 c1 c2 c3
+    S[2] = __builtin_amdgcn_fdot2(c2, lo(c2), T01, false);      // c0 c1 c2 c3 | c4
+    S[3] = __builtin_amdgcn_fdot2(c0, hi(c0), T12, false);      // c1 | c2 c3 c4 c5
+    S[4] = __builtin_amdgcn_fdot2(c3, lo(c3), T12, false);      // c2 c3 c4 c5 | c6
+    S[5] = __builtin_amdgcn_fdot2(c1, hi(c1), T23, false);      // c3 | c4 c5 c6 c7
+    S[6] = __builtin_amdgcn_fdot2(r0, lo(r0), T23, false);      // c4 c5 c6 c7 | r0
+    S[7] = __builtin_amdgcn_fdot2(c2, hi(c2), T3r, false);      // c5 | c6 c7 r0 r1
+#else
     float q[12];      // squares of channels c-2 .. c+9
     q[0] = (float)l[6] * (float)l[6];
     q[1] = (float)l[7] * (float)l[7];
@@ -534,15 +564,26 @@ __device__ __forceinline__ h8_t lrn5_h8(const h8_t l, const h8_t c, const h8_t r
     for (int e = 0; e < 8; ++e) q[2 + e] = (float)c[e] * (float)c[e];
     q[10] = (float)r[0] * (float)r[0];
     q[11] = (float)r[1] * (float)r[1];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) S[e] = q[e] + q[e + 1] + q[e + 2] + q[e + 3] + q[e + 4];
+#endif
     h8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float s = kk + alpha_over_n * (q[e] + q[e + 1] + q[e + 2] + q[e + 3] + q[e + 4]);
-        o[e] = (_Float16)((float)c[e] * pow_neg_beta_fast(s, beta));
+        const float sc = __builtin_fmaf(alpha_over_n, S[e], kk);
+        float f;
+        if (B075) {
+            const float rs = __builtin_amdgcn_rsqf(sc);      // sc^-0.75 = sc^-0.5 * sqrt(sc^-0.5), both 1 ulp of f32
+            f = rs * __builtin_amdgcn_sqrtf(rs);
+        } else {
+            f = powf(sc, -beta);
+        }
+        o[e] = (_Float16)((float)c[e] * f);
     }
     return o;
 }
 
+template <bool B075>
 __global__ __launch_bounds__(256) void lrn5_f16_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, long long pixels, int C,
                                                        int x_cstride, int y_cstride, float alpha_over_n, float beta, float kk) {
     const int cg = C / 8;
@@ -557,7 +598,7 @@ __global__ __launch_bounds__(256) void lrn5_f16_kernel(const _Float16* __restric
         for (int e = 0; e < 8; ++e) l[e] = r[e] = (_Float16)0.f;
         if (g > 0) l = *(const h8_t*)(xp - 8);
         if (g + 1 < cg) r = *(const h8_t*)(xp + 8);
-        *(h8_t*)(y + (size_t)pix * y_cstride + g * 8) = lrn5_h8(l, c, r, alpha_over_n, beta, kk);
+        *(h8_t*)(y + (size_t)pix * y_cstride + g * 8) = lrn5_h8<B075>(l, c, r, alpha_over_n, beta, kk);
     }
 }
 
@@ -570,7 +611,7 @@ __device__ __forceinline__ h8_t max8(const h8_t a, const h8_t b) {
     return m;
 }
 
-template <bool LRN_FIRST>
+template <bool LRN_FIRST, bool B075>
 __global__ __launch_bounds__(512) void maxpool_lrn5_f16_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int H, int W, int C,
                                                                int x_cstride, int k, int stride, int pad, int OH, int OW, int y_cstride,
                                                                int cgroups, float alpha_over_n, float beta, float kk) {
@@ -599,14 +640,14 @@ __global__ __launch_bounds__(512) void maxpool_lrn5_f16_kernel(const _Float16* _
             const h8_t l = hl ? *(const h8_t*)(xp - 8) : zero;
             const h8_t r = hr ? *(const h8_t*)(xp + 8) : zero;
             if (LRN_FIRST) {
-                m = max8(m, lrn5_h8(l, c, r, alpha_over_n, beta, kk));
+                m = max8(m, lrn5_h8<B075>(l, c, r, alpha_over_n, beta, kk));
             } else {
                 m = max8(m, c);
                 if (hl) ml = max8(ml, l);
                 if (hr) mr = max8(mr, r);
             }
         }
-    if (!LRN_FIRST) m = lrn5_h8(ml, m, mr, alpha_over_n, beta, kk);
+    if (!LRN_FIRST) m = lrn5_h8<B075>(ml, m, mr, alpha_over_n, beta, kk);
     *(h8_t*)(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + g * 8) = m;
 }
 
@@ -621,12 +662,14 @@ __global__ __launch_bounds__(512) void maxpool_lrn5_f16_kernel(const _Float16* _
 // Measured at batch 32: pool1 + norm1 73 -> 69 us, norm2 + pool2 105 -> 92 us: the LRN arithmetic (two hardware square roots per
 // element) is what bounds both forms - the fused one saves the blob's round trip but serialises stage / normalise / pool per workgroup.
 constexpr int kPL_TH = 4;
-constexpr int kPLLdsBytes = 80 * 1024;
+constexpr int kPLLdsBytes = 64 * 1024;      // (dynamic LDS: what a launch may ask for without a function attribute)
 
-template <bool LRN_FIRST>
+template <bool LRN_FIRST, bool B075>
 __global__ __launch_bounds__(512) void pool_lrn5_f16_lds_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int H, int W, int C, int x_cstride,
                                                                 int OH, int OW, int y_cstride, int TW, float alpha_over_n, float beta, float kk) {
-    __shared__ __attribute__((aligned(16))) char lds[kPLLdsBytes];
+    // (sized by the launch: patch + pooled tile rounded up to the 1 KiB staging pieces - a fixed 80 KiB held a CU to two workgroups,
+    //  and a workgroup stages, waits, normalises and pools one step after the other: what hides the wait is the workgroups beside it)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
     typedef const void __attribute__((address_space(1))) * gptr;
     typedef void __attribute__((address_space(3))) * lptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -654,7 +697,7 @@ __global__ __launch_bounds__(512) void pool_lrn5_f16_lds_kernel(const _Float16* 
         const h8_t c = *reinterpret_cast<const h8_t*>(base + sg * 16);
         const h8_t l = sg > 0 ? *reinterpret_cast<const h8_t*>(base + sg * 16 - 16) : zero;
         const h8_t r = sg + 1 < segs ? *reinterpret_cast<const h8_t*>(base + sg * 16 + 16) : zero;
-        return lrn5_h8(l, c, r, alpha_over_n, beta, kk);
+        return lrn5_h8<B075>(l, c, r, alpha_over_n, beta, kk);
     };
     if (LRN_FIRST) {      // normalise the patch in place: all results first (they read their neighbours' raw values), then all writes
         constexpr int MAXI = 8;
@@ -899,8 +942,9 @@ int fcn_maxpool_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int 
         // tile extents that divide the image where they can (28 = 4 x 7 rows of 28 columns; 56 = 7 x 8 rows of 2 x 28 columns)
         const int TW = W % 32 == 0 ? 32 : W % 28 == 0 ? 28 : W % 24 == 0 ? 24 : W < 32 ? W : 32;
         const int TH = H % 8 == 0 ? 8 : H % 7 == 0 ? 7 : 8;
-        hipLaunchKernelGGL(maxpool3s1_f16_lds_kernel, dim3((unsigned)(cgroups * cdiv(W, TW)), cdiv(H, TH), N), dim3(256), 0, as_stream(s), xh, yh, H, W, C,
-                           x_cstride, y_cstride, y_coffset, cgroups, TH, TW);
+        const unsigned p3_bytes = (unsigned)(((TH + 2) * (TW + 2) * 128 + 1023) / 1024 * 1024);      // (<= kP3LdsBytes)
+        hipLaunchKernelGGL(maxpool3s1_f16_lds_kernel, dim3((unsigned)(cgroups * cdiv(W, TW)), cdiv(H, TH), N), dim3(256), p3_bytes, as_stream(s), xh, yh, H, W,
+                           C, x_cstride, y_cstride, y_coffset, cgroups, TH, TW);
         FCN_LAUNCH_CHECK("maxpool3s1_f16_lds");
         return 0;
     }
@@ -933,26 +977,38 @@ int fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C,
     const float aon = alpha / 5.f;
     {   // large blobs, 3x3 / stride 2 without padding: the LDS-patch kernel (all channels of a pixel in one workgroup)
         static const bool lds_ok = !(getenv("FCN_POOL_LDS") && atoi(getenv("FCN_POOL_LDS")) == 0);
-        const int TW = C <= 96 ? 16 : 8;
+        // (192 channels: 7 columns make a 52 KiB patch - three workgroups per CU where 8 columns (58 KiB) leave room for two)
+        const int TW = C <= 96 ? 16 : (OW % 7 == 0 && getenv("FCN_PL_TW8") == nullptr) ? 7 : 8;
         const long long patch = (long long)(2 * kPL_TH + 1) * (2 * TW + 1) * C * 2 + (lrn_first ? 0 : (long long)kPL_TH * TW * C * 2);
         const long long items = (long long)(2 * kPL_TH + 1) * (2 * TW + 1) * (C / 8);
         if (lds_ok && k == 3 && stride == 2 && pad == 0 && patch + 1024 <= kPLLdsBytes && items <= 8 * 512 && (long long)N * H * W * C >= (1 << 22) &&
             cdiv(OH, kPL_TH) <= 65535) {
             const dim3 g2(cdiv(OW, TW), cdiv(OH, kPL_TH), N);
-            if (lrn_first)
-                hipLaunchKernelGGL(pool_lrn5_f16_lds_kernel<true>, g2, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, OH, OW, y_cstride, TW, aon, beta, lrn_k);
-            else
-                hipLaunchKernelGGL(pool_lrn5_f16_lds_kernel<false>, g2, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, OH, OW, y_cstride, TW, aon, beta, lrn_k);
+            // staging writes whole 1 KiB pieces: the patch is rounded up to them, the pooled tile sits behind the patch's own bytes
+            const long long staged = (items + 63) / 64 * 1024;
+            const long long need = lrn_first ? staged : std::max(staged, (long long)(2 * kPL_TH + 1) * (2 * TW + 1) * C * 2 + (long long)kPL_TH * TW * C * 2);
+            const unsigned lds_bytes = (unsigned)((need + 1023) / 1024 * 1024);
+            const bool b075 = beta == 0.75f;
+#define FCN_PL_LAUNCH(F, B)                                                                                                             \
+    hipLaunchKernelGGL((pool_lrn5_f16_lds_kernel<F, B>), g2, dim3(512), lds_bytes, as_stream(s), xh, yh, H, W, C, x_cstride, OH, OW, y_cstride, \
+                       TW, aon, beta, lrn_k)
+            if (lrn_first && b075) FCN_PL_LAUNCH(true, true);
+            else if (lrn_first) FCN_PL_LAUNCH(true, false);
+            else if (b075) FCN_PL_LAUNCH(false, true);
+            else FCN_PL_LAUNCH(false, false);
+#undef FCN_PL_LAUNCH
             FCN_LAUNCH_CHECK("pool_lrn5_f16_lds");
             return 0;
         }
     }
-    if (lrn_first)
-        hipLaunchKernelGGL(maxpool_lrn5_f16_kernel<true>, grid, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
-                           cgroups, aon, beta, lrn_k);
-    else
-        hipLaunchKernelGGL(maxpool_lrn5_f16_kernel<false>, grid, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
-                           cgroups, aon, beta, lrn_k);
+#define FCN_ML_LAUNCH(F, B)                                                                                                                        \
+    hipLaunchKernelGGL((maxpool_lrn5_f16_kernel<F, B>), grid, dim3(512), 0, as_stream(s), xh, yh, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride, \
+                       cgroups, aon, beta, lrn_k)
+    if (lrn_first && beta == 0.75f) FCN_ML_LAUNCH(true, true);
+    else if (lrn_first) FCN_ML_LAUNCH(true, false);
+    else if (beta == 0.75f) FCN_ML_LAUNCH(false, true);
+    else FCN_ML_LAUNCH(false, false);
+#undef FCN_ML_LAUNCH
     FCN_LAUNCH_CHECK("maxpool_lrn5_f16");
     return 0;
 }
@@ -963,9 +1019,13 @@ int fcn_lrn_fwd_f16(const void* x, void* y, int pixels, int C, int x_cstride, in
     FCN_REQUIRE(local_size == 5, FCN_E_UNSUPPORTED, "lrn_f16: local_size %d (the reference nets use 5)", local_size);
     FCN_REQUIRE(C % 8 == 0 && x_cstride % 8 == 0 && y_cstride % 8 == 0 && x_cstride >= C && y_cstride >= C && aligned16(x) && aligned16(y),
                 FCN_E_ALIGN, "lrn_f16: channels / strides must be multiples of 8");
-    hipLaunchKernelGGL(lrn5_f16_kernel, dim3(stream_grid((long long)pixels * (C / 8), 256)), dim3(256), 0, as_stream(s),
-                       reinterpret_cast<const _Float16*>(x), reinterpret_cast<_Float16*>(y), (long long)pixels, C, x_cstride, y_cstride,
-                       alpha / (float)local_size, beta, k);
+    const dim3 lgrid(stream_grid((long long)pixels * (C / 8), 256));
+    if (beta == 0.75f)
+        hipLaunchKernelGGL(lrn5_f16_kernel<true>, lgrid, dim3(256), 0, as_stream(s), reinterpret_cast<const _Float16*>(x), reinterpret_cast<_Float16*>(y),
+                           (long long)pixels, C, x_cstride, y_cstride, alpha / (float)local_size, beta, k);
+    else
+        hipLaunchKernelGGL(lrn5_f16_kernel<false>, lgrid, dim3(256), 0, as_stream(s), reinterpret_cast<const _Float16*>(x), reinterpret_cast<_Float16*>(y),
+                           (long long)pixels, C, x_cstride, y_cstride, alpha / (float)local_size, beta, k);
     FCN_LAUNCH_CHECK("lrn_f16");
     return 0;
 }
