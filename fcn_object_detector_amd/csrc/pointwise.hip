@@ -661,24 +661,25 @@ __global__ __launch_bounds__(512) void maxpool_lrn5_f16_kernel(const _Float16* _
 // half-way point between two halves (tests/test_gpu_f16.py: 2e-5 of the elements, one f16 ulp).
 // Measured at batch 32: pool1 + norm1 73 -> 69 us, norm2 + pool2 105 -> 92 us: the LRN arithmetic (two hardware square roots per
 // element) is what bounds both forms - the fused one saves the blob's round trip but serialises stage / normalise / pool per workgroup.
-constexpr int kPL_TH = 4;
+constexpr int kPL_TH = 4;      // output rows per workgroup (the default; FCN_PL_TH / FCN_PL_NT: experiments)
 constexpr int kPLLdsBytes = 64 * 1024;      // (dynamic LDS: what a launch may ask for without a function attribute)
 
 template <bool LRN_FIRST, bool B075>
 __global__ __launch_bounds__(512) void pool_lrn5_f16_lds_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int H, int W, int C, int x_cstride,
-                                                                int OH, int OW, int y_cstride, int TW, float alpha_over_n, float beta, float kk) {
+                                                                int OH, int OW, int y_cstride, int TW, int TH, float alpha_over_n, float beta, float kk) {
     // (sized by the launch: patch + pooled tile rounded up to the 1 KiB staging pieces - a fixed 80 KiB held a CU to two workgroups,
     //  and a workgroup stages, waits, normalises and pools one step after the other: what hides the wait is the workgroups beside it)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     typedef const void __attribute__((address_space(1))) * gptr;
     typedef void __attribute__((address_space(3))) * lptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NT = (int)blockDim.x, nwaves = NT >> 6;      // 256 or 512 threads
     const int segs = C / 8, pitch = C * 2;                        // 16-byte segments / bytes per pixel
-    const int oy0 = (int)blockIdx.y * kPL_TH, ox0 = (int)blockIdx.x * TW, n = (int)blockIdx.z;
-    const int PWp = 2 * TW + 1, PH = 2 * kPL_TH + 1, npix = PH * PWp, nitems = npix * segs;
+    const int oy0 = (int)blockIdx.y * TH, ox0 = (int)blockIdx.x * TW, n = (int)blockIdx.z;
+    const int PWp = 2 * TW + 1, PH = 2 * TH + 1, npix = PH * PWp, nitems = npix * segs;
     const _Float16* xn = x + (size_t)n * H * W * x_cstride;
     // ---- stage the patch: item g = (pixel, segment) in patch order, 64 items (1 KiB) per wave-instruction
-    for (int i = wave; i * 64 < nitems; i += 8) {
+    for (int i = wave; i * 64 < nitems; i += nwaves) {
         int g = i * 64 + lane;
         g = g < nitems ? g : nitems - 1;
         const int p = g / segs, sg = g - p * segs;
@@ -704,21 +705,21 @@ __global__ __launch_bounds__(512) void pool_lrn5_f16_lds_kernel(const _Float16* 
         h8_t res[MAXI];
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) {
-            const int g = tid + 512 * j;
+            const int g = tid + NT * j;
             if (g < nitems) res[j] = lrn_at(lds + (g / segs) * pitch, g % segs);
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) {
-            const int g = tid + 512 * j;
+            const int g = tid + NT * j;
             if (g < nitems) *reinterpret_cast<h8_t*>(lds + (size_t)g * 16) = res[j];
         }
         __syncthreads();
     }
     // ---- pool: item = (output pixel of the tile, segment)
-    const int nout = kPL_TH * TW * segs;
+    const int nout = TH * TW * segs;
     char* const pooled = lds + (size_t)npix * pitch;              // (pool first: the pooled tile, normalised in a second step)
-    for (int g = tid; g < nout; g += 512) {
+    for (int g = tid; g < nout; g += NT) {
         const int op = g / segs, sg = g - op * segs;
         const int oyl = op / TW, oxl = op - oyl * TW;
         const char* w0 = lds + ((2 * oyl) * PWp + 2 * oxl) * pitch + sg * 16;
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(512) void pool_lrn5_f16_lds_kernel(const _Float16* 
     }
     if (!LRN_FIRST) {
         __syncthreads();
-        for (int g = tid; g < nout; g += 512) {
+        for (int g = tid; g < nout; g += NT) {
             const int op = g / segs, sg = g - op * segs;
             const int oy = oy0 + op / TW, ox = ox0 + op % TW;
             if (oy < OH && ox < OW)
@@ -979,19 +980,21 @@ int fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C,
         static const bool lds_ok = !(getenv("FCN_POOL_LDS") && atoi(getenv("FCN_POOL_LDS")) == 0);
         // (192 channels: 7 columns make a 52 KiB patch - three workgroups per CU where 8 columns (58 KiB) leave room for two)
         const int TW = C <= 96 ? 16 : (OW % 7 == 0 && getenv("FCN_PL_TW8") == nullptr) ? 7 : 8;
-        const long long patch = (long long)(2 * kPL_TH + 1) * (2 * TW + 1) * C * 2 + (lrn_first ? 0 : (long long)kPL_TH * TW * C * 2);
-        const long long items = (long long)(2 * kPL_TH + 1) * (2 * TW + 1) * (C / 8);
-        if (lds_ok && k == 3 && stride == 2 && pad == 0 && patch + 1024 <= kPLLdsBytes && items <= 8 * 512 && (long long)N * H * W * C >= (1 << 22) &&
-            cdiv(OH, kPL_TH) <= 65535) {
-            const dim3 g2(cdiv(OW, TW), cdiv(OH, kPL_TH), N);
+        static const int th_env = getenv("FCN_PL_TH") ? atoi(getenv("FCN_PL_TH")) : 0, nt_env = getenv("FCN_PL_NT") ? atoi(getenv("FCN_PL_NT")) : 0;
+        const int TH = th_env >= 1 && th_env <= 8 ? th_env : kPL_TH, NT = nt_env == 256 ? 256 : 512;
+        const long long patch = (long long)(2 * TH + 1) * (2 * TW + 1) * C * 2 + (lrn_first ? 0 : (long long)TH * TW * C * 2);
+        const long long items = (long long)(2 * TH + 1) * (2 * TW + 1) * (C / 8);
+        if (lds_ok && k == 3 && stride == 2 && pad == 0 && patch + 1024 <= kPLLdsBytes && items <= 8 * NT && (long long)N * H * W * C >= (1 << 22) &&
+            cdiv(OH, TH) <= 65535) {
+            const dim3 g2(cdiv(OW, TW), cdiv(OH, TH), N);
             // staging writes whole 1 KiB pieces: the patch is rounded up to them, the pooled tile sits behind the patch's own bytes
             const long long staged = (items + 63) / 64 * 1024;
-            const long long need = lrn_first ? staged : std::max(staged, (long long)(2 * kPL_TH + 1) * (2 * TW + 1) * C * 2 + (long long)kPL_TH * TW * C * 2);
+            const long long need = lrn_first ? staged : std::max(staged, (long long)(2 * TH + 1) * (2 * TW + 1) * C * 2 + (long long)TH * TW * C * 2);
             const unsigned lds_bytes = (unsigned)((need + 1023) / 1024 * 1024);
             const bool b075 = beta == 0.75f;
 #define FCN_PL_LAUNCH(F, B)                                                                                                             \
-    hipLaunchKernelGGL((pool_lrn5_f16_lds_kernel<F, B>), g2, dim3(512), lds_bytes, as_stream(s), xh, yh, H, W, C, x_cstride, OH, OW, y_cstride, \
-                       TW, aon, beta, lrn_k)
+    hipLaunchKernelGGL((pool_lrn5_f16_lds_kernel<F, B>), g2, dim3(NT), lds_bytes, as_stream(s), xh, yh, H, W, C, x_cstride, OH, OW, y_cstride, \
+                       TW, TH, aon, beta, lrn_k)
             if (lrn_first && b075) FCN_PL_LAUNCH(true, true);
             else if (lrn_first) FCN_PL_LAUNCH(true, false);
             else if (b075) FCN_PL_LAUNCH(false, true);
