@@ -1454,7 +1454,14 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
             q.tiles_n_magic = q.tiles_n > 1 ? (unsigned)(((1ull << 32) + q.tiles_n - 1) / q.tiles_n) : 0u;
             total += q.tiles_m * q.tiles_n;
             q.tile_end = total;
-            q.lean_chunks = q.kh * q.kw * cdiv(q.Cin, 64);
+            // Packed taps (conv_stream.hip): a 5x5 / 3x3 filter row over a dense 16- or 32-channel blob runs 4 / 2 taps per 64-wide
+            // chunk instead of one tap that is 75 / 50 % padding - lean_chunks carries log2(taps per chunk) for this kernel.  Only
+            // where a slab still serves two chunks or more (the single-chunk protocol is the 1x1 one: three slab buffers).
+            static const bool pack_ok = !(getenv("FCN_STREAM_PACK") && atoi(getenv("FCN_STREAM_PACK")) == 0);
+            int tsh = 0;
+            if (pack_ok && k > 1 && q.x_cstride == q.Cin && ((uintptr_t)q.x & 15) == 0) tsh = q.Cin == 16 ? 2 : q.Cin == 32 ? 1 : 0;
+            if (tsh && cdiv(k, 1 << tsh) < 2) tsh = 0;
+            q.lean_chunks = tsh;
             q.cin_magic24 = (unsigned)(((1ull << 32) + pw - 1) / pw);      // (stream problems: entry / PW of the padded raster)
         }
         return total;

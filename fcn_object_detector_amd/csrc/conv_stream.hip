@@ -153,9 +153,9 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         if (tile < total) {
             int pi, begin;
             find_problem(tile, pi, begin);
-            const int kh = ka->p[pi].kh, kw = ka->p[pi].kw, cin = ka->p[pi].Cin;
-            w.kw = kw;
-            w.mac_left = kh * ((cin + kChunkK - 1) / kChunkK);
+            const int kh = ka->p[pi].kh, kw = ka->p[pi].kw, cin = ka->p[pi].Cin, tsh = ka->p[pi].lean_chunks;
+            w.kw = (kw + (1 << tsh) - 1) >> tsh;      // chunks per slab: one per tap, or one per 2 / 4 taps of a narrow input (packed taps)
+            w.mac_left = tsh ? kh : kh * ((cin + kChunkK - 1) / kChunkK);
         }
     };
     auto walk_step = [&](Walk& w) __attribute__((always_inline)) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         const int lane_c = lseg * 8;
         char* const lds_wave = smem + WRING0 + wb * 1024;
         int b_vo[NPB];
-        int ti = v, r = 0, cc = 0, q = 0, kh = 1, kw = 1, ncc = 1, cin = 0;
+        int ti = v, r = 0, cc = 0, q = 0, kh = 1, kw = 1, ncc = 1, cin = 0, tsh = 0, cps = 1;
         bool live = true;
         const f16_t* pw = nullptr;
         int w_bytes = 0, cur_pi = -1, p_cout = 0, p_K = 0, p_tiles_n = 1;
@@ -190,7 +190,9 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 pw = reinterpret_cast<const f16_t*>(p.w);
                 w_bytes = p.Cout * p.K * 2;
                 kh = p.kh; kw = p.kw; cin = p.Cin;
-                ncc = (p.Cin + kChunkK - 1) / kChunkK;
+                tsh = p.lean_chunks;                      // packed taps (plan_tiles_cfg): a chunk's 64 k are 2 / 4 taps x Cin = 32 / 16 channels,
+                cps = (p.kw + (1 << tsh) - 1) >> tsh;     // contiguous in the OHWI bank; the last chunk of a filter row may hold fewer taps
+                ncc = tsh ? 1 : (p.Cin + kChunkK - 1) / kChunkK;
                 p_cout = p.Cout; p_K = p.K; p_tiles_n = p.tiles_n; p_tiles_n_magic = p.tiles_n_magic;
             }
             const int lt = ti - begin;
@@ -205,8 +207,9 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         };
         auto issue_chunk = [&](const int slot) __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(pw), 0, w_bytes, 0x00020000);
-            const int soff = ((r * kw + q) * cin + cc * kChunkK) * 2;
-            const bool cvalid = live && lane_c < cin - cc * kChunkK;      // (the last chunk of a tap may cover fewer than 64 channels)
+            const int soff = ((r * kw + (q << tsh)) * cin + cc * kChunkK) * 2;
+            // (the last chunk of a tap may cover fewer than 64 channels; the last chunk of a packed filter row fewer taps)
+            const bool cvalid = live && lane_c < (tsh ? min(1 << tsh, kw - (q << tsh)) * cin : cin - cc * kChunkK);
             char* const dst = lds_wave + slot * WCH;
 #pragma unroll
             for (int t = 0; t < NPB; ++t) {
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
 #endif
             }
             if (live) {      // next chunk: taps of the row, then channel chunks, then filter rows, then the next tile
-                if (++q == kw) {
+                if (++q == cps) {
                     q = 0;
                     if (++cc == ncc) {
                         cc = 0;
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         // what the loader keeps of a problem
         struct SlabP {
             const f16_t* px;
-            int x_bytes, H, W, pad, kh, cin, ncc, row_bytes, xcs, PW, rows_total, tiles_n, pi;
+            int x_bytes, H, W, pad, kh, cin, ncc, row_bytes, xcs, PW, rows_total, tiles_n, pi, dpx;
             unsigned ow_magic, oh_magic, pw_magic, tiles_n_magic;
         };
         auto slab_problem = [&](const int pi) __attribute__((always_inline)) {
@@ -276,8 +279,15 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             SlabP q;
             q.px = reinterpret_cast<const f16_t*>(p.x);
             q.x_bytes = (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * 2);
-            q.H = p.H; q.W = p.W; q.pad = p.pad; q.kh = p.kh; q.cin = p.Cin;
-            q.ncc = (p.Cin + kChunkK - 1) / kChunkK;
+            q.H = p.H; q.W = p.W; q.pad = p.pad; q.kh = p.kh;
+            // Packed taps (x_cstride == Cin == 16 or 32, plan_tiles_cfg): the 128 bytes behind a pixel ARE the next 3 (1) pixels of its
+            // image row, so a slab row holds the channels of 4 (2) neighbouring padded-raster entries - four (two) taps of a filter row
+            // in one 64-wide chunk.  Same address as ever; a lane's segment just belongs to entry p + dpx and is tested against the
+            // image row with that offset (entries outside the image are the zero padding).
+            const int tsh = p.lean_chunks;
+            q.dpx = tsh ? lseg >> (3 - tsh) : 0;
+            q.cin = tsh ? kChunkK : p.Cin;
+            q.ncc = tsh ? 1 : (p.Cin + kChunkK - 1) / kChunkK;
             q.row_bytes = p.W * p.x_cstride * 2;
             q.xcs = p.x_cstride;
             q.PW = p.W + 2 * p.pad;
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 if (prep == sl) {      // (a scalar branch per slice: the register arrays are indexed statically inside it)
 #pragma unroll
                     for (int t = sl * kSlice; t < (sl + 1) * kSlice && t < NPA; ++t) {
-                        const bool okx = (unsigned)(w_xp - nxt.pad) < (unsigned)nxt.W && w_t1 < nxt.rows_total;
+                        const bool okx = (unsigned)(w_xp + nxt.dpx - nxt.pad) < (unsigned)nxt.W && w_t1 < nxt.rows_total;
                         const int lo = max(nxt.pad - w_y, 0), hi = min(nxt.H + nxt.pad - w_y, nxt.kh);      // filter rows whose input row exists
                         vmask_n[t] = (okx && hi > lo) ? (1 << hi) - (1 << lo) : 0;
                         off_n[t] = w_off;
@@ -497,7 +507,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         struct MulP {
             f16_t* y;
             const float* bias;
-            int M, Cout, y_cstride, y_coffset, relu, m0, n0, kw, nch, W, PW;
+            int M, Cout, y_cstride, y_coffset, relu, m0, n0, kw, nch, W, PW, tsh;
             unsigned ow_magic;
         };
         int mul_pi = -1, mul_tiles_n = 1;
@@ -513,8 +523,9 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 mul_const.bias = p.bias;
                 mul_const.M = p.M; mul_const.Cout = p.Cout; mul_const.y_cstride = p.y_cstride; mul_const.y_coffset = p.y_coffset;
                 mul_const.relu = p.flags & FCN_CONV_RELU;
-                mul_const.kw = p.kw;
-                mul_const.nch = p.kh * ((p.Cin + kChunkK - 1) / kChunkK) * p.kw;
+                mul_const.tsh = p.lean_chunks;                                   // packed taps: chunk q of a slab starts at tap q << tsh
+                mul_const.kw = (p.kw + (1 << p.lean_chunks) - 1) >> p.lean_chunks;      // chunks per slab
+                mul_const.nch = p.kh * (p.lean_chunks ? 1 : (p.Cin + kChunkK - 1) / kChunkK) * mul_const.kw;
                 mul_const.W = p.W; mul_const.PW = p.W + 2 * p.pad; mul_const.ow_magic = p.ow_magic;
                 mul_tiles_n = p.tiles_n; mul_tiles_n_magic = p.tiles_n_magic;
             }
@@ -665,7 +676,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 int rsel[WTM];
 #pragma unroll
                 for (int i = 0; i < WTM; ++i) rsel[i] = tile_end ? rho_nt[i] : rho[i];
-                chunk(ch == 0, rsel, qn, abuf_n);
+                chunk(ch == 0, rsel, qn << cur.tsh, abuf_n);
                 q = qn;
                 abuf = abuf_n;
             }

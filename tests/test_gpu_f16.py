@@ -141,6 +141,10 @@ def _run_stream_group(probs, cfg):
     (192, 16, 1, 0, 9, 11, 1),        # image rows of 11: refused
     (64, 64, 1, 0, 33, 31, 2),        # one chunk per tile (conv2/3x3_reduce): every chunk is a tile's first and last
     (128, 256, 3, 1, 56, 56, 1),      # image rows of 56: a tile covers 4.6 of them
+    (32, 96, 5, 2, 28, 28, 3),        # packed taps: two taps of a 32-channel blob per chunk (three chunks per filter row, the last one half empty)
+    (16, 48, 5, 2, 28, 28, 3),        # packed taps: four taps of a 16-channel blob per chunk (4 + 1), several tiles across images
+    (32, 64, 3, 1, 19, 23, 2),        # packed taps on a 3x3 filter (2 + 1 taps), odd image extents
+    (16, 24, 3, 1, 28, 28, 1),        # 3x3 on 16 channels would be ONE chunk per slab: stays unpacked (plan_tiles_cfg)
 ])
 def test_stream_kernel_matches_oracle(gpu, case, cfg):
     cin, cout, k, pad, h, w, n = case

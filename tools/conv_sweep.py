@@ -41,6 +41,15 @@ SHAPES = [
     ("k5760", [(640, 320, 3, 1, 1, 28, 28)]),
     # same K, 1x1 (no halo / tap logic): K = Cin
     ("p1440", [(1440, 320, 1, 0, 1, 28, 28)]),
+    # round 3: what the 5x5 convolutions on 16 / 32 channels cost inside their launches (a 64-channel chunk per tap is 75 / 50 % padding)
+    ("3a_5x5", [(16, 32, 5, 2, 1, 56, 56)]),
+    ("3a_B_no5", [(96, 128, 3, 1, 1, 56, 56), (192, 32, 1, 0, 1, 56, 56)]),
+    ("3b_5x5", [(32, 96, 5, 2, 1, 56, 56)]),
+    ("3b_B_no5", [(128, 192, 3, 1, 1, 56, 56), (256, 64, 1, 0, 1, 56, 56)]),
+    ("4a_5x5", [(16, 48, 5, 2, 1, 28, 28)]),
+    ("4a_B_no5", [(96, 208, 3, 1, 1, 28, 28), (480, 64, 1, 0, 1, 28, 28)]),
+    ("4e_B", [(160, 320, 3, 1, 1, 28, 28), (32, 128, 5, 2, 1, 28, 28)]),
+    ("4e_5x5", [(32, 128, 5, 2, 1, 28, 28)]),
 ]
 
 
