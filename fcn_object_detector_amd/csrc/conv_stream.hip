@@ -707,13 +707,16 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
 // configurations: X(index, WTN, slab pieces, slab buffers, weight slots)
 //   0/1: 3x3 and 5x5 launches (slabs of 304 rows, two buffers: a slab is needed kw >= 2 chunks after its issue)
 //   2/3: 1x1 launches (256-row slabs, three / four buffers)       4/5: mixed 1x1 + 3x3 launches (288-row slabs, three buffers)
+//   6: a whole inception level on 28-wide images - 3x3 + 5x5 + pool_proj in one launch (304-row slabs AND three buffers: 146 KiB
+//      with 64-channel tiles; the 128-channel form would need 162)
 #define FCN_STREAM_CONFIGS(X) \
     X(0, 2, 38, 2, 5)         \
     X(1, 1, 38, 2, 5)         \
     X(2, 2, 32, 3, 4)         \
     X(3, 1, 32, 4, 4)         \
     X(4, 2, 36, 3, 3)         \
-    X(5, 1, 36, 3, 4)
+    X(5, 1, 36, 3, 4)         \
+    X(6, 1, 38, 3, 4)
 
 constexpr StreamCfgInfo kStreamCfgs[] = {
 #define X(I, A, B, NA_, NB_) {kBM, SCfg<A, B, NA_, NB_>::BN, 32, SCfg<A, B, NA_, NB_>::LDS_BYTES, SCfg<A, B, NA_, NB_>::NT, B * 8, NA_},

@@ -51,9 +51,9 @@ def f16_conv(x, wt, b, pad, stride, flags, out_f32, y_cstride=None, y_coffset=0)
     return y
 
 
-STREAM_CFGS = [32, 33, 34, 35, 36, 37]      # conv_stream_f16: persistent workgroups, 256-pixel tiles x 128 / 64 channels
-# (slab rows, slab buffers) per configuration: 32/33 take 3x3 and 5x5 launches, 34/35 1x1 launches, 36/37 mixed 1x1 + 3x3
-_STREAM_SHAPE = {32: (304, 2), 33: (304, 2), 34: (256, 3), 35: (256, 4), 36: (288, 3), 37: (288, 3)}
+STREAM_CFGS = [32, 33, 34, 35, 36, 37, 38]      # conv_stream_f16: persistent workgroups, 256-pixel tiles x 128 / 64 channels
+# (slab rows, slab buffers) per configuration: 32/33 take 3x3 and 5x5 launches, 34/35 1x1 launches, 36/37 mixed 1x1 + 3x3, 38 all three
+_STREAM_SHAPE = {32: (304, 2), 33: (304, 2), 34: (256, 3), 35: (256, 4), 36: (288, 3), 37: (288, 3), 38: (304, 3)}
 
 
 @pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15", "23", "24", "26", "29"])
@@ -179,6 +179,12 @@ def test_stream_kernel_group_slices_and_flags(gpu, cfg):
     if _stream_takes(cfg, 3, w) and _stream_takes(cfg, 1, w):
         _run_stream_group([_stream_problem(rng, 96, 128, 3, 1, h, w, n, y_cstride=256, y_coffset=64),
                            _stream_problem(rng, 192, 32, 1, 0, h, w, n, y_cstride=256, y_coffset=224)], cfg)
+        ran += 1
+    if _stream_takes(cfg, 1, w) and _stream_takes(cfg, 3, w) and _stream_takes(cfg, 5, w):      # a whole inception level on 28-wide images
+        grp = _run_stream_group([_stream_problem(rng, 96, 208, 3, 1, h, w, n, y_cstride=320, y_coffset=0),
+                                 _stream_problem(rng, 16, 48, 5, 2, h, w, n, y_cstride=320, y_coffset=208),
+                                 _stream_problem(rng, 480, 64, 1, 0, h, w, n, y_cstride=320, y_coffset=256)], cfg)
+        assert grp.n == 3
         ran += 1
     assert ran >= 1
 
