@@ -67,13 +67,14 @@ constexpr bool getenv_free_noprio = true;
 #else
 constexpr bool getenv_free_noprio = false;
 #endif
-constexpr int kBM = 256;          // pixels per tile
 constexpr int kChunkK = 64;       // halves of K per chunk (128-byte LDS rows)
 
-template <int WTN_, int SRP_, int NA_, int NB_>
+template <int WTN_, int SRP_, int NA_, int NB_, int WTM_ = 4>
 struct SCfg {
     static constexpr int WTN = WTN_, SRP = SRP_, NA = NA_, NB = NB_;
-    static constexpr int WTM = 4, BM = kBM, BN = 64 * WTN;
+    static constexpr int WTM = WTM_, BM = 64 * WTM, BN = 64 * WTN;      // the multiplying waves form a 2 x 2 grid of (32 WTM) x (32 WTN) outputs
+    static_assert(WTM == 4 || WTM == 2, "pixel tiles of 256 or 128");
+    static_assert(WTN >= 1 && WTN <= 3, "weight fragments are read with up to three fixed offsets");
     static constexpr int NT = 512;
     static constexpr int NPA = SRP / 2;                 // slab pieces (1 KiB = 8 rows) per slab-loading wave
     static constexpr int NPB = BN / 16;                 // weight pieces per weight-loading wave and chunk
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             for (int j = 0; j < WTN; ++j) {
                 if (j == 0) ds_read(wf[par][0], aw, std::integral_constant<int, 0>{});
                 if (j == 1) ds_read(wf[par][WTN > 1 ? 1 : 0], aw, std::integral_constant<int, 32 * 128>{});
+                if (j == 2) ds_read(wf[par][WTN > 2 ? 2 : 0], aw, std::integral_constant<int, 64 * 128>{});
             }
         };
         auto read_x = [&](const int i, const int st) __attribute__((always_inline)) {
@@ -709,17 +711,22 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
 //   2/3: 1x1 launches (256-row slabs, three / four buffers)       4/5: mixed 1x1 + 3x3 launches (288-row slabs, three buffers)
 //   6: a whole inception level on 28-wide images - 3x3 + 5x5 + pool_proj in one launch (304-row slabs AND three buffers: 146 KiB
 //      with 64-channel tiles; the 128-channel form would need 162)
+//   7/8: 128 pixels x 192 channels (a wave multiplies 64 x 96: 96 accumulator registers) - for the layers with 192 / 384 output
+//      channels (conv2/3x3, inception_3b/3x3, inception_5b/3x3), where 128-channel tiles leave a quarter of their MFMAs on padding;
+//      7: 3x3 / 5x5 launches (160-row slabs, two buffers), 8: with 1x1 problems (three buffers)
 #define FCN_STREAM_CONFIGS(X) \
-    X(0, 2, 38, 2, 5)         \
-    X(1, 1, 38, 2, 5)         \
-    X(2, 2, 32, 3, 4)         \
-    X(3, 1, 32, 4, 4)         \
-    X(4, 2, 36, 3, 3)         \
-    X(5, 1, 36, 3, 4)         \
-    X(6, 1, 38, 3, 4)
+    X(0, 2, 38, 2, 5, 4)      \
+    X(1, 1, 38, 2, 5, 4)      \
+    X(2, 2, 32, 3, 4, 4)      \
+    X(3, 1, 32, 4, 4, 4)      \
+    X(4, 2, 36, 3, 3, 4)      \
+    X(5, 1, 36, 3, 4, 4)      \
+    X(6, 1, 38, 3, 4, 4)      \
+    X(7, 3, 20, 2, 5, 2)      \
+    X(8, 3, 20, 3, 4, 2)
 
 constexpr StreamCfgInfo kStreamCfgs[] = {
-#define X(I, A, B, NA_, NB_) {kBM, SCfg<A, B, NA_, NB_>::BN, 32, SCfg<A, B, NA_, NB_>::LDS_BYTES, SCfg<A, B, NA_, NB_>::NT, B * 8, NA_},
+#define X(I, A, B, NA_, NB_, TM) {SCfg<A, B, NA_, NB_, TM>::BM, SCfg<A, B, NA_, NB_, TM>::BN, 32, SCfg<A, B, NA_, NB_, TM>::LDS_BYTES, SCfg<A, B, NA_, NB_, TM>::NT, B * 8, NA_},
     FCN_STREAM_CONFIGS(X)
 #undef X
 };
@@ -748,9 +755,9 @@ void launch_stream(int idx, const GroupArgs& ga, int total, hipStream_t st) {
     }
     const int grid = total < cus ? total : cus;      // persistent: one workgroup per compute unit
     switch (idx) {
-#define X(I, A, B, NA_, NB_)                                                                                                                          \
+#define X(I, A, B, NA_, NB_, TM)                                                                                                                      \
     case I:                                                                                                                                           \
-        hipLaunchKernelGGL((conv_stream_f16<SCfg<A, B, NA_, NB_>>), dim3(grid), dim3(512), 0, st, ga.nprob, ga.tile_end[0], ga.tile_end[1],            \
+        hipLaunchKernelGGL((conv_stream_f16<SCfg<A, B, NA_, NB_, TM>>), dim3(grid), dim3(512), 0, st, ga.nprob, ga.tile_end[0], ga.tile_end[1],        \
                            ga.tile_end[2], ga.tile_end[3], ga.tile_end[4], ga.tile_end[5], ga.tile_end[6], ga.tile_end[7], total, 0, ga);              \
         break;
         FCN_STREAM_CONFIGS(X)

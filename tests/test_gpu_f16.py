@@ -51,9 +51,10 @@ def f16_conv(x, wt, b, pad, stride, flags, out_f32, y_cstride=None, y_coffset=0)
     return y
 
 
-STREAM_CFGS = [32, 33, 34, 35, 36, 37, 38]      # conv_stream_f16: persistent workgroups, 256-pixel tiles x 128 / 64 channels
+STREAM_CFGS = [32, 33, 34, 35, 36, 37, 38, 39, 40]      # conv_stream_f16: persistent workgroups, 256-pixel tiles x 128 / 64 channels, 128 x 192
 # (slab rows, slab buffers) per configuration: 32/33 take 3x3 and 5x5 launches, 34/35 1x1 launches, 36/37 mixed 1x1 + 3x3, 38 all three
-_STREAM_SHAPE = {32: (304, 2), 33: (304, 2), 34: (256, 3), 35: (256, 4), 36: (288, 3), 37: (288, 3), 38: (304, 3)}
+_STREAM_SHAPE = {32: (304, 2, 256), 33: (304, 2, 256), 34: (256, 3, 256), 35: (256, 4, 256), 36: (288, 3, 256), 37: (288, 3, 256), 38: (304, 3, 256),
+                 39: (160, 2, 128), 40: (160, 3, 128)}      # (slab rows, slab buffers, pixels per tile)
 
 
 @pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15", "23", "24", "26", "29"])
@@ -103,11 +104,11 @@ def _stream_problem(rng, cin, cout, k, pad, h, w, n, relu=True, bias=True, y_cst
 
 
 def _stream_takes(cfg, k, w):
-    """A tile's 256 pixels in padded raster order, plus the taps of a filter row, must fit the configuration's slab; 1x1 filters
+    """A tile's 256 (128) pixels in padded raster order, plus the taps of a filter row, must fit the configuration's slab; 1x1 filters
     need three slab buffers; padded image rows hold at least 16 entries (conv_fwd.hip plan_tiles_cfg)."""
-    rows_max, bufs = _STREAM_SHAPE[cfg]
+    rows_max, bufs, bm = _STREAM_SHAPE[cfg]
     pad = (k - 1) // 2
-    rows = 255 + 2 * pad * ((254 + w) // w) + 2 * pad + 1
+    rows = bm - 1 + 2 * pad * ((bm - 2 + w) // w) + 2 * pad + 1
     return rows <= rows_max and (k > 1 or bufs >= 3) and w + 2 * pad >= 16
 
 
