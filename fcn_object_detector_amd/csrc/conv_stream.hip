@@ -442,7 +442,16 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         // step rides in the address instruction as a constant (v_xad_u32)
         const unsigned kh16 = (unsigned)kh_ * 16u;
         const unsigned wrow = lds0 + (unsigned)(WRING0 + (wn * 32 * WTN + tau) * 128), xw = (unsigned)((((tau >> 1) ^ kh_) & 7) * 16);
-        v4f xf[WTM], wf[2][WTN];      // pixel fragments: one set, each re-read behind the MFMAs that consumed it; weight fragments: two sets
+        // Fragment registers.  FCN_STREAM_XF2 = 0 (the product): ONE set of pixel fragments, each re-read right behind the MFMAs that
+        // consumed it - the read then has the other WTM - 1 tiles' MFMAs to land.  FCN_STREAM_XF2 = 1 (experiment, round 3): TWO sets,
+        // like the weight fragments - all reads of the next k-step go out at the top of the step and have the whole step's MFMAs to
+        // land, one wait per step, 4 WTM more registers (247 / 221).  Measured 1-4 % SLOWER on every shape (conv2/3x3 147 -> 151 us,
+        // gpurun_out/r3/sweep_xf2.txt): the multiplying waves do not wait for fragment latency, so the second set buys nothing.
+#ifndef FCN_STREAM_XF2
+#define FCN_STREAM_XF2 0
+#endif
+        constexpr int XS = FCN_STREAM_XF2 ? 2 : 1;
+        v4f xf[XS][WTM], wf[2][WTN];
         auto ds_read = [](v4f& dst, unsigned addr, auto off) __attribute__((always_inline)) {
 #ifdef FCN_EXP_NOREAD
             asm volatile("" : "=v"(dst) : "v"(addr));
@@ -470,8 +479,8 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                 if (j == 2) ds_read(wf[par][WTN > 2 ? 2 : 0], aw, std::integral_constant<int, 64 * 128>{});
             }
         };
-        auto read_x = [&](const int i, const int st) __attribute__((always_inline)) {
-            ds_read(xf[i], (xk[i] ^ (unsigned)(32 * st)) + rowb[i], std::integral_constant<int, 0>{});
+        auto read_x = [&](const int par, const int i, const int st) __attribute__((always_inline)) {
+            ds_read(xf[XS == 2 ? par : 0][i], (xk[i] ^ (unsigned)(32 * st)) + rowb[i], std::integral_constant<int, 0>{});
         };
         // LDS operations of a wave return in order.  In front of the MFMAs of pixel tile i the reads still allowed in flight are the
         // WTM - 1 pixel fragments and WTN weight fragments issued after the ones it needs: one constant count for every wait of the
@@ -482,7 +491,12 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             return;
 #endif
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(decltype(pending)::value) : "memory");
-            asm volatile("" : "+v"(xf[i]));
+            if (XS == 2) {
+#pragma unroll
+                for (int ii = 0; ii < WTM; ++ii) asm volatile("" : "+v"(xf[par][ii]));
+            } else {
+                asm volatile("" : "+v"(xf[0][i]));
+            }
 #pragma unroll
             for (int j = 0; j < WTN; ++j) asm volatile("" : "+v"(wf[par][j]));
             __builtin_amdgcn_sched_barrier(0);
@@ -498,11 +512,11 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
             if (first) {
 #pragma unroll
                 for (int j = 0; j < WTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, wf[par][j]), __builtin_bit_cast(v8h, xf[i]), biasv[j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, wf[par][j]), __builtin_bit_cast(v8h, xf[XS == 2 ? par : 0][i]), biasv[j], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int j = 0; j < WTN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, wf[par][j]), __builtin_bit_cast(v8h, xf[i]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, wf[par][j]), __builtin_bit_cast(v8h, xf[XS == 2 ? par : 0][i]), acc[i][j], 0, 0, 0);
             }
         };
         // what this role keeps of a tile's problem
@@ -622,7 +636,7 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
         asm volatile("" ::: "memory");
         read_w(0, 0, wslot);
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) read_x(i, 0);
+        for (int i = 0; i < WTM; ++i) read_x(0, i, 0);
         // one chunk = 4 k-steps of a tap: [barrier] then per step { the next step's weight fragments; per pixel tile: wait, WTN MFMAs,
         // re-read the tile's fragment for the next step }.  ONE copy of this body in the kernel (the register allocator keeps the
         // accumulators in place across a single loop; four specialised copies of it made it shuffle and spill them).
@@ -642,13 +656,24 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
                     chunk_addr(rh_next, q_next, abuf_next);
                     read_w(0, 0, wslot_next);
                 }
-                if (st == 0 && first) bias_landed(std::integral_constant<int, 2 * WTM * WTN>{});      // (behind the loads: the previous tile's stores)
+                if (XS == 2) {
 #pragma unroll
-                for (int i = 0; i < WTM; ++i) {
-                    frag_landed(st & 1, i, std::integral_constant<int, WTM - 1 + WTN>{});
-                    mfma_pair(st & 1, i, st == 0 && first);
+                    for (int i = 0; i < WTM; ++i) read_x((st + 1) & 1, i, stn);
+                }
+                if (st == 0 && first) bias_landed(std::integral_constant<int, 2 * WTM * WTN>{});      // (behind the loads: the previous tile's stores)
+                if (XS == 2) {
+                    frag_landed(st & 1, 0, std::integral_constant<int, WTM + WTN>{});      // everything older than this step's reads: the step's operands
+#pragma unroll
+                    for (int i = 0; i < WTM; ++i) mfma_pair(st & 1, i, st == 0 && first);
                     __builtin_amdgcn_sched_barrier(0);
-                    read_x(i, stn);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < WTM; ++i) {
+                        frag_landed(st & 1, i, std::integral_constant<int, WTM - 1 + WTN>{});
+                        mfma_pair(st & 1, i, st == 0 && first);
+                        __builtin_amdgcn_sched_barrier(0);
+                        read_x(0, i, stn);
+                    }
                 }
             }
             wslot = wslot_next;
