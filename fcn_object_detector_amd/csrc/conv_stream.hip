@@ -739,6 +739,8 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
 //   7/8: 128 pixels x 192 channels (a wave multiplies 64 x 96: 96 accumulator registers) - for the layers with 192 / 384 output
 //      channels (conv2/3x3, inception_3b/3x3, inception_5b/3x3), where 128-channel tiles leave a quarter of their MFMAs on padding;
 //      7: 3x3 / 5x5 launches (160-row slabs, two buffers), 8: with 1x1 problems (three buffers)
+//   9/10: 128 pixels x 128 / 64 channels, any filter size: twice the tiles of 4/5 - for launches of ~1.2 - 2.5 tiles per CU, where
+//      a 256-pixel tile more or less on a CU is a quarter of the launch
 #define FCN_STREAM_CONFIGS(X) \
     X(0, 2, 38, 2, 5, 4)      \
     X(1, 1, 38, 2, 5, 4)      \
@@ -748,7 +750,9 @@ __global__ __launch_bounds__(C::NT) void conv_stream_f16(const int nprob, const 
     X(5, 1, 36, 3, 4, 4)      \
     X(6, 1, 38, 3, 4, 4)      \
     X(7, 3, 20, 2, 5, 2)      \
-    X(8, 3, 20, 3, 4, 2)
+    X(8, 3, 20, 3, 4, 2)      \
+    X(9, 2, 20, 3, 4, 2)      \
+    X(10, 1, 20, 4, 4, 2)
 
 constexpr StreamCfgInfo kStreamCfgs[] = {
 #define X(I, A, B, NA_, NB_, TM) {SCfg<A, B, NA_, NB_, TM>::BM, SCfg<A, B, NA_, NB_, TM>::BN, 32, SCfg<A, B, NA_, NB_, TM>::LDS_BYTES, SCfg<A, B, NA_, NB_, TM>::NT, B * 8, NA_},

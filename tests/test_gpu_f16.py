@@ -51,10 +51,10 @@ def f16_conv(x, wt, b, pad, stride, flags, out_f32, y_cstride=None, y_coffset=0)
     return y
 
 
-STREAM_CFGS = [32, 33, 34, 35, 36, 37, 38, 39, 40]      # conv_stream_f16: persistent workgroups, 256-pixel tiles x 128 / 64 channels, 128 x 192
+STREAM_CFGS = [32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42]      # conv_stream_f16: persistent workgroups, 256-pixel tiles x 128 / 64 channels, 128 x 192
 # (slab rows, slab buffers) per configuration: 32/33 take 3x3 and 5x5 launches, 34/35 1x1 launches, 36/37 mixed 1x1 + 3x3, 38 all three
 _STREAM_SHAPE = {32: (304, 2, 256), 33: (304, 2, 256), 34: (256, 3, 256), 35: (256, 4, 256), 36: (288, 3, 256), 37: (288, 3, 256), 38: (304, 3, 256),
-                 39: (160, 2, 128), 40: (160, 3, 128)}      # (slab rows, slab buffers, pixels per tile)
+                 39: (160, 2, 128), 40: (160, 3, 128), 41: (160, 3, 128), 42: (160, 4, 128)}      # (slab rows, slab buffers, pixels per tile)
 
 
 @pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15", "23", "24", "26", "29"])
