@@ -191,7 +191,7 @@ def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
     wg = [r for r in eng.time_ops(reps=3, ops=eng.bwd_ops) if r[0] == "wgrad"]
     wg_ms, wg_fl = sum(r[2] for r in wg), sum(r[3] for r in wg)
     if wg_ms > 0:
-        res["roofline"] = {"bound": "mfma", "kernel": "conv_wgrad_group_kernel (f32 MFMA, reduction over pixels) + reduce_partials_group_kernel; %d launches" % len(wg),
+        res["roofline"] = {"bound": "mfma", "kernel": "conv_wgrad_split_kernel / conv_wgrad_group_kernel (f32 MFMA, reduction over pixels; per launch the faster of the two, timed at plan time) + reduce_partials_group_kernel; %d launches" % len(wg),
                            "achieved": round(wg_fl / wg_ms / 1e9, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(wg_fl / wg_ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                            "ms_per_step": round(wg_ms, 3), "whole_step_frac": round(res["achieved_tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
