@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""GPU probe (round 3): does an inception module's 3x3 / stride 1 pooling hide behind the module's 1x1 convolution launch when the
+two run on different streams (both read the module's input, nothing else connects them)?  Times the pair back to back on one stream
+and forked / joined with events over two streams, half floats at batch 32.  usage: python tools/overlap_probe.py [module ...]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fcn_object_detector_amd import lib as L  # noqa: E402
+from fcn_object_detector_amd.engine import DeviceBuffer  # noqa: E402
+from gpu_util import conv_desc, dev_from  # noqa: E402
+
+MODULES = {  # name: (H = W, Cin, [Cout of the three 1x1 convolutions])
+    "3a": (56, 192, [64, 96, 16]), "3b": (56, 256, [128, 128, 32]), "4a": (28, 480, [192, 96, 16]), "4e": (28, 528, [256, 160, 32]),
+    "5b": (28, 832, [384, 192, 48]),
+}
+
+
+def main():
+    n = 32
+    lib = L.load()
+    L.call("fcn_init", 0)
+    s1, s2 = C.c_void_p(), C.c_void_p()
+    L.call("fcn_stream_create", C.byref(s1))
+    L.call("fcn_stream_create", C.byref(s2))
+    ev = [C.c_void_p() for _ in range(4)]
+    for e in ev:
+        L.call("fcn_event_create", C.byref(e))
+    rng = np.random.default_rng(0)
+    for name in (sys.argv[1:] or MODULES):
+        h, cin, couts = MODULES[name]
+        x = dev_from(rng.standard_normal((n, h, h, cin)).astype(np.float16))
+        keep, descs = [x], []
+        for co in couts:
+            wt = dev_from((rng.standard_normal((co, 1, 1, cin)) * 0.05).astype(np.float16))
+            b = dev_from(np.zeros(co, np.float32))
+            y = dev_from(np.zeros((n, h, h, co), np.float16))
+            keep += [wt, b, y]
+            descs.append(conv_desc(x, wt, b, y, n, h, h, cin, cin, co, 1, 0, 1, h, h, co, 0, L.CONV_RELU | L.CONV_F16))
+        arr = (L.ConvDesc * 3)(*descs)
+        ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(3)), zero=False)
+        py = DeviceBuffer(n * h * h * cin * 2, zero=False)
+        best = None
+        for cfg in range(32, int(lib.fcn_conv2d_num_configs())):      # the streaming configuration the tuner would pick
+            grp = L.ConvGroup()
+            if lib.fcn_conv2d_group_prepare(arr, 3, ws.ptr, cfg, C.byref(grp)) != 0:
+                continue
+            for _ in range(2):
+                L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), s1)
+            L.call("fcn_event_record", ev[0], s1)
+            for _ in range(10):
+                L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), s1)
+            L.call("fcn_event_record", ev[1], s1)
+            L.call("fcn_event_sync", ev[1])
+            ms = C.c_float()
+            L.call("fcn_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+            if best is None or ms.value < best[1]:
+                best = (cfg, ms.value)
+        grp = L.ConvGroup()
+        L.call("fcn_conv2d_group_prepare", arr, 3, ws.ptr, best[0], C.byref(grp))
+
+        def conv(st):
+            L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), st)
+
+        def pool(st):
+            L.call("fcn_maxpool_fwd_f16", x.ptr, py.ptr, n, h, h, cin, cin, 3, 1, 1, h, h, cin, 0, st)
+
+        def timed(body, reps=20):
+            for _ in range(3):
+                body()
+            L.call("fcn_event_record", ev[0], s1)
+            for _ in range(reps):
+                body()
+            L.call("fcn_event_record", ev[1], s1)
+            L.call("fcn_event_sync", ev[1])
+            ms = C.c_float()
+            L.call("fcn_event_elapsed_ms", ev[0], ev[1], C.byref(ms))
+            return ms.value / reps * 1e3
+
+        def forked(first_pool):
+            L.call("fcn_event_record", ev[2], s1)
+            L.call("fcn_stream_wait_event", s2, ev[2])
+            if first_pool:
+                pool(s2)
+                conv(s1)
+            else:
+                conv(s1)
+                pool(s2)
+            L.call("fcn_event_record", ev[3], s2)
+            L.call("fcn_stream_wait_event", s1, ev[3])
+
+        t_conv, t_pool = timed(lambda: conv(s1)), timed(lambda: pool(s1))
+        t_seq = timed(lambda: (pool(s1), conv(s1)))
+        t_f1, t_f2 = timed(lambda: forked(True)), timed(lambda: forked(False))
+        print("%-3s cfg%d  conv %6.1f us  pool %6.1f us  one stream %6.1f us  two streams: pool enqueued first %6.1f us, conv first %6.1f us" %
+              (name, best[0], t_conv, t_pool, t_seq, t_f1, t_f2), flush=True)
+        L.call("fcn_conv2d_group_release", ws.ptr)
+
+
+if __name__ == "__main__":
+    main()
