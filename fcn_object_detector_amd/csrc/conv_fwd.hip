@@ -1141,10 +1141,214 @@ __global__ __launch_bounds__(kD7Threads) void conv_first7_f16_kernel(const ConvP
 #endif
 }
 
+// The half-float first layer on an image whose channels 3 and 4 are the constant 1 (FCN_CONV_IMAGE_ONES: the engine's folded
+// Power shift, Engine._packed_weight) - round 3.  The kernel above multiplies 8-half pixels of which three carry data: 112 MFMAs per
+// wave and tile, 224 filter registers per lane, ONE wave per SIMD (405 VGPRs) - nothing overlaps a tile's epilogue (2.9 of its 4.6 us).
+// With the flag the two constant channels need no multiplication at all: their contribution to an output is the sum of the filter's
+// shift terms over the taps that lie inside the image - a per-channel constant for every pixel whose window is inside (added to the
+// bias, in f32) and a short sum over a 49 x 64 table in LDS for the pixels within 3 columns / rows of the border.  What is left is
+// b, g, r: a pixel shrinks to 4 halves (8 bytes, the fourth zero) in the LDS patch, one 16-byte fragment read covers TWO neighbouring
+// taps (the stride of 2 keeps it aligned), a filter row takes 2 MFMA steps instead of 4: 56 MFMAs per wave and tile, 112 filter
+// registers - and with <= 256 VGPRs TWO workgroups share a CU, so one multiplies while the other stores.  Same tile walk, same
+// epilogue through the LDS image (whole 128-byte lines per store instruction: DESIGN.md 4.7 (b)).
+constexpr int kX4PatchBytes = kD7Ph * kD7Pw * 8;                              // 21 x 70 pixels of 8 bytes; rows of 560 bytes (16-byte multiples)
+constexpr int kX4EpiOff = 2 * kX4PatchBytes;                                  // two patch buffers, then the epilogue image, then the shift table
+constexpr int kX4EpiPitch = 144;
+constexpr int kX4TabOff = kX4EpiOff + 4 * 64 * kX4EpiPitch;
+constexpr int kX4LdsBytes = kX4TabOff + 64 * 64 * 4;      // prefix sums P[r][q][channel], r, q = 0 .. 7, of the shift terms
+static_assert(kX4PatchBytes % 16 == 0 && (kD7Pw * 8) % 16 == 0, "fragment reads are 16-byte aligned");
+static_assert(2 * kX4LdsBytes <= 160 * 1024, "two workgroups per CU");
+
+#ifdef FCN_EXP_X4_FREE      // (experiment: no register cap - one workgroup per CU)
+#define FCN_X4_ATTR
+#else
+#define FCN_X4_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+__global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kernel(const ConvP p, const int ntiles) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) char smem[kX4LdsBytes];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (p.OW + kD7Tw - 1) / kD7Tw, tiles_y = (p.OH + kD7Th - 1) / kD7Th;
+    const f16_t* xh = reinterpret_cast<const f16_t*>(p.x);
+    const f16_t* wh = reinterpret_cast<const f16_t*>(p.w);
+    f16_t* yh = reinterpret_cast<f16_t*>(p.y);
+    // (pixels and filter segments travel as INTEGER words: two halves seen as a float are a denormal once the upper one is masked
+    //  away, and float moves may flush it)
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2u zero2 = {0u, 0u};
+    constexpr int PI = (kD7Ph * kD7Pw + kD7Threads - 1) / kD7Threads;
+    // a tile's patch: b, g, r of this thread's slots (the fourth half zeroed; zeros outside the image / past the last tile)
+    auto fetch_patch = [&](const int tile, v2u (&px)[PI]) {
+        int t = tile;
+        const int tx = t % tiles_x;
+        t /= tiles_x;
+        const int ty = t % tiles_y, n = t / tiles_y;
+        const int iy0 = 2 * ty * kD7Th - 3, ix0 = 2 * tx * kD7Tw - 3;
+        const f16_t* xn = xh + (size_t)n * p.H * p.W * 8;
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int sl = tid + kD7Threads * i;
+            const int pr = sl / kD7Pw, pc = sl - pr * kD7Pw;
+            const int iy = iy0 + pr, ix = ix0 + pc;
+            const bool ok = tile < ntiles && sl < kD7Ph * kD7Pw && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            v2u v = ok ? *reinterpret_cast<const v2u*>(xn + ((size_t)iy * p.W + ix) * 8) : zero2;
+            v[1] &= 0xffffu;      // (b, g), (r, 0): the constant channel is not multiplied
+            px[i] = v;
+        }
+    };
+    auto store_patch = [&](const int buf, const v2u (&px)[PI]) {
+#pragma unroll
+        for (int i = 0; i < PI; ++i) {
+            const int sl = tid + kD7Threads * i;
+            if (sl < kD7Ph * kD7Pw) *reinterpret_cast<v2u*>(smem + buf * kX4PatchBytes + sl * 8) = px[i];
+        }
+    };
+    // ---- once per workgroup: the shift table T[tap][channel] = w[channel][tap][3] + w[channel][tap][4] (the two halves of the
+    //      folded Power shift), this lane's filter segments (channel 2 nl + nt, filter row r, taps 4 hs + 2 h and + 1; tap 7: zeros)
+    //      and its 2-D prefix sums P[r][q] = sum of T over filter rows < r and taps < q: the taps of a window that lie inside the image
+    //      are a rectangle [rlo, rhi) x [qlo, qhi), so a border pixel's shift is four table reads (a loop over up to 49 taps per pixel
+    //      made the tiles of the first image rows the slowest of the launch)
+    float* traw = reinterpret_cast<float*>(smem + kX4EpiOff);      // (the epilogue image is free until the first tile ends)
+    float* tab = reinterpret_cast<float*>(smem + kX4TabOff);
+    for (int e = tid; e < 49 * 64; e += kD7Threads) {
+        const int t = e >> 6, co = e & 63;
+        traw[e] = co < p.Cout ? (float)wh[((size_t)co * 49 + t) * 8 + 3] + (float)wh[((size_t)co * 49 + t) * 8 + 4] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 8 * 64; e += kD7Threads) {      // one (r, channel) per item: the running sums along q, rows < r in row order
+        const int r = e >> 6, co = e & 63;
+        float run = 0.f;
+        tab[(r * 8) * 64 + co] = 0.f;
+        for (int q = 0; q < 7; ++q) {
+            for (int rr = 0; rr < r; ++rr) run += traw[(rr * 7 + q) * 64 + co];
+            tab[(r * 8 + q + 1) * 64 + co] = run;
+        }
+    }
+    const int nl = lane & 31, h = lane >> 5;
+    v2u px[PI];
+    int tile = blockIdx.x;
+    fetch_patch(tile, px);
+    v4u breg[14][2];
+#pragma unroll
+    for (int step = 0; step < 14; ++step)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int r = step >> 1, q0 = 4 * (step & 1) + 2 * h, co = 2 * nl + nt;
+            v2u lo = zero2, hi = zero2;
+            if (co < p.Cout) {
+                lo = *reinterpret_cast<const v2u*>(wh + ((size_t)co * 49 + r * 7 + q0) * 8);
+                if (q0 + 1 < 7) hi = *reinterpret_cast<const v2u*>(wh + ((size_t)co * 49 + r * 7 + q0 + 1) * 8);
+            }
+            breg[step][nt] = v4u{lo[0], lo[1] & 0xffffu, hi[0], hi[1] & 0xffffu};
+        }
+    store_patch(0, px);
+    __syncthreads();      // the table and the first patch
+    // ---- per-lane constants: fragment base (bytes), bias + the whole shift of this lane's two channels (windows inside the image)
+    const char* a_lane = smem + ((4 * wave) * kD7Pw + 2 * nl + 2 * h) * 8;
+    const float bias0 = (p.bias && 2 * nl < p.Cout) ? p.bias[2 * nl] : 0.f;
+    const float bias1 = (p.bias && 2 * nl + 1 < p.Cout) ? p.bias[2 * nl + 1] : 0.f;
+    const v2f tall = *reinterpret_cast<const v2f*>(tab + (7 * 8 + 7) * 64 + 2 * nl);
+    const float in0 = bias0 + tall[0], in1 = bias1 + tall[1];
+    const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
+    char* epi = smem + kX4EpiOff + wave * (64 * kX4EpiPitch);
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        fetch_patch(tile + (int)gridDim.x, px);      // the next tile's pixels travel while this tile multiplies
+        const char* a_base = a_lane + buf * kX4PatchBytes;
+        v16f acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        auto frag = [&](const int step, v4u (&a)[2]) {
+            const int r = step >> 1, hs = step & 1;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const v4u*>(a_base + ((2 * mt + r) * kD7Pw + 4 * hs) * 8);
+        };
+        v4u fa[3][2];
+        frag(0, fa[0]);
+        frag(1, fa[1]);
+#pragma unroll
+        for (int step = 0; step < 14; ++step) {
+            if (step + 2 < 14) frag(step + 2, fa[(step + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fa[step % 3][mt]), __builtin_bit_cast(v8h, breg[step][nt]),
+                                                                         acc[mt][nt], 0, 0, 0);
+        }
+        int tq = tile;
+        const int tx = tq % tiles_x;
+        tq /= tiles_x;
+        const int ty = tq % tiles_y, n = tq / tiles_y;
+        // windows of this tile that reach outside the image: rows 2 oy - 3 .. + 3, columns 2 ox - 3 .. + 3
+        const bool border = ty == 0 || tx == 0 || 2 * (ty * kD7Th + kD7Th - 1) + 3 >= p.H || 2 * (tx * kD7Tw + kD7Tw - 1) + 3 >= p.W;
+        // ---- epilogue: register v of lane (nl, h) is pixel ox = (v & 3) + 8 (v >> 2) + 4 h, channels 2 nl (N-tile 0) and 2 nl + 1 (N-tile 1)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int oy = ty * kD7Th + 2 * wave + mt;
+            const int rlo = max(0, 3 - 2 * oy), rhi = min(7, p.H + 3 - 2 * oy);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int oxl = (v & 3) + 8 * (v >> 2) + 4 * h;
+                float b0 = in0, b1 = in1;
+                if (border) {
+                    const int ox = tx * kD7Tw + oxl;
+                    const int qlo = max(0, 3 - 2 * ox), qhi = min(7, p.W + 3 - 2 * ox);
+                    if (rlo > 0 || rhi < 7 || qlo > 0 || qhi < 7) {      // the shift terms of the taps inside the image only
+                        const int rh = max(rhi, rlo), qh = max(qhi, qlo);      // (pixels past the image: an empty rectangle)
+                        const v2f a = *reinterpret_cast<const v2f*>(tab + (rh * 8 + qh) * 64 + 2 * nl), bq = *reinterpret_cast<const v2f*>(tab + (rlo * 8 + qh) * 64 + 2 * nl),
+                                  cq = *reinterpret_cast<const v2f*>(tab + (rh * 8 + qlo) * 64 + 2 * nl), dq = *reinterpret_cast<const v2f*>(tab + (rlo * 8 + qlo) * 64 + 2 * nl);
+                        b0 = bias0 + ((a[0] - bq[0]) - (cq[0] - dq[0]));
+                        b1 = bias1 + ((a[1] - bq[1]) - (cq[1] - dq[1]));
+                    }
+                }
+                float e0 = acc[mt][0][v] + b0, e1 = acc[mt][1][v] + b1;
+                if (do_relu) {
+                    e0 = fmaxf(e0, 0.f);
+                    e1 = fmaxf(e1, 0.f);
+                }
+                typedef f16_t v2h __attribute__((ext_vector_type(2)));
+                const v2h pk = {(f16_t)e0, (f16_t)e1};
+                *reinterpret_cast<v2h*>(epi + (mt * 32 + oxl) * kX4EpiPitch + nl * 4) = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave reads back its own image only)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int c8 = (lane & 7) * 8;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int oy = ty * kD7Th + 2 * wave + mt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int ox = (lane >> 3) + 8 * i;
+                    const v4f val = *reinterpret_cast<const v4f*>(epi + (mt * 32 + ox) * kX4EpiPitch + c8 * 2);
+                    if (oy < p.OH && tx * kD7Tw + ox < p.OW && c8 < p.Cout)
+                        *reinterpret_cast<v4f*>(yh + ((size_t)(n * p.OH + oy) * p.OW + tx * kD7Tw + ox) * p.y_cstride + p.y_coffset + c8) = val;
+                }
+            }
+        }
+        store_patch(buf ^ 1, px);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        buf ^= 1;
+    }
+#endif
+}
+
 bool first7_f16_ok(const ConvP& p) {
     return p.kh == 7 && p.kw == 7 && p.stride == 2 && p.pad == 3 && p.Cin == 8 && p.x_cstride == 8 && p.Cout > 32 && p.Cout <= 64 &&
            p.Cout % 8 == 0 && ((p.y_cstride | p.y_coffset) & 7) == 0 && ((uintptr_t)p.y & 15) == 0 &&
-           (p.flags & ~FCN_CONV_RELU) == FCN_CONV_F16;
+           (p.flags & ~(FCN_CONV_RELU | FCN_CONV_IMAGE_ONES)) == FCN_CONV_F16;
 }
 
 // Does the first-layer kernel take this problem?
@@ -1333,6 +1537,8 @@ int validate(const fcn_conv_desc& d) {
                 "conv: Cin (%d) and x_cstride (%d) must be multiples of %d (pad the input channels)", d.Cin, d.x_cstride, eps);
     FCN_REQUIRE((d.flags & FCN_CONV_F16) || !(d.flags & FCN_CONV_OUT_F32), FCN_E_ARG, "conv: FCN_CONV_OUT_F32 only qualifies FCN_CONV_F16");
     FCN_REQUIRE(!(d.flags & FCN_CONV_F16) || !(d.flags & FCN_CONV_OUT_F16), FCN_E_ARG, "conv: FCN_CONV_OUT_F16 only qualifies float32 inputs");
+    FCN_REQUIRE(!(d.flags & FCN_CONV_IMAGE_ONES) || ((d.flags & FCN_CONV_F16) && d.Cin == 8 && d.x_cstride == 8), FCN_E_ARG,
+                "conv: FCN_CONV_IMAGE_ONES describes an 8-half pixel image (FCN_CONV_F16, Cin = x_cstride = 8)");
     FCN_REQUIRE(((uintptr_t)d.x & 15) == 0 && ((uintptr_t)d.w & 15) == 0, FCN_E_ALIGN, "conv: x/w must be 16-byte aligned");
     FCN_REQUIRE(d.OH == (d.H + 2 * d.pad - d.kh) / d.stride + 1 && d.OW == (d.W + 2 * d.pad - d.kw) / d.stride + 1,
                 FCN_E_ARG, "conv: OH/OW (%d,%d) do not match floor((H+2p-k)/s)+1", d.OH, d.OW);
@@ -1510,6 +1716,12 @@ template <typename T>
 void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
     if (cfg == kFirst7Cfg) {
         if (p.flags & FCN_CONV_F16) {      // persistent: one workgroup per CU (a wave per SIMD holds its filters in registers), each walks its share of the tiles
+            static const bool x4_ok = !(getenv("FCN_FIRST7_X4") && atoi(getenv("FCN_FIRST7_X4")) == 0);      // (experiments: the 8-half kernel)
+            if ((p.flags & FCN_CONV_IMAGE_ONES) && x4_ok) {      // channels 3 and 4 are the constant 1: three multiplied channels, two workgroups per CU
+                const int grid = total < 2 * device_cus() ? total : 2 * device_cus();
+                hipLaunchKernelGGL(conv_first7_f16x4_kernel, dim3(grid), dim3(kD7Threads), 0, st, p, total);
+                return;
+            }
             const int grid = total < device_cus() ? total : device_cus();      // persistent: one workgroup per compute unit
             hipLaunchKernelGGL(conv_first7_f16_kernel, dim3(grid), dim3(kD7Threads), 0, st, p, total);
         } else {

@@ -440,6 +440,10 @@ class Engine:
         flags = 0
         if xb.esize == 2:
             flags |= L.CONV_F16 | (L.CONV_OUT_F32 if yb.esize == 4 else 0)
+            # the half image of _half_inputs: channels 3 and 4 are the constant 1 (written once, _plan_buffers), 5..7 stay zero and
+            # _packed_weight puts the folded shift into the filters' channels 3 and 4 - the first-layer kernel may take them as constants
+            if any(l.bottoms[0] == t and sh for t, sh in getattr(self, "_half_inputs", {}).values()) and _ra(cin, 2) == 8 and xb.cstride == 8:
+                flags |= L.CONV_IMAGE_ONES
         elif yb.esize != 4:
             flags |= L.CONV_OUT_F16      # first layer of an f16 net: float32 image in, halves out
         if fused_relu:

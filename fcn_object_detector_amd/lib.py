@@ -78,6 +78,7 @@ class DetectParams(C.Structure):
 
 
 CONV_RELU, CONV_SIGMOID2, CONV_ACCUM, CONV_OUT_F32, CONV_F16, CONV_OUT_F16, CONV_MASK = 1, 2, 4, 8, 16, 32, 64
+CONV_IMAGE_ONES = 128      # half image whose channels 3 and 4 are the constant 1 (the folded Power shift): see include/fcnhip.h
 ELT_PROD, ELT_SUM, ELT_MAX = 0, 1, 2
 RECT_ROUND_NEAREST_EVEN, RECT_ROUND_TRUNCATE = 0, 1
 

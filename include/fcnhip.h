@@ -93,6 +93,10 @@ int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int
 #define FCN_CONV_ACCUM     4   /* y += result (gradient fan-in when the kernel runs as a data-gradient pass) */
 #define FCN_CONV_MASK     64   /* y = (y2 > 0) ? result : 0 with y2 read at the result's position (y2_cstride / y2_coffset): the ReLU
                                 * backward of the layer below, applied by the LAST data-gradient pass that writes its gradient   */
+#define FCN_CONV_IMAGE_ONES 128 /* with FCN_CONV_F16 on an 8-half pixel image (the first layer of an f16 net): the caller promises that channels 3
+                                * and 4 of x hold the constant 1 at every pixel and channels 5..7 contribute nothing (zero pixels or zero
+                                * weights) - the folded Power shift of models/deploy.prototxt:8-16.  Their products are then added
+                                * as per-tap constants (f32) instead of being multiplied; pixels outside the image count as 0, as ever */
 #define FCN_CONV_OUT_F32   8   /* with FCN_CONV_F16: y is float32 (the detection heads feed the f32 decode kernel)   */
 #define FCN_CONV_OUT_F16  32   /* float32 x and w, y stored as half floats: the first layer of an f16 net keeps its input in
                                 * float32 (models/deploy.prototxt shifts a [0,1] image by -127: 16 half-float levels)   */

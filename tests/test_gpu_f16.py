@@ -399,6 +399,49 @@ def test_f16_first_layer_kernel_matches_oracle(gpu, monkeypatch, n, h, w, cout, 
     L.call("fcn_conv2d_group_release", ws.ptr)
 
 
+@pytest.mark.parametrize("n,h,w,cout,relu", [(2, 448, 448, 64, 1), (5, 100, 130, 48, 0), (1, 64, 64, 64, 1), (11, 40, 201, 40, 1), (3, 13, 9, 64, 1)])
+def test_f16_first_layer_with_constant_channels(gpu, monkeypatch, n, h, w, cout, relu):
+    """FCN_CONV_IMAGE_ONES (conv_first7_f16x4_kernel): an 8-half pixel image whose channels 3 and 4 are the constant 1 - the folded Power
+    shift of the f16 engine.  The kernel multiplies b, g, r only and adds the two constant channels' filters as per-tap constants,
+    for every pixel over exactly the taps that lie inside the image (odd extents, images smaller than a tile, more tiles than
+    workgroups).  Against float64 convolution of the same half operands, and against the 8-half kernel (FCN_FIRST7_X4=0 is read once
+    per process, so the comparison goes through the flag)."""
+    monkeypatch.delenv("FCN_CONV_CFG", raising=False)
+    rng = np.random.default_rng(n * 1000 + h)
+    x = np.zeros((n, 8, h, w), np.float32)
+    x[:, :3] = rng.random((n, 3, h, w)).astype(np.float16)
+    x[:, 3:5] = 1.0
+    wt = np.zeros((cout, 8, 7, 7), np.float32)
+    wt[:, :3] = (rng.standard_normal((cout, 3, 7, 7)) / np.sqrt(147)).astype(np.float16)
+    term = -127.0 * wt[:, :3].astype(np.float64).sum(1)                      # what Engine._packed_weight folds: hi + lo halves
+    wt[:, 3] = term.astype(np.float16)
+    wt[:, 4] = (term - wt[:, 3].astype(np.float64)).astype(np.float16)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = R.conv2d(x.astype(np.float64), wt.astype(np.float64), b.astype(np.float64), 3, 2)
+    if relu:
+        ref = np.maximum(ref, 0)
+    oh, ow = R.conv_out(h, 7, 3, 2), R.conv_out(w, 7, 3, 2)
+    xd = dev_from(np.ascontiguousarray(x.transpose(0, 2, 3, 1)).astype(np.float16))
+    wd = dev_from(np.ascontiguousarray(wt.transpose(0, 2, 3, 1)).astype(np.float16))
+    bd = dev_from(b)
+    outs = []
+    for flag in (L.CONV_IMAGE_ONES, 0):
+        yd = dev_from(np.full((n, oh, ow, r8(cout) + 8), -7.0, np.float16))
+        d = conv_desc(xd, wd, bd, yd, n, h, w, 8, 8, cout, 7, 3, 2, oh, ow, r8(cout) + 8, 8, L.CONV_F16 | flag | (L.CONV_RELU if relu else 0))
+        L.call("fcn_conv2d_fwd_f32", C.byref(d), None)
+        L.call("fcn_device_sync")
+        y16 = dev_to(yd, (n, oh, ow, r8(cout) + 8), np.float16)
+        got = y16[..., 8:8 + cout].astype(np.float64).transpose(0, 3, 1, 2)
+        scale = max(np.abs(ref).max(), 1.0)
+        assert np.abs(got - ref).max() <= scale * 2.0 ** -10, flag              # half an f16 ulp of the largest value
+        assert np.all(y16[..., :8] == np.float16(-7.0)) and np.all(y16[..., 8 + cout:] == np.float16(-7.0))
+        outs.append(got)
+    assert np.abs(outs[0] - outs[1]).max() <= max(np.abs(ref).max(), 1.0) * 2.0 ** -10
+    # the flag is refused where it cannot hold
+    bad = conv_desc(xd, wd, bd, yd, n, h, w, 8, 8, cout, 7, 3, 2, oh, ow, r8(cout) + 8, 8, L.CONV_IMAGE_ONES)
+    assert L.load().fcn_conv2d_fwd_f32(C.byref(bad), None) != 0
+
+
 @pytest.mark.parametrize("lrn_first", [0, 1])
 @pytest.mark.parametrize("k,s,p,h,w,c", [(3, 2, 0, 28, 28, 64), (3, 2, 0, 15, 21, 8), (3, 1, 1, 9, 7, 16), (3, 2, 1, 10, 11, 40), (3, 2, 0, 17, 9, 192)])
 def test_f16_maxpool_lrn_single_pass_equals_the_two_launches(gpu, lrn_first, k, s, p, h, w, c):
