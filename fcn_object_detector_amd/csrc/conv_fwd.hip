@@ -1152,57 +1152,65 @@ __global__ __launch_bounds__(kD7Threads) void conv_first7_f16_kernel(const ConvP
 // registers - and with <= 256 VGPRs TWO workgroups share a CU, so one multiplies while the other stores.  Same tile walk, same
 // epilogue through the LDS image (whole 128-byte lines per store instruction: DESIGN.md 4.7 (b)).
 constexpr int kX4PatchBytes = kD7Ph * kD7Pw * 8;                              // 21 x 70 pixels of 8 bytes; rows of 560 bytes (16-byte multiples)
-constexpr int kX4EpiOff = 2 * kX4PatchBytes;                                  // two patch buffers, then the epilogue image, then the shift table
+constexpr int kX4PatchInstr = 48;                                             // LDS-DMA instructions per patch (256 bytes each; 46 carry pixels)
+constexpr int kX4PatchPitch = kX4PatchInstr * 256;                            // bytes between the patch buffers
+constexpr int kX4NBuf = 3;                                                    // patch buffers: the tile being multiplied and two on their way
+constexpr int kX4EpiOff = kX4NBuf * kX4PatchPitch;                            // then the epilogue image (one output row per wave at a time), then the table
 constexpr int kX4EpiPitch = 144;
-constexpr int kX4TabOff = kX4EpiOff + 4 * 64 * kX4EpiPitch;
+constexpr int kX4TabOff = kX4EpiOff + 4 * 32 * kX4EpiPitch;
 constexpr int kX4LdsBytes = kX4TabOff + 64 * 64 * 4;      // prefix sums P[r][q][channel], r, q = 0 .. 7, of the shift terms
-static_assert(kX4PatchBytes % 16 == 0 && (kD7Pw * 8) % 16 == 0, "fragment reads are 16-byte aligned");
-static_assert(2 * kX4LdsBytes <= 160 * 1024, "two workgroups per CU");
+static_assert(kX4PatchBytes % 16 == 0 && (kD7Pw * 8) % 16 == 0 && kX4PatchBytes <= 46 * 256, "fragment reads are 16-byte aligned; 46 instructions cover a patch");
+static_assert(2 * kX4LdsBytes <= 160 * 1024 && 49 * 64 * 4 <= kX4EpiOff, "two workgroups per CU; the raw shift table borrows the patch buffers");
 
 #ifdef FCN_EXP_X4_FREE      // (experiment: no register cap - one workgroup per CU)
 #define FCN_X4_ATTR
 #else
 #define FCN_X4_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
+#ifndef FCN_X4_LINEAR
+#define FCN_X4_LINEAR 1      // 1: tiles b, b + G, ..; 0 (experiment): runs of consecutive tiles per XCD - measured no gain (97 vs 100 us):
+#endif                       // the kernel is bound by its own vector instructions, not by memory (elimination builds: 90 us without loads AND stores)
 __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kernel(const ConvP p, const int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) char smem[kX4LdsBytes];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = (p.OW + kD7Tw - 1) / kD7Tw, tiles_y = (p.OH + kD7Th - 1) / kD7Th;
-    const f16_t* xh = reinterpret_cast<const f16_t*>(p.x);
     const f16_t* wh = reinterpret_cast<const f16_t*>(p.w);
     f16_t* yh = reinterpret_cast<f16_t*>(p.y);
-    // (pixels and filter segments travel as INTEGER words: two halves seen as a float are a denormal once the upper one is masked
-    //  away, and float moves may flush it)
+    // (filter segments travel as INTEGER words: two halves seen as a float are a denormal once the upper one is masked away, and
+    //  float moves may flush it)
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2u zero2 = {0u, 0u};
-    constexpr int PI = (kD7Ph * kD7Pw + kD7Threads - 1) / kD7Threads;
-    // a tile's patch: b, g, r of this thread's slots (the fourth half zeroed; zeros outside the image / past the last tile)
-    auto fetch_patch = [&](const int tile, v2u (&px)[PI]) {
+    // A tile's patch goes from HBM to LDS by LDS-DMA, TWO tiles ahead (with the patch in registers a workgroup had one tile's bytes
+    // in flight and waited a memory latency per tile - 5.7 us per tile where the MFMAs take 0.85): a lane moves one dword - half of a
+    // pixel's (b, g, r, 1) - so two neighbouring lanes fill a pixel's 8 bytes; instruction k of the patch carries slots 32 k .. 32 k + 31.
+    // The pixel's constant channel arrives as it is (1 inside the image): the filters' fourth half is zero.  Pixels outside the
+    // image / past the last tile take an out-of-range offset: zeros.
+    constexpr int OOB = (int)0x80000000u;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)((long long)p.N * p.H * p.W * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        yh, 0, (int)((((long long)p.N * p.OH * p.OW - 1) * p.y_cstride + p.y_coffset + p.Cout) * 2), 0x00020000);
+    auto issue_patch = [&](const int tile, const int buf) __attribute__((always_inline)) {
         int t = tile;
         const int tx = t % tiles_x;
         t /= tiles_x;
         const int ty = t % tiles_y, n = t / tiles_y;
         const int iy0 = 2 * ty * kD7Th - 3, ix0 = 2 * tx * kD7Tw - 3;
-        const f16_t* xn = xh + (size_t)n * p.H * p.W * 8;
+        const int img = n * p.H;
 #pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int sl = tid + kD7Threads * i;
+        for (int i = 0; i < kX4PatchInstr / 4; ++i) {
+            const int k = wave + 4 * i;
+            const int sl = k * 32 + (lane >> 1);
             const int pr = sl / kD7Pw, pc = sl - pr * kD7Pw;
             const int iy = iy0 + pr, ix = ix0 + pc;
             const bool ok = tile < ntiles && sl < kD7Ph * kD7Pw && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            v2u v = ok ? *reinterpret_cast<const v2u*>(xn + ((size_t)iy * p.W + ix) * 8) : zero2;
-            v[1] &= 0xffffu;      // (b, g), (r, 0): the constant channel is not multiplied
-            px[i] = v;
-        }
-    };
-    auto store_patch = [&](const int buf, const v2u (&px)[PI]) {
-#pragma unroll
-        for (int i = 0; i < PI; ++i) {
-            const int sl = tid + kD7Threads * i;
-            if (sl < kD7Ph * kD7Pw) *reinterpret_cast<v2u*>(smem + buf * kX4PatchBytes + sl * 8) = px[i];
+            int vo = ok ? ((img + iy) * p.W + ix) * 16 + (lane & 1) * 4 : OOB;
+            asm volatile("" : "+v"(vo));
+#ifndef FCN_X4_NOLOAD      // (elimination builds: timing only)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(smem + buf * kX4PatchPitch + k * 256), 4, vo, 0, 0, 0);
+#endif
         }
     };
     // ---- once per workgroup: the shift table T[tap][channel] = w[channel][tap][3] + w[channel][tap][4] (the two halves of the
@@ -1210,7 +1218,7 @@ __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kern
     //      and its 2-D prefix sums P[r][q] = sum of T over filter rows < r and taps < q: the taps of a window that lie inside the image
     //      are a rectangle [rlo, rhi) x [qlo, qhi), so a border pixel's shift is four table reads (a loop over up to 49 taps per pixel
     //      made the tiles of the first image rows the slowest of the launch)
-    float* traw = reinterpret_cast<float*>(smem + kX4EpiOff);      // (the epilogue image is free until the first tile ends)
+    float* traw = reinterpret_cast<float*>(smem);                  // (the patch buffers are free until the first patch is asked for)
     float* tab = reinterpret_cast<float*>(smem + kX4TabOff);
     for (int e = tid; e < 49 * 64; e += kD7Threads) {
         const int t = e >> 6, co = e & 63;
@@ -1226,10 +1234,18 @@ __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kern
             tab[(r * 8 + q + 1) * 64 + co] = run;
         }
     }
+    __syncthreads();      // everybody is done with the raw table: the patch buffers may fill
     const int nl = lane & 31, h = lane >> 5;
-    v2u px[PI];
-    int tile = blockIdx.x;
-    fetch_patch(tile, px);
+    // Tile walk: b, b + G, ...  (FCN_X4_LINEAR = 0: blocks b and b + 8 share an XCD, so the blocks of one XCD take RUNS of consecutive
+    // tiles - neighbouring tiles share 5 of their patch's 21 rows and 6 of its 70 columns; step k of block (x = b & 7, j = b >> 3) is tile
+    // (8 k + x) J + j, J = blocks per XCD.)
+    const int G = (int)gridDim.x, xcd = (int)blockIdx.x & 7, J = G >> 3;
+    const bool runs = (G & 7) == 0 && !(FCN_X4_LINEAR);
+    auto tile_of = [&](const int kk) __attribute__((always_inline)) { return runs ? (8 * kk + xcd) * J + ((int)blockIdx.x >> 3) : (int)blockIdx.x + kk * G; };
+    int step_k = 0;
+    int tile = tile_of(0);
+    issue_patch(tile, 0);
+    issue_patch(tile_of(1), 1);
     v4u breg[14][2];
 #pragma unroll
     for (int step = 0; step < 14; ++step)
@@ -1241,10 +1257,8 @@ __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kern
                 lo = *reinterpret_cast<const v2u*>(wh + ((size_t)co * 49 + r * 7 + q0) * 8);
                 if (q0 + 1 < 7) hi = *reinterpret_cast<const v2u*>(wh + ((size_t)co * 49 + r * 7 + q0 + 1) * 8);
             }
-            breg[step][nt] = v4u{lo[0], lo[1] & 0xffffu, hi[0], hi[1] & 0xffffu};
+            breg[step][nt] = v4u{lo[0], lo[1] & 0xffffu, hi[0], hi[1] & 0xffffu};      // (the fourth half - the constant channel's filter - is not multiplied)
         }
-    store_patch(0, px);
-    __syncthreads();      // the table and the first patch
     // ---- per-lane constants: fragment base (bytes), bias + the whole shift of this lane's two channels (windows inside the image)
     const char* a_lane = smem + ((4 * wave) * kD7Pw + 2 * nl + 2 * h) * 8;
     const float bias0 = (p.bias && 2 * nl < p.Cout) ? p.bias[2 * nl] : 0.f;
@@ -1252,12 +1266,19 @@ __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kern
     const v2f tall = *reinterpret_cast<const v2f*>(tab + (7 * 8 + 7) * 64 + 2 * nl);
     const float in0 = bias0 + tall[0], in1 = bias1 + tall[1];
     const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
-    char* epi = smem + kX4EpiOff + wave * (64 * kX4EpiPitch);
+    char* epi = smem + kX4EpiOff + wave * (32 * kX4EpiPitch);
     typedef float v16f __attribute__((ext_vector_type(16)));
+    // the filter loads above are older than nothing that matters: wait for the FIRST patch (this wave's 12 instructions of the second
+    // one may stay in flight), then publish it
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kX4PatchInstr / 4) : "memory");
+    __syncthreads();
     int buf = 0;
-    for (; tile < ntiles; tile += gridDim.x) {
-        fetch_patch(tile + (int)gridDim.x, px);      // the next tile's pixels travel while this tile multiplies
-        const char* a_base = a_lane + buf * kX4PatchBytes;
+    for (; tile < ntiles; tile = tile_of(++step_k)) {
+        {      // the patch two tiles ahead goes into the buffer the previous tile used (everybody left it at the last barrier)
+            const int b2 = buf + 2 >= kX4NBuf ? buf + 2 - kX4NBuf : buf + 2;
+            issue_patch(tile_of(step_k + 2), b2);
+        }
+        const char* a_base = a_lane + buf * kX4PatchPitch;
         v16f acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1281,8 +1302,12 @@ __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kern
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
+#ifdef FCN_X4_NOMFMA
+                    acc[mt][nt][0] += __builtin_bit_cast(float, fa[step % 3][mt][0] ^ breg[step][nt][0]);
+#else
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(v8h, fa[step % 3][mt]), __builtin_bit_cast(v8h, breg[step][nt]),
                                                                          acc[mt][nt], 0, 0, 0);
+#endif
         }
         int tq = tile;
         const int tx = tq % tiles_x;
@@ -1290,7 +1315,8 @@ __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kern
         const int ty = tq % tiles_y, n = tq / tiles_y;
         // windows of this tile that reach outside the image: rows 2 oy - 3 .. + 3, columns 2 ox - 3 .. + 3
         const bool border = ty == 0 || tx == 0 || 2 * (ty * kD7Th + kD7Th - 1) + 3 >= p.H || 2 * (tx * kD7Tw + kD7Tw - 1) + 3 >= p.W;
-        // ---- epilogue: register v of lane (nl, h) is pixel ox = (v & 3) + 8 (v >> 2) + 4 h, channels 2 nl (N-tile 0) and 2 nl + 1 (N-tile 1)
+        // ---- epilogue, one output row of the wave at a time: register v of lane (nl, h) is pixel ox = (v & 3) + 8 (v >> 2) + 4 h,
+        //      channels 2 nl (N-tile 0) and 2 nl + 1 (N-tile 1); through the LDS image whole 128-byte lines leave per store instruction
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int oy = ty * kD7Th + 2 * wave + mt;
@@ -1317,31 +1343,38 @@ __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kern
                 }
                 typedef f16_t v2h __attribute__((ext_vector_type(2)));
                 const v2h pk = {(f16_t)e0, (f16_t)e1};
-                *reinterpret_cast<v2h*>(epi + (mt * 32 + oxl) * kX4EpiPitch + nl * 4) = pk;
+                *reinterpret_cast<v2h*>(epi + oxl * kX4EpiPitch + nl * 4) = pk;
             }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave reads back its own image only)
-        __builtin_amdgcn_sched_barrier(0);
-        {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave reads back its own image only; LDS operations of a wave run in order)
+            __builtin_amdgcn_sched_barrier(0);
             const int c8 = (lane & 7) * 8;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int oy = ty * kD7Th + 2 * wave + mt;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int ox = (lane >> 3) + 8 * i;
-                    const v4f val = *reinterpret_cast<const v4f*>(epi + (mt * 32 + ox) * kX4EpiPitch + c8 * 2);
-                    if (oy < p.OH && tx * kD7Tw + ox < p.OW && c8 < p.Cout)
-                        *reinterpret_cast<v4f*>(yh + ((size_t)(n * p.OH + oy) * p.OW + tx * kD7Tw + ox) * p.y_cstride + p.y_coffset + c8) = val;
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int ox = (lane >> 3) + 8 * i;
+                const v4u val = *reinterpret_cast<const v4u*>(epi + ox * kX4EpiPitch + c8 * 2);
+                // (always ONE store instruction per i - lanes without an output take an out-of-range offset - so that the wait below can
+                //  count this iteration's stores whatever the tile)
+                const bool okp = oy < p.OH && tx * kD7Tw + ox < p.OW && c8 < p.Cout;
+                int vo = okp ? (((n * p.OH + oy) * p.OW + tx * kD7Tw + ox) * p.y_cstride + p.y_coffset + c8) * 2 : OOB;
+                asm volatile("" : "+v"(vo));
+#ifdef FCN_X4_NOSTORE
+                asm volatile("" ::"v"(val), "v"(vo));
+#else
+                __builtin_amdgcn_raw_buffer_store_b128(val, ry, vo, 0, 0);
+#endif
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the image is rewritten for the next row)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        store_patch(buf ^ 1, px);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // The next tile's patch - asked for one iteration ago, older than this iteration's 12 DMA instructions and 8 stores, and the
+        // vector-memory counter retires in order - has landed; everybody is done with this tile's patch: publish / release with one
+        // raw barrier (__syncthreads() would also wait for the tile's global stores: a write latency per tile).
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kX4PatchInstr / 4 + 8) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        buf ^= 1;
+        buf = buf + 1 == kX4NBuf ? 0 : buf + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (patches asked for past the last tile: all-zero loads, but they write this workgroup's LDS)
 #endif
 }
 
@@ -1717,7 +1750,9 @@ void launch_one_cfg(int cfg, const ConvP& p, int total, hipStream_t st) {
     if (cfg == kFirst7Cfg) {
         if (p.flags & FCN_CONV_F16) {      // persistent: one workgroup per CU (a wave per SIMD holds its filters in registers), each walks its share of the tiles
             static const bool x4_ok = !(getenv("FCN_FIRST7_X4") && atoi(getenv("FCN_FIRST7_X4")) == 0);      // (experiments: the 8-half kernel)
-            if ((p.flags & FCN_CONV_IMAGE_ONES) && x4_ok) {      // channels 3 and 4 are the constant 1: three multiplied channels, two workgroups per CU
+            const bool small = (long long)p.N * p.H * p.W * 16 < (1ll << 31) &&      // (32-bit buffer offsets in the 4-half kernel)
+                               (((long long)p.N * p.OH * p.OW - 1) * p.y_cstride + p.y_coffset + p.Cout) * 2 < (1ll << 31);
+            if ((p.flags & FCN_CONV_IMAGE_ONES) && x4_ok && small) {      // channels 3 and 4 are the constant 1: three multiplied channels, two workgroups per CU
                 const int grid = total < 2 * device_cus() ? total : 2 * device_cus();
                 hipLaunchKernelGGL(conv_first7_f16x4_kernel, dim3(grid), dim3(kD7Threads), 0, st, p, total);
                 return;
