@@ -1336,13 +1336,10 @@ __global__ __launch_bounds__(kD7Threads) FCN_X4_ATTR void conv_first7_f16x4_kern
                         b1 = bias1 + ((a[1] - bq[1]) - (cq[1] - dq[1]));
                     }
                 }
-                float e0 = acc[mt][0][v] + b0, e1 = acc[mt][1][v] + b1;
-                if (do_relu) {
-                    e0 = fmaxf(e0, 0.f);
-                    e1 = fmaxf(e1, 0.f);
-                }
                 typedef f16_t v2h __attribute__((ext_vector_type(2)));
-                const v2h pk = {(f16_t)e0, (f16_t)e1};
+                const v2f e = v2f{acc[mt][0][v], acc[mt][1][v]} + v2f{b0, b1};      // (one packed add, one packed conversion, one packed maximum:
+                v2h pk = {(f16_t)e[0], (f16_t)e[1]};                                  //  the kernel is bound by its vector instructions)
+                if (do_relu) pk = __builtin_elementwise_max(pk, v2h{(f16_t)0.f, (f16_t)0.f});      // (max after rounding = rounding after max)
                 *reinterpret_cast<v2h*>(epi + oxl * kX4EpiPitch + nl * 4) = pk;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the wave reads back its own image only; LDS operations of a wave run in order)
