@@ -31,7 +31,23 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__
     frame += (size_t)blockIdx.y * frame_stride;
     mm += 8 * blockIdx.y;
     int lo[3] = {255, 255, 255}, hi[3] = {0, 0, 0};
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
+    // Round 3: 48 bytes = 16 pixels per step as three 16-byte loads (one byte load per channel and pixel kept this pass at ~30 us for a
+    // batch of 32 frames); byte b of the 48 belongs to channel b % 3.  Frames that are not 16-byte aligned, and the tail, go bytewise.
+    const long long bytes = npix * 3;
+    const bool vec = (((size_t)frame) & 15) == 0;
+    const long long chunks = vec ? bytes / 48 : 0;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < chunks; q += (long long)gridDim.x * blockDim.x) {
+        const uint4* src = reinterpret_cast<const uint4*>(frame + q * 48);
+        const uint4 a = src[0], b = src[1], c = src[2];
+        const unsigned dw[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 48; ++k) {
+            const int v = (int)((dw[k >> 2] >> (8 * (k & 3))) & 0xffu);
+            lo[k % 3] = min(lo[k % 3], v);
+            hi[k % 3] = max(hi[k % 3], v);
+        }
+    }
+    for (long long p = chunks * 16 + (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long long)gridDim.x * blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int v = frame[p * 3 + c];
@@ -66,7 +82,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(const uint8_t* __restrict__
 constexpr int kMaxRois = 32;
 struct RoiTable { int n; int r[kMaxRois][4]; };
 
-template <typename D>
+template <typename D, bool ONES = false>
 __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restrict__ frame, int h, int w, D* __restrict__ dst, int H,
                                                           int W, int cstride, float shift, const int* __restrict__ mm, long long frame_stride,
                                                           long long dst_stride, const RoiTable rois) {
@@ -88,6 +104,15 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
         gmax = fmax(gmax, (double)mm[3 + c] - kMeanBGR[c]);
     }
     const double range = gmax - gmin;
+    // Round 3: the normalised value of a pixel depends on its byte and its channel only - a table of 3 x 256 doubles per workgroup holds
+    // (v - mean - min) / range, the SAME division the reference makes, once per value instead of twelve times per output pixel (four
+    // taps x three channels in float64: the divisions were most of this pass).
+    __shared__ double lut[3][256];
+    for (int e = threadIdx.x; e < 768; e += blockDim.x) {
+        const int c = e >> 8, v = e & 255;
+        lut[c][v] = ((double)v - kMeanBGR[c] - gmin) / range;
+    }
+    __syncthreads();
     const double scale_x = (double)w / (double)W, scale_y = (double)h / (double)H;
     const long long total = (long long)H * W;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
@@ -105,16 +130,24 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
         if (sy >= h - 1) { fy = 0.f; sy = h - 1; }
         const int sx1 = min(sx + 1, w - 1), sy1 = min(sy + 1, h - 1);
         const double a0 = (double)(1.f - fx), a1 = (double)fx, b0 = (double)(1.f - fy), b1 = (double)fy;
+        float out[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const double m = kMeanBGR[c];
-            const double s00 = ((double)frame[((size_t)sy * pitch + sx) * 3 + c] - m - gmin) / range;
-            const double s01 = ((double)frame[((size_t)sy * pitch + sx1) * 3 + c] - m - gmin) / range;
-            const double s10 = ((double)frame[((size_t)sy1 * pitch + sx) * 3 + c] - m - gmin) / range;
-            const double s11 = ((double)frame[((size_t)sy1 * pitch + sx1) * 3 + c] - m - gmin) / range;
+            const double s00 = lut[c][frame[((size_t)sy * pitch + sx) * 3 + c]];
+            const double s01 = lut[c][frame[((size_t)sy * pitch + sx1) * 3 + c]];
+            const double s10 = lut[c][frame[((size_t)sy1 * pitch + sx) * 3 + c]];
+            const double s11 = lut[c][frame[((size_t)sy1 * pitch + sx1) * 3 + c]];
             const double r0 = s00 * a0 + s01 * a1;
             const double r1 = s10 * a0 + s11 * a1;
-            dst[(size_t)t * cstride + c] = (D)((float)(r0 * b0 + r1 * b1) + shift);   // blob value rounded to f32 first, as Caffe's Power layer sees it
+            out[c] = (float)(r0 * b0 + r1 * b1) + shift;   // blob value rounded to f32 first, as Caffe's Power layer sees it
+        }
+        if (ONES) {      // the half image of the f16 engine: (b, g, r, 1, 1, 0, 0, 0) in ONE 16-byte store (three 2-byte stores 16 bytes apart before)
+            typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+            const h8 px = {(_Float16)out[0], (_Float16)out[1], (_Float16)out[2], (_Float16)1.f, (_Float16)1.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            *reinterpret_cast<h8*>(dst + (size_t)t * 8) = px;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dst[(size_t)t * cstride + c] = (D)out[c];
         }
     }
 }
@@ -124,7 +157,7 @@ __global__ __launch_bounds__(256) void resize_norm_kernel(const uint8_t* __restr
 extern "C" {
 
 static int preprocess_any(const uint8_t* frame, int n, int h, int w, void* dst, bool f16, int H, int W, int dst_cstride, float shift,
-                          float* d_minmax, fcn_stream_t s, const int32_t* h_rois = nullptr) {
+                          float* d_minmax, fcn_stream_t s, const int32_t* h_rois = nullptr, bool ones = false) {
     FCN_REQUIRE(frame && dst && d_minmax && n > 0 && n <= 65535 && h > 0 && w > 0 && H > 0 && W > 0 && dst_cstride >= 3, FCN_E_ARG,
                 "preprocess: bad args");
     RoiTable rois = {};
@@ -146,9 +179,18 @@ static int preprocess_any(const uint8_t* frame, int n, int h, int w, void* dst, 
     int mm_blocks = stream_grid((long long)h * w, 256 * 16);      // >= 16 pixels per lane: a few hundred workgroups at most
     if (mm_blocks > 256) mm_blocks = 256;
     hipLaunchKernelGGL(minmax_kernel, dim3(mm_blocks, frames), dim3(256), 0, st, frame, (long long)h * w, mm, fstride);
-    int rn_blocks = stream_grid((long long)H * W, 256);
+    FCN_REQUIRE(!ones || (f16 && dst_cstride == 8 && (((size_t)dst) & 15) == 0), FCN_E_ARG,
+                "preprocess: the constant-channel form needs a half image of 8-half pixels, 16-byte aligned");
+    // (the table of normalised values is built once per workgroup: 8 pixels per lane where the batch still fills the chip, fewer for a
+    //  single frame, whose pre-processing is latency)
+    int rn_blocks = stream_grid((long long)H * W, 256 * 8);
+    const int fine = stream_grid((long long)H * W, 256), want = (1024 + n - 1) / n;
+    if (rn_blocks < want) rn_blocks = want < fine ? want : fine;
     if (rn_blocks > 8192) rn_blocks = 8192;
-    if (f16)
+    if (ones)
+        hipLaunchKernelGGL((resize_norm_kernel<_Float16, true>), dim3(rn_blocks, n), dim3(256), 0, st, frame, h, w, reinterpret_cast<_Float16*>(dst), H, W,
+                           dst_cstride, shift, mm, fstride, dstride, rois);
+    else if (f16)
         hipLaunchKernelGGL(resize_norm_kernel<_Float16>, dim3(rn_blocks, n), dim3(256), 0, st, frame, h, w, reinterpret_cast<_Float16*>(dst), H, W,
                            dst_cstride, shift, mm, fstride, dstride, rois);
     else
@@ -171,12 +213,12 @@ int fcn_preprocess_bgr8_f16(const uint8_t* frame, int h, int w, void* dst, int H
 int fcn_preprocess_bgr8_rois(const uint8_t* frame, int h, int w, const int32_t* h_rois, int n, void* dst, int dst_f16, int H, int W,
                              int dst_cstride, float shift, float* d_minmax, fcn_stream_t s) {
     FCN_REQUIRE(h_rois, FCN_E_ARG, "preprocess_rois: null window list");
-    return preprocess_any(frame, n, h, w, dst, dst_f16 != 0, H, W, dst_cstride, shift, d_minmax, s, h_rois);
+    return preprocess_any(frame, n, h, w, dst, dst_f16 != 0, H, W, dst_cstride, shift, d_minmax, s, h_rois, (dst_f16 & 2) != 0);
 }
 
 int fcn_preprocess_bgr8_batch(const uint8_t* frames, int n, int h, int w, void* dst, int dst_f16, int H, int W, int dst_cstride, float shift,
                               float* d_minmax, fcn_stream_t s) {
-    return preprocess_any(frames, n, h, w, dst, dst_f16 != 0, H, W, dst_cstride, shift, d_minmax, s);
+    return preprocess_any(frames, n, h, w, dst, dst_f16 != 0, H, W, dst_cstride, shift, d_minmax, s, nullptr, (dst_f16 & 2) != 0);
 }
 
 }  // extern "C"

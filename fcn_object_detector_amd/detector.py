@@ -234,6 +234,13 @@ class FCNObjectDetector:
         self._minmax = DeviceBuffer(32)
         self._minmax_batch_holder: List[DeviceBuffer] = []
 
+    def _half_flag(self, data) -> int:
+        """dst_f16 of fcn_preprocess_bgr8_batch / _rois: 0 = float32 blob, 1 = half blob, 3 = the f16 engine's half image (8-half pixels
+        whose channels 3 and 4 are the constant 1): the kernel then writes whole pixels in one store."""
+        if data.esize != 2:
+            return 0
+        return 3 if data.name in getattr(self.engine, "_half_inputs", {}) and data.cstride == 8 and data.coffset == 0 else 1
+
     def run_detector_batch(self, frames: Sequence[np.ndarray]) -> List[Tuple[np.ndarray, np.ndarray]]:
         """BASELINE configs[4] minus the fp16 arithmetic: `batch` frames through pre-processing, ONE forward and ONE fused
         decode + groupRectangles launch ((image, class) per workgroup); per frame the result of run_detector."""
@@ -275,13 +282,12 @@ class FCNObjectDetector:
         eng = self.engine
         data = eng.blobs["data"]
         if same:      # one camera: the whole batch in three launches
-            L.call("fcn_preprocess_bgr8_batch", dev_ptr, len(layout), layout[0][1], layout[0][2], data.ptr, 1 if data.esize == 2 else 0,
+            L.call("fcn_preprocess_bgr8_batch", dev_ptr, len(layout), layout[0][1], layout[0][2], data.ptr, self._half_flag(data),
                    self.im_height, self.im_width, data.cstride, data.upload_shift, self._minmax_batch_holder[0].ptr, eng.stream)
         else:
             for i, (off, h, w) in enumerate(layout):
-                L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", dev_ptr + off, h, w,
-                       data.ptr + data.esize * i * self.im_height * self.im_width * data.cstride, self.im_height, self.im_width,
-                       data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
+                L.call("fcn_preprocess_bgr8_batch", dev_ptr + off, 1, h, w, data.ptr + data.esize * i * self.im_height * self.im_width * data.cstride,
+                       self._half_flag(data), self.im_height, self.im_width, data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
         eng.forward_enqueue()
         self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
         self.decoder.fetch_begin(eng.stream)
@@ -314,7 +320,7 @@ class FCNObjectDetector:
             stage[...] = frame.reshape(-1)
             data = eng.blobs["data"]
             L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, stage.ctypes.data, frame.nbytes, eng.stream)
-            L.call("fcn_preprocess_bgr8_rois", self._frame_dev.ptr, h, w, rects.ctypes.data, len(rects), data.ptr, 1 if data.esize == 2 else 0,
+            L.call("fcn_preprocess_bgr8_rois", self._frame_dev.ptr, h, w, rects.ctypes.data, len(rects), data.ptr, self._half_flag(data),
                    self.im_height, self.im_width, data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
             eng.forward_enqueue()
             self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
@@ -364,8 +370,8 @@ class FCNObjectDetector:
             stage[...] = frame.reshape(-1)
             data = eng.blobs["data"]
             L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, stage.ctypes.data, frame.nbytes, eng.stream)
-            L.call("fcn_preprocess_bgr8_f16" if data.esize == 2 else "fcn_preprocess_bgr8", self._frame_dev.ptr, h, w, data.ptr, self.im_height,
-                   self.im_width, data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
+            L.call("fcn_preprocess_bgr8_batch", self._frame_dev.ptr, 1, h, w, data.ptr, self._half_flag(data), self.im_height, self.im_width,
+                   data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
             eng.forward_enqueue()
             self.decoder.launch(*self._cvg_args, *self._box_args, eng.stream)
             self.decoder.fetch_begin(eng.stream)

@@ -229,6 +229,9 @@ int  fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C
  * fcn_preprocess_bgr8 (float64, float resize coefficients). */
 int  fcn_preprocess_bgr8_rois(const uint8_t* frame, int h, int w, const int32_t* h_rois, int n, void* dst, int dst_f16, int H, int W,
                               int dst_cstride, float shift, float* d_minmax, fcn_stream_t s);
+/* dst_f16 of the two calls below: 0 = float32 blob, 1 = half blob (channels 0..2 of every pixel are written, nothing else), 3 = the
+ * half image of an f16 engine - 8-half pixels whose channels 3 and 4 hold the constant 1 and 5..7 zero (FCN_CONV_IMAGE_ONES): the whole
+ * pixel (b, g, r, 1, 1, 0, 0, 0) leaves in ONE 16-byte store (dst_cstride must be 8, dst 16-byte aligned). */
 /* n equally sized frames (h*w*3 bytes apart) -> the n images of an N x H x W x dst_cstride blob in three launches;
  * each frame is normalised with its own min / max.  d_minmax: 32 bytes per frame. */
 int  fcn_preprocess_bgr8_batch(const uint8_t* frames, int n, int h, int w, void* dst, int dst_f16, int H, int W, int dst_cstride,

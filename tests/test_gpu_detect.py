@@ -307,3 +307,34 @@ def test_roi_preprocessing_refuses_windows_outside_the_frame(gpu):
         assert lib.fcn_preprocess_bgr8_rois(frame.ptr, 48, 64, rois.ctypes.data, 2, dst.ptr, 0, 32, 32, 4, 0.0, mm.ptr, None) == 1      # FCN_E_ARG
     too_many = np.tile(np.asarray([[0, 0, 8, 8]], np.int32), (33, 1))
     assert lib.fcn_preprocess_bgr8_rois(frame.ptr, 48, 64, too_many.ctypes.data, 33, dst.ptr, 0, 32, 32, 4, 0.0, mm.ptr, None) == 1      # FCN_E_ARG
+
+
+def test_preprocessing_writes_whole_half_pixels_when_asked(gpu):
+    """dst_f16 = 3 (the f16 engine's half image): every pixel leaves as (b, g, r, 1, 1, 0, 0, 0) in one store - channels 0..2 bit-equal to
+    the three-store form (dst_f16 = 1), which leaves the other channels alone; refused for other pixel widths."""
+    lib = L.load()
+    L.call("fcn_init", 0)
+    rng = np.random.default_rng(11)
+    n, h, w, H, W = 3, 37, 53, 24, 40
+    frames = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    src = DeviceBuffer(frames.nbytes, zero=False)
+    L.call("fcn_memcpy_h2d_async", src.ptr, frames.ctypes.data, frames.nbytes, None)
+    mm = DeviceBuffer(32 * n)
+    outs = []
+    for flag in (1, 3):
+        fill = np.full((n, H, W, 8), -7.0, np.float16)
+        dst = DeviceBuffer(fill.nbytes, zero=False)
+        L.call("fcn_memcpy_h2d_async", dst.ptr, fill.ctypes.data, fill.nbytes, None)
+        L.call("fcn_preprocess_bgr8_batch", src.ptr, n, h, w, dst.ptr, flag, H, W, 8, 0.0, mm.ptr, None)
+        got = np.empty_like(fill)
+        L.call("fcn_memcpy_d2h_async", got.ctypes.data, dst.ptr, got.nbytes, None)
+        L.call("fcn_device_sync")
+        outs.append(got)
+    assert np.array_equal(outs[0][..., :3], outs[1][..., :3])
+    assert np.all(outs[0][..., 3:] == np.float16(-7.0))
+    assert np.all(outs[1][..., 3:5] == np.float16(1.0)) and np.all(outs[1][..., 5:] == 0)
+    for i in range(n):      # and both equal the oracle's blob, rounded once to half
+        want = D.preprocess_frame(frames[i], W, H).transpose(1, 2, 0).astype(np.float16)
+        assert np.array_equal(outs[1][i, ..., :3], want)
+    dst4 = DeviceBuffer(n * H * W * 4 * 2)
+    assert lib.fcn_preprocess_bgr8_batch(src.ptr, n, h, w, dst4.ptr, 3, H, W, 4, 0.0, mm.ptr, None) != 0
