@@ -465,6 +465,9 @@ def main() -> None:
                                                              "(1 = one stream, launches strictly serial)")
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timing is repeated this many times inside the run: `value` is the median, "
                                                            "the spread rides beside it (a 200-step window is 40 ms: one sample says little)")
+    ap.add_argument("--no-io-region", action="store_true", help="skip SURVEY 8(d) config 2's own timed region (the hipGraph with the H2D / D2H copy nodes): "
+                    "the four-in-flight kernel-trace pass of tools/profile_bench.sh - that graph's launch segfaulted inside the HIP runtime "
+                    "under rocprofv3 on three of five runs in round 3 (never without the profiler); DESIGN.md 5")
     ap.add_argument("--trace-clean", action="store_true", help="kernel-trace passes of tools/profile_bench.sh: whole forwards only - no per-launch "
                                                                "event timing loops, one repeat - so that every kernel's calls = frames x its launches per frame")
     ap.add_argument("--no-secondary", action="store_true", help="skip the VGG16-FCN (train/fcn_bbox) measurements reported under 'secondary'")
@@ -544,11 +547,11 @@ def main() -> None:
         # SURVEY 8(d) config 2's own timed region: H2D of the (3,448,448) f32 frame from pinned host memory + layout change + all
         # kernels + D2H of the two head blobs - one frame at a time, and with `depth` frames in flight (every frame's copies ride on
         # its replica's stream and overlap the other replicas' kernels).  Never `value` (inputs resident in HBM there).
-        for _ in range(5):
-            eng.forward()
         n_io = max(min(args.steps, 200), 10) if not args.trace_clean else 5
-        io_one, io_fly = [], []
-        for _ in range(max(args.repeats, 1)):
+        io_one, io_fly = ([], []) if not args.no_io_region else ([0.0], [0.0])
+        for _ in range(5 if not args.no_io_region else 0):
+            eng.forward()
+        for _ in range(max(args.repeats, 1) if not args.no_io_region else 0):
             t1 = time.perf_counter()
             for _ in range(n_io):
                 eng.forward()
@@ -616,7 +619,7 @@ def main() -> None:
                            "spread_pct": round(100.0 * (max(rep_s) - min(rep_s)) / t_max, 2)},
                "config2_frames_per_s": round(pcie_fps, 2),
                "config2_frames_per_s_in_flight": round(pcie_fly_fps, 2),
-               "config2_timed_region": {"frames_per_s": round(pcie_fps, 2), "ms_per_frame": round(1e3 / pcie_fps, 4),
+               "config2_timed_region": {"frames_per_s": round(pcie_fps, 2), "ms_per_frame": round(1e3 / pcie_fps, 4) if pcie_fps else None,
                                         "frames_per_s_in_flight": round(pcie_fly_fps, 2), "frames_in_flight": depth,
                                         "repeats": {"one_at_a_time": [round(v, 1) for v in io_one], "in_flight": [round(v, 1) for v in io_fly]},
                                         "includes": "SURVEY 8(d) config 2: H2D of the (3,448,448) f32 frame (pinned host memory) + layout change + all kernels + "

@@ -41,7 +41,7 @@ prof ${TAG}_f16_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU
 unset FCN_NO_GRAPH
 prof ${TAG}_stats --stats -- python3 "$ROOT/bench.py" $ONE --no-train --trace-clean > "$OUT/${TAG}_bench_under_rocprof.json"
 rm -rf "$OUT/${TAG}_inflight"
-( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_inflight" -o run -- python3 "$ROOT/bench.py" $ARGS --no-train \
+( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_inflight" -o run -- python3 "$ROOT/bench.py" $ARGS --no-train --no-io-region \
     > "$OUT/${TAG}_bench_inflight_under_rocprof.json" ) 2> "$OUT/${TAG}_inflight.err" || echo "in-flight pass under rocprofv3 failed"
 [ -d "$OUT/${TAG}_stats" ] || { echo "graph-replay trace missing: using the plain-launch trace for the kernel statistics"; cp -r "$OUT/${TAG}_pstats" "$OUT/${TAG}_stats"; }
 for pair in stats:bench_kernel_stats pstats:bench_plain_kernel_stats tstats:train_kernel_stats fetch:bench_pmc_fetch write:bench_pmc_write mfma:bench_pmc_mfma tmfma:train_pmc_mfma \
@@ -51,7 +51,8 @@ for pair in stats:bench_kernel_stats pstats:bench_plain_kernel_stats tstats:trai
 done
 for pair in stats:bench_kernel_stats tstats:train_kernel_stats inflight:bench_inflight_kernel_stats f16_stats:infer32_f16_kernel_stats; do
     d=${pair%%:*}; o=${pair##*:}
-    f=$(find "$OUT/${TAG}_$d" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/${TAG}_$o.csv"
+    [ -d "$OUT/${TAG}_$d" ] || continue      # (a pass that failed leaves no directory: that must not end the script in front of the clean-up)
+    f=$(find "$OUT/${TAG}_$d" -name '*kernel_stats.csv' | head -1) || true; [ -n "$f" ] && cp "$f" "$OUT/${TAG}_$o.csv"
 done
 python3 - "$OUT" "$TAG" $N32 <<'PY'
 import json, sys
