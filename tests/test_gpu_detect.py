@@ -298,6 +298,34 @@ def test_run_detector2_windows_match_oracle(gpu, h, w, stride):
     eng.close()
 
 
+def test_run_detector2_on_the_half_float_engine(gpu):
+    """The window batch through the f16 engine: the windows are written as whole 8-half pixels (dst_f16 = 3: b, g, r and the two constant
+    channels of the folded Power shift), the first layer takes the constant-channel kernel; blob within half an f16 ulp of the oracle,
+    boxes bit-exact on the maps the GPU produced."""
+    msg = proto.parse_text(models.googlenet_detectnet_deploy(5, 160, 192, 2))
+    spec = NetSpec(msg, "TEST"); spec.infer()
+    params = fill_params(spec, seed=3)
+    rng = np.random.default_rng(21)
+    params["cvg/classifier"][1][...] = 1.5
+    params["bbox/regressor"][0][...] = 0
+    params["bbox/regressor"][1][...] = np.tile(np.array([-30, -25, 35, 40], np.float32), 2) + rng.normal(0, 0.5, 8).astype(np.float32)
+    eng = Engine(NetSpec(msg, "TEST"), params=params, device=0, autotune=False, dtype="f16")
+    det = FCNObjectDetector(eng, 0.5, 3, 0.2, HeadMapping.detectnet_deploy())
+    frame = rng.integers(0, 256, (301, 517, 3), dtype=np.uint8)
+    rects, res = det.run_detector2(frame, 2)
+    want, rrects = D.run_detector2_inputs(frame, 192, 160, 2)
+    assert np.array_equal(rects, np.asarray(rrects, dtype=np.int32))
+    assert np.abs(eng.read_blob("data") - want).max() <= 2.0 ** -11      # [0, 1] values rounded once to halves
+    cvg, bb = eng.read_blob("coverage"), eng.read_blob("bboxes")
+    total = 0
+    for i, (boxes, labels) in enumerate(res):
+        rdet, rlab = D.detect(cvg[i], bb[i], 192, 160, 16, 0.5, 3, 0.2, fast=True)
+        assert np.array_equal(boxes, D.window_boxes_to_frame(rrects[i], rdet, 192, 160)) and np.array_equal(labels, rlab), i
+        total += len(boxes)
+    assert total > 0
+    eng.close()
+
+
 def test_roi_preprocessing_refuses_windows_outside_the_frame(gpu):
     lib = L.load()
     L.call("fcn_init", 0)
