@@ -772,7 +772,11 @@ constexpr int kSplitCfg = kNumWgCfg;      // conv_wgrad_split_kernel: a region s
 // and walks the slabs with 16-byte loads, eight of them in flight at a time (the adds stay in slab order): every access is
 // a full 1 KiB wave-instruction.  Round 1 gave each output 16 lanes that read 4 bytes per slab - 256 B per wave-instruction,
 // 64 outputs per 1024-thread block, two barriers - and the pass cost 10 % of the training step (profiles/r01_train_*).
-constexpr int RED_THREADS = 256, RED_PER_BLOCK = RED_THREADS * 4;
+// Round 3: FOUR waves walk the slabs of one run of outputs (wave w takes the w-th quarter of the slabs, in order; the four quarter sums
+// are added as (Q0 + Q1) + (Q2 + Q3) through LDS): a small layer's matrix is a few hundred float4 columns, and with one lane walking all
+// of a column's 40-60 slabs eight loads at a time the pass was a handful of workgroups waiting for memory - as long as the MFMA launch it
+// follows (tools/wgrad_timeline.py: inception_4a's 1x1 group, kernel 20.9 us, kernel + reduction 41.8 us).  Still one fixed order.
+constexpr int RED_THREADS = 256, RED_WALKERS = 4, RED_PER_BLOCK = RED_THREADS / RED_WALKERS * 4;
 // How many slabs hold element i.  The role-split kernel gives the region classes of a problem their own split counts: weights
 // (i < wcount) by the class of (row, column) of the Cout x K matrix, the bias sums behind them by the class of their channel in
 // the first k-region.  Every other producer fills all slabs: uniform.
@@ -799,40 +803,63 @@ static RedSplits red_uniform(int splits) {
     RedSplits r = {0, 1, 0, 0, 0, 1, {splits, splits, splits, splits}};
     return r;
 }
+// i4: first of this lane's four outputs; walker: which quarter of the slabs this wave adds; red: RED_WALKERS x 64 float4 of LDS
 __device__ __forceinline__ void reduce_slabs(const float* __restrict__ parts, float* __restrict__ out, size_t count, const RedSplits& rs, size_t stride,
-                                             size_t i4) {
-    if (i4 >= count) return;
+                                             size_t i4, const int walker, float* red) {
     typedef float v4 __attribute__((ext_vector_type(4)));
-    const bool vec = i4 + 3 < count && (stride & 3) == 0 && (((size_t)parts | (size_t)out) & 15) == 0;
-    if (vec) {
-        const int splits = red_splits_for(rs, i4);      // (four consecutive elements share a class: K, wcount and the class borders are multiples of 4)
-        const v4* src = reinterpret_cast<const v4*>(parts + i4);
-        const size_t st4 = stride / 4;
-        v4 acc = src[0];
-        int k = 1;
-        for (; k + 7 < splits; k += 8) {
-            v4 v[8];
+    const int lane = threadIdx.x & 63;
+    const bool live = i4 < count;
+    const bool vec = live && i4 + 3 < count && (stride & 3) == 0 && (((size_t)parts | (size_t)out) & 15) == 0;
+    v4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        if (vec) {
+            const int splits = red_splits_for(rs, i4);      // (four consecutive elements share a class: K, wcount and the class borders are multiples of 4)
+            const int per = (splits + RED_WALKERS - 1) / RED_WALKERS;
+            const int k0 = walker * per, k1 = min(k0 + per, splits);
+            const v4* src = reinterpret_cast<const v4*>(parts + i4);
+            const size_t st4 = stride / 4;
+            int k = k0;
+            for (; k + 7 < k1; k += 8) {
+                v4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + j) * st4];
+                for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + j) * st4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += v[j];
-        }
-        for (; k < splits; ++k) acc += src[(size_t)k * st4];
-        *reinterpret_cast<v4*>(out + i4) = acc;
-    } else {
-        for (size_t i = i4; i < count && i < i4 + 4; ++i) {
-            const int splits = red_splits_for(rs, i);
-            float t = parts[i];
-            for (int k = 1; k < splits; ++k) t += parts[(size_t)k * stride + i];
-            out[i] = t;
+                for (int j = 0; j < 8; ++j) acc += v[j];
+            }
+            for (; k < k1; ++k) acc += src[(size_t)k * st4];
+        } else {
+            for (int e = 0; e < 4; ++e) {
+                const size_t i = i4 + e;
+                if (i >= count) break;
+                const int splits = red_splits_for(rs, i);
+                const int per = (splits + RED_WALKERS - 1) / RED_WALKERS;
+                const int k0 = walker * per, k1 = min(k0 + per, splits);
+                float t = 0.f;
+                for (int k = k0; k < k1; ++k) t += parts[(size_t)k * stride + i];
+                acc[e] = t;
+            }
         }
     }
+    reinterpret_cast<v4*>(red)[walker * 64 + lane] = acc;
+    __syncthreads();
+    if (walker == 0 && live) {
+        const v4* r = reinterpret_cast<const v4*>(red);
+        const v4 t = (r[lane] + r[64 + lane]) + (r[128 + lane] + r[192 + lane]);
+        if (vec) {
+            *reinterpret_cast<v4*>(out + i4) = t;
+        } else {
+            for (int e = 0; e < 4 && i4 + e < count; ++e) out[i4 + e] = t[e];
+        }
+    }
+    __syncthreads();      // (the grid-stride form reuses the scratch)
 }
 
 __global__ __launch_bounds__(RED_THREADS) void reduce_partials_kernel(const float* __restrict__ parts, float* __restrict__ out, size_t count,
                                                                       const RedSplits rs, size_t stride) {
-    for (size_t base = (size_t)blockIdx.x * RED_PER_BLOCK; base < count; base += (size_t)gridDim.x * RED_PER_BLOCK)
-        reduce_slabs(parts, out, count, rs, stride, base + (size_t)threadIdx.x * 4);
+    __shared__ __attribute__((aligned(16))) float red[RED_WALKERS * 64 * 4];
+    const int walker = threadIdx.x >> 6;
+    for (size_t base = (size_t)blockIdx.x * RED_PER_BLOCK; base < count; base += (size_t)gridDim.x * RED_PER_BLOCK)      // (uniform per workgroup)
+        reduce_slabs(parts, out, count, rs, stride, base + (size_t)(threadIdx.x & 63) * 4, walker, red);
 }
 
 struct ReduceGroupArgs {
@@ -860,7 +887,8 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_partials_group_kernel(cons
 #pragma unroll
     for (int i = 1; i < kMaxWgGroup; ++i)
         if (pi == i) { parts = a.parts[i]; out = a.out[i]; count = a.count[i]; stride = a.stride[i]; rs = a.rs[i]; }
-    reduce_slabs(parts, out, count, rs, stride, ((size_t)((int)blockIdx.x - begin) * RED_THREADS + threadIdx.x) * 4);
+    __shared__ __attribute__((aligned(16))) float red[RED_WALKERS * 64 * 4];
+    reduce_slabs(parts, out, count, rs, stride, ((size_t)((int)blockIdx.x - begin) * 64 + (threadIdx.x & 63)) * 4, threadIdx.x >> 6, red);
 }
 
 // wt[c][kh-1-r][kw-1-q][k] = w[k][r][q][c]   (w: [Cout][kh][kw][Cin4], wt: [Cin][kh][kw][Cout4], pads of wt zero)
