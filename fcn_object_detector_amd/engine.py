@@ -774,34 +774,67 @@ class Engine:
         return best, best_ms / 6.0
 
     def _split_level(self, chunk: List[dict]) -> List[List[dict]]:
-        """Half-float engines: one launch for the level's convolutions, or one for its 3x3 / 5x5 ones and one for its 1x1 ones?
-        Timed once per level at plan time; the decision rides in the tune cache beside the configurations."""
-        big = [it for it in chunk if it["desc"].kh > 1]
-        small = [it for it in chunk if it["desc"].kh == 1]
-        if not big or not small:
+        """Half-float engines: which launches carry a level's convolutions?  The streaming kernel's configurations are shaped for one
+        kind of problem or another (filter sizes, channel counts), so for the two to four convolutions of an inception level every way
+        of cutting the level into launches is priced - each subset's fastest configuration is timed once - and the cheapest cut is
+        kept (round 3; rounds 2-3a knew two cuts: one launch, or 3x3 / 5x5 beside 1x1).  The decision rides in the tune cache beside the
+        configurations, as a string of group labels ("001": the third convolution has a launch of its own)."""
+        n = len(chunk)
+        if n < 2 or n > 4:
             return [chunk]
         lib = L.load()
-        key = "split|" + self._tune_key("+".join(it["layer"].name for it in chunk))
-        if self._tune_from is not None and key in self._tune_from._chosen_cfgs:
+        key = "cut|" + self._tune_key("+".join(it["layer"].name for it in chunk))
+
+        def valid(code) -> bool:
+            return isinstance(code, str) and len(code) == n and all(ch.isdigit() and int(ch) < n for ch in code)
+
+        choice = None
+        if self._tune_from is not None and valid(self._tune_from._chosen_cfgs.get(key)):
             choice = self._tune_from._chosen_cfgs[key]
         else:
             cache = self._load_tune_cache()
-            if cache is not None and key in cache:
-                choice = int(cache[key])
-            else:
-                times = []
-                for part in (chunk, big, small):
+            if cache is not None and valid(cache.get(key)):
+                choice = cache[key]
+        if choice is None:
+            memo: Dict[Tuple[int, ...], float] = {}
+
+            def cost(sub: Tuple[int, ...]) -> float:
+                if sub not in memo:
+                    part = [chunk[i] for i in sub]
                     arr = (L.ConvDesc * len(part))(*[it["desc"] for it in part])
                     ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(part))), zero=False)
-                    times.append(self._time_conv_cfgs(arr, len(part), ws)[1])
+                    memo[sub] = self._time_conv_cfgs(arr, len(part), ws)[1]
                     L.call("fcn_conv2d_group_release", ws.ptr)
                     ws.free()
-                choice = 1 if times[1] + times[2] < times[0] else 0
-                if cache is not None:
-                    cache[key] = choice
-                    self._save_tune_cache()
+                return memo[sub]
+
+            def partitions(items: List[int]):      # set partitions as restricted-growth strings
+                def rec(i: int, labels: List[int], groups: int):
+                    if i == len(items):
+                        yield list(labels)
+                        return
+                    for g in range(groups + 1):
+                        labels.append(g)
+                        yield from rec(i + 1, labels, max(groups, g + 1))
+                        labels.pop()
+                yield from rec(0, [], 0)
+
+            best, best_ms = None, 1e30
+            for labels in partitions(list(range(n))):
+                groups = sorted(set(labels))
+                ms = sum(cost(tuple(i for i in range(n) if labels[i] == g)) for g in groups)
+                if ms < best_ms - 1e-7:
+                    best, best_ms = labels, ms
+            choice = "".join(str(g) for g in best)
+            cache = self._load_tune_cache()
+            if cache is not None:
+                cache[key] = choice
+                self._save_tune_cache()
         self._chosen_cfgs[key] = choice
-        return [big, small] if choice else [chunk]
+        groups: Dict[str, List[dict]] = {}
+        for it, g in zip(chunk, choice):
+            groups.setdefault(g, []).append(it)
+        return [groups[g] for g in sorted(groups)]
 
     def _loss_grad_ptr(self, blob: str) -> Optional[int]:
         """Device address the loss kernel writes d(loss)/d(blob) to; None in an inference engine."""
