@@ -527,7 +527,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // cannot see: nothing waits for them, their destination registers are dead, and the register allocator hands those
     // registers to the epilogue (the accumulator copies).  A read that returns late - LDS contended by a co-resident
     // kernel of another stream - then overwrites four consecutive accumulator copies AFTER v_accvgpr_read filled them:
-    // a 32-column x 4-register block of stale partial sums (tools/race_hunt3.py found it).  Retire them -
+    // a 32-column x 4-register block of stale partial sums (found in round 2 by diffing gradient blobs of repeated two-stream steps).  Retire them -
     // and keep the fragment registers ALIVE across the wait (frags_landed pins them and ends with a scheduling barrier):
     // a bare `s_waitcnt` asm orders memory operations only, and the scheduler did hoist the epilogue's v_accvgpr_read
     // into those registers above it (round 2: the two-stream determinism tests caught exactly that).

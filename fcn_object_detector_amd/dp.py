@@ -115,8 +115,10 @@ def env_device() -> int:
 def _single_node_job(world: int, master_addr: str) -> bool:
     """Every rank on this host?  LOCAL_WORLD_SIZE == WORLD_SIZE (torch.distributed.run sets both), or MASTER_ADDR names this host."""
     lws = os.environ.get("LOCAL_WORLD_SIZE")
-    if lws is not None and int(lws) == int(world):
-        return True
+    if lws is not None:
+        # a launcher that sets it has said how many ranks share this host: fewer than WORLD_SIZE is a multi-node job even on the
+        # node whose name MASTER_ADDR is (rank 0's own node: the name test below would call that job single-node)
+        return int(lws) == int(world)
     if master_addr in ("127.0.0.1", "localhost", "::1"):
         return True
     try:

@@ -1085,6 +1085,18 @@ class Engine:
             self.run_ops(self.stream)
             L.call("fcn_stream_sync", self.stream)
             self._warm = True
+        if with_io and not getattr(self, "_warm_io", False):
+            # the same for the kernels only the graph with the copy nodes holds: the layout converters of the upload and - never
+            # launched by anything else before the first forward() - of the download (round 3: a process whose first
+            # fcn_nhwc_to_nchw_f32 launch happened inside this capture died later in hipGraphLaunch under rocprofv3).
+            # The eager pass moves the same bytes the captured one will: the host arrays end up holding the outputs of the warm pass.
+            for nm in self.inputs:
+                if nm not in self.device_fed:
+                    self._enqueue_upload(nm, self.stream)
+            for nm in self.outputs:
+                self._enqueue_download(nm, self.stream)
+            L.call("fcn_stream_sync", self.stream)
+            self._warm_io = True
         L.call("fcn_graph_begin", self.stream)
         try:
             if with_io:

@@ -219,7 +219,10 @@ int  fcn_maxpool_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int
                          int y_cstride, int y_coffset, fcn_stream_t s);
 int  fcn_lrn_fwd_f16(const void* x, void* y, int pixels, int C, int x_cstride, int y_cstride, int local_size, float alpha, float beta,
                      float k, fcn_stream_t s);
-/* the half twin of fcn_maxpool_lrn5_fwd_f32 (8-channel groups); bit-identical to fcn_maxpool_fwd_f16 + fcn_lrn_fwd_f16 in either order */
+/* the half twin of fcn_maxpool_lrn5_fwd_f32 (8-channel groups).  Against fcn_maxpool_fwd_f16 + fcn_lrn_fwd_f16 run one after the other
+ * (either order): 3x3 / stride 2 / pad 0 poolings of at most 192 channels take an LDS-patch kernel whose LRN differs from the stand-alone
+ * one in the last float32 bit of scale^-beta on a few elements - fewer than 1e-4 of the outputs differ, each by ONE f16 ulp
+ * (tests/test_gpu_f16.py asserts exactly that bound); every other geometry is bit-identical to the two launches. */
 int  fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
                               int OH, int OW, int y_cstride, int lrn_first, float alpha, float beta, float lrn_k, fcn_stream_t s);
 /* n windows of ONE frame -> the n images of an N x H x W x dst_cstride blob: the node's multi-window path

@@ -238,3 +238,17 @@ def test_multi_node_master_addr_needs_an_explicit_bind(monkeypatch):
     monkeypatch.setenv("MASTER_PORT", str(_free_port()))
     with pytest.raises(RuntimeError, match="FCN_DP_BIND"):
         dp.ControlPlane(0, 2, timeout=1)
+
+
+def test_multi_node_job_on_the_master_node_itself_needs_an_explicit_bind(monkeypatch):
+    """Rank 0's own node of a two-node job: MASTER_ADDR names THIS host, but LOCAL_WORLD_SIZE (1) differs from WORLD_SIZE (2), so
+    the job is not single-node and rank 0 must not bind the loopback interface silently (the remote rank would time out)."""
+    import pytest
+    monkeypatch.delenv("FCN_DP_BIND", raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "1")
+    monkeypatch.setenv("MASTER_ADDR", socket.getfqdn())
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    assert dp._single_node_job(2, socket.getfqdn()) is False
+    assert dp._single_node_job(1, socket.getfqdn()) is True
+    with pytest.raises(RuntimeError, match="FCN_DP_BIND"):
+        dp.ControlPlane(0, 2, timeout=1)

@@ -107,13 +107,25 @@ def test_first_launch_of_every_kernel_happens_outside_the_stream_capture(gpu, mo
 
     for i, op in enumerate(eng.ops):
         op.run = (lambda st, f=op.run, i=i: (events.append(("op", i)), f(st))[1])
+    # the graph with the copy nodes also holds the layout converters of the upload and of the download (round 4: the download's
+    # kernel used to be launched for the first time INSIDE the capture - nothing else runs it before the first forward())
+    up, down = eng._enqueue_upload, eng._enqueue_download
+    eng._enqueue_upload = lambda nm, st: (events.append(("up", nm)), up(nm, st))[1]
+    eng._enqueue_download = lambda nm, st: (events.append(("down", nm)), down(nm, st))[1]
     monkeypatch.setattr(L, "call", spy)
-    eng.host_array("data")[...] = np.random.default_rng(0).random((1, 3, 96, 128), dtype=np.float32)
-    out = eng.forward()
+    x = np.random.default_rng(0).random((1, 3, 96, 128), dtype=np.float32)
+    eng.host_array("data")[...] = x
+    out = {k: v.copy() for k, v in eng.forward().items()}
     begin = events.index("fcn_graph_begin")
-    assert [e for e in events[:begin] if e != "fcn_graph_end"] == [("op", i) for i in range(len(eng.ops))]      # one eager pass first
-    assert events[begin + 1:begin + 1 + len(eng.ops)] == [("op", i) for i in range(len(eng.ops))]                # then the captured one
+    n_ops = len(eng.ops)
+    io = [("up", "data")] + [("down", nm) for nm in eng.outputs]
+    assert [e for e in events[:begin] if e != "fcn_graph_end"] == [("op", i) for i in range(n_ops)] + io      # one eager pass of everything first
+    assert events[begin + 1:begin + 2 + n_ops + len(eng.outputs)] == [("up", "data")] + [("op", i) for i in range(n_ops)] + io[1:]      # then the captured one
     assert np.isfinite(out["coverage"]).all()
+    again = eng.forward()                                   # a replay of the captured graph gives the same frame the same result
+    assert all(np.array_equal(again[k], out[k]) for k in out)
+    plain = eng.forward(use_graph=False)
+    assert all(np.array_equal(plain[k], out[k]) for k in out)
     monkeypatch.setattr(L, "call", real_call)
     eng.close()
 

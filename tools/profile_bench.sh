@@ -18,7 +18,8 @@ export TMPDIR=/tmp
 prof() {      # prof <dir> <rocprofv3 options...> -- <program...>   (the program itself follows `--`: never a wrapper)
     local d=$1; shift
     rm -rf "$OUT/$d"
-    ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/$d" -o run "$@" ) 2> "$OUT/$d.err" || { echo "pass $d FAILED:"; tail -5 "$OUT/$d.err"; return 0; }
+    local err="$OUT/$d.$(date +%H%M%S).err"      # never overwritten: a failing pass keeps its traceback (round 3 lost one to a later clean run)
+    ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/$d" -o run "$@" ) 2> "$err" || { echo "pass $d FAILED ($err):"; tail -5 "$err"; cp "$err" "$OUT/FAILED_$(basename "$err")"; return 0; }
 }
 ONE="$ARGS --in-flight 1"      # ONE frame in flight: per-kernel durations only mean something when launches do not overlap
 export PYTHONFAULTHANDLER=1
@@ -40,9 +41,9 @@ prof ${TAG}_f16_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU
 # the hipGraph replay itself, the launch path `value` is measured on: one frame in flight (what `roofline` is computed from), then four
 unset FCN_NO_GRAPH
 prof ${TAG}_stats --stats -- python3 "$ROOT/bench.py" $ONE --no-train --trace-clean > "$OUT/${TAG}_bench_under_rocprof.json"
-rm -rf "$OUT/${TAG}_inflight"
-( cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_inflight" -o run -- python3 "$ROOT/bench.py" $ARGS --no-train --no-io-region \
-    > "$OUT/${TAG}_bench_inflight_under_rocprof.json" ) 2> "$OUT/${TAG}_inflight.err" || echo "in-flight pass under rocprofv3 failed"
+# four frames in flight, config 2's region (the hipGraph with the copy nodes) included: round 3 ran this pass with --no-io-region after three
+# segmentation faults in that graph's launch; round 4 launches the I/O kernels eagerly before the capture (Engine._capture) and runs it whole, ONCE
+prof ${TAG}_inflight --stats -- python3 "$ROOT/bench.py" $ARGS --no-train > "$OUT/${TAG}_bench_inflight_under_rocprof.json"
 [ -d "$OUT/${TAG}_stats" ] || { echo "graph-replay trace missing: using the plain-launch trace for the kernel statistics"; cp -r "$OUT/${TAG}_pstats" "$OUT/${TAG}_stats"; }
 for pair in stats:bench_kernel_stats pstats:bench_plain_kernel_stats tstats:train_kernel_stats fetch:bench_pmc_fetch write:bench_pmc_write mfma:bench_pmc_mfma tmfma:train_pmc_mfma \
             inflight:bench_inflight_kernel_stats f16_stats:infer32_f16_kernel_stats f16_fetch:infer32_f16_pmc_fetch f16_write:infer32_f16_pmc_write f16_mfma:infer32_f16_pmc_mfma; do
