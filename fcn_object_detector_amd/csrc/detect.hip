@@ -29,7 +29,12 @@ namespace {
 
 constexpr int kDetThreads = 1024;
 constexpr int kDetWaves = kDetThreads / 64;
-constexpr int kMaxCand = 4096;  // LDS capacity: parent + count + 4 sums = 6 * 16 KiB
+// CANDIDATES (cells at or above the threshold) of one (image, class) the LDS holds: parent + count + 4 sums = 6 x 20 KiB, plus
+// 2 x 10 KiB of containment margins = 140 of the CU's 160 KiB.  Round 4: the bound is on the candidates, no longer on the grid -
+// every LDS structure is indexed by candidate, the per-cell planes live in the workspace - and 5120 covers the largest grid the
+// reference's own vectors hold with EVERY cell firing (640 x 480 at stride 8 = 4800 cells, fcn_object_detector.py:357-394).  A
+// class with more candidates than this reports out_count = -1 (FCN_DETECT_OVERFLOW): the caller raises, nothing is dropped silently.
+constexpr int kMaxCand = 5120;
 constexpr int kMaxBig = kMaxCand / 2;   // classes with n > groupThreshold >= 1 members: at most M / 2
 constexpr int kSliceMinCand = 192;      // below this many candidates one workgroup does the whole problem
 constexpr int kMaxSlices = 8;
@@ -156,6 +161,10 @@ __global__ __launch_bounds__(kDetThreads) void detect_kernel(DetP d) {
             rects[3 * G + at] = round_coord(y2, P.round_mode);  // read back as height (reference passes y2)
         }
         M += tot;
+    }
+    if (M > kMaxCand) {                              // (every slice of the problem sees the same M and takes the same exit)
+        if (tid == 0 && slice == 0) d.out_count[prob] = -1;
+        return;
     }
     if (any_nonzero) atomicOr(&s_any, 1);
     for (int i = tid; i < M; i += kDetThreads) {
@@ -466,7 +475,7 @@ int fcn_detect_decode_group(const float* cvg, const float* bbox, int batch, size
     FCN_REQUIRE(cvg && bbox && h_p && d_workspace && out_rects && out_weights && out_count && batch > 0, FCN_E_ARG, "detect: null/empty");
     const fcn_detect_params& P = *h_p;
     FCN_REQUIRE(P.num_classes > 0 && P.gy > 0 && P.gx > 0 && P.max_out > 0, FCN_E_ARG, "detect: bad grid/classes/max_out");
-    FCN_REQUIRE((long long)P.gy * P.gx <= kMaxCand, FCN_E_UNSUPPORTED, "detect: grid %dx%d exceeds %d cells", P.gy, P.gx, kMaxCand);
+    FCN_REQUIRE((long long)P.gy * P.gx < (1 << 24), FCN_E_UNSUPPORTED, "detect: grid %dx%d too large", P.gy, P.gx);
     FCN_REQUIRE(P.cvg_coffset >= 0 && P.cvg_cstride >= P.cvg_coffset + P.num_classes, FCN_E_ARG, "detect: coverage slice out of range");
     FCN_REQUIRE(P.box_coffset >= 0 && P.box_cstride >= P.box_coffset + 4 * P.num_classes, FCN_E_ARG, "detect: bbox slice out of range");
     FCN_REQUIRE(P.round_mode == FCN_RECT_ROUND_NEAREST_EVEN || P.round_mode == FCN_RECT_ROUND_TRUNCATE, FCN_E_ARG, "detect: bad round_mode");

@@ -102,6 +102,9 @@ class GridDecoder:
             for c in range(self.C):
                 slot = img * self.C + c
                 n = int(self.h_count[slot])
+                if n < 0:
+                    raise RuntimeError("decode: image %d, class %d has more candidate cells than the kernel's 5120 (include/fcnhip.h); "
+                                       "raise the detection threshold" % (img, c))
                 if n > self.params.max_out:
                     raise RuntimeError("detection overflow: %d clusters > max_out %d" % (n, self.params.max_out))
                 for r, wgt in zip(self.h_rects[slot, :n], self.h_weights[slot, :n]):

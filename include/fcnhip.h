@@ -322,7 +322,9 @@ typedef struct fcn_detect_params {
  * cluster order), out_weights[slot][max_out] int32 (cluster size n; the reference's confidence is
  * log(n)), out_count[slot] int32 (may exceed max_out: then only max_out entries were stored).
  * Concatenating the slots of one image in class order reproduces the reference's nested loops
- * (fcn_object_detector.py:104-118).  Grids up to 4096 cells.  d_workspace:
+ * (fcn_object_detector.py:104-118).  Any grid; at most 5120 CANDIDATES (cells at or above prob_thresh) per (image, class) -
+ * enough for every cell of a 640 x 480 frame at stride 8 - beyond which that slot's out_count is -1 and nothing else of the
+ * slot is written.  d_workspace:
  * fcn_detect_workspace_bytes() bytes; image strides are in floats. */
 size_t fcn_detect_workspace_bytes(const fcn_detect_params* h_p, int batch);
 int  fcn_detect_decode_group(const float* cvg, const float* bbox, int batch,

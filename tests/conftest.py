@@ -49,3 +49,19 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def elem_err(a, b, tol=1e-3):
+    """Element-wise criterion beside rel_err: every element must satisfy
+    |a - b| <= tol * |b| + tol * rms(b).  rel_err normalises by the blob's LARGEST value, so in a blob that spans orders of
+    magnitude (`bboxes`, parameter gradients) a small element may be off by far more than `tol` of itself and still pass;
+    here the allowance of an element is `tol` of its own magnitude plus `tol` of the blob's typical magnitude (the rms term
+    covers sums that cancel to ~0).  Returns (worst ratio |a-b| / allowance, flat index of the worst element): <= 1 passes."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    if a.size == 0:
+        return 0.0, -1
+    allow = tol * np.abs(b) + tol * max(float(np.sqrt(np.mean(b * b))), 1e-30)
+    r = np.abs(a - b) / allow
+    i = int(np.argmax(r))
+    return float(r[i]), i

@@ -81,6 +81,25 @@ def test_detect_edge_cases(gpu):
     assert check(half, hb, 448, 16) == 1 and check(half, hb, 448, 16, mode="trunc") == 1
 
 
+def test_detect_grids_beyond_4096_cells(gpu):
+    """Round 4: the kernel's bound is on a class's CANDIDATES (5120, the LDS), not on the grid.  640 x 480 at stride 8 - the node's
+    camera frame on the stride-8 heads (fcn_object_detector.py:357-394), 4800 cells - with EVERY cell firing, in both rounding
+    modes; a 6400-cell grid with ordinary scenes; and the same grid with every cell firing, which must be refused loudly."""
+    rng = np.random.default_rng(11)
+    gy, gx, stride = 60, 80, 8
+    full = np.ones((1, 1, gy, gx), np.float32)
+    fb = (rng.standard_normal((1, 4, gy, gx)) * 6).astype(np.float32)
+    fb[0, 2:] += 40
+    for mode, lmode in (("nearest_even", L.RECT_ROUND_NEAREST_EVEN), ("trunc", L.RECT_ROUND_TRUNCATE)):
+        got = detect_from_maps(full, fb, gx * stride, gy * stride, round_mode=lmode)
+        rdet, rlab = D.detect(full[0], fb[0], gx * stride, gy * stride, stride, 0.5, 3, 0.2, mode, fast=True)
+        assert len(rdet) > 0 and np.array_equal(got[0][0], rdet) and np.array_equal(got[0][1], rlab)
+    cvg, bb = synth_maps(rng, 2, 3, 80, 80, 8, n_obj=6)
+    assert check(cvg, bb, 640, 8) > 0
+    with pytest.raises(RuntimeError, match="5120"):
+        detect_from_maps(np.ones((1, 1, 80, 80), np.float32), np.ones((1, 4, 80, 80), np.float32), 640, 640)
+
+
 def test_targets_kats_and_random(gpu):
     fg, bl, sl, ol, cl = generate_targets([[(100, 120, 80, 60)]], [[0]], 448, 448, 16, 1)
     assert int(fg.sum()) == 28 and bl[0, :, 8, 7].tolist() == [-12.0, -8.0, 68.0, 52.0]

@@ -9,7 +9,7 @@ so that the random-weight net emits detections (every class has candidates; the 
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import elem_err, rel_err
 from fcn_object_detector_amd import models, proto
 from fcn_object_detector_amd.detector import FCNObjectDetector, HeadMapping
 from fcn_object_detector_amd.engine import Engine
@@ -70,6 +70,9 @@ def test_config2_train_step_batch8_448(gpu):
     assert abs(out["total_loss"] - ref.total_loss()) < 1e-3 * abs(ref.total_loss())
     for name in ("coverage", "bboxes", "pool5/drop_s1", "inception_4a/output", "conv2/norm2"):
         assert rel_err(eng.read_blob(name), ref.blobs[name]) < 1e-3, name
+    for name in ("coverage", "bboxes"):      # the head blobs element by element: |a - b| <= 1e-3 |b| + 1e-3 rms(b)
+        worst, at = elem_err(eng.read_blob(name), ref.blobs[name])
+        assert worst <= 1.0, (name, worst, at)
     # (3) backward of the heads and the top of the net, on the device's own activations
     adopt_device_activations(ref, eng, spec, keep=data)
     grads = ref.backward(stop_at="inception_5a/3x3_reduce")
@@ -80,6 +83,7 @@ def test_config2_train_step_batch8_448(gpu):
     for name in ("bbox/regressor", "cvg/classifier", "inception_5b/1x1", "inception_5b/3x3", "inception_5b/5x5_reduce", "inception_5a/pool_proj"):
         for g, r in zip(got[name], grads[name]):
             assert g.shape == r.shape and rel_err(g, r) < 1e-3, name
+            assert elem_err(g, r)[0] <= 1.0, (name, elem_err(g, r))
             checked += 1
     assert checked == 12
     eng.close()
@@ -137,22 +141,48 @@ def test_full_backward_448_to_conv1_and_an_independent_oracle_step(gpu, capsys):
             pool_flips += int((np.asarray(ref.aux[l.name]) != dev_idx).sum())
     ind_err = {name: max(rel_err(g, r) for g, r in zip(got[name], ind[name])) for name in ind}
     worst = max(ind_err, key=ind_err.get)
+    # The decomposition (round 4): the SAME independent oracle pass - its own activations, its own ReLU
+    # masks - but with the DEVICE's pooling argmaxes in place of its own.  If the excursion above 1e-3 is the argmax flips and
+    # nothing else, this residual is under 1e-3 for every parameter blob; what is left of it is the handful of ReLU flips and
+    # the forward rounding itself.
+    own_aux = {}
+    for l in spec.layers:
+        if l.type == "Pooling" and str(l.sub("pooling_param").get("pool", "MAX")) == "MAX":
+            k, s_, p_ = (int(l.sub("pooling_param").get(q, d)) for q, d in (("kernel_size", 0), ("stride", 1), ("pad", 0)))
+            own_aux[l.name] = ref.aux[l.name]
+            ref.aux[l.name] = R.max_pool(eng.read_blob(l.bottoms[0]), k, s_, p_, return_index=True)[1]
+    adopted = ref.backward()
+    ref.aux.update(own_aux)
+    ado_err = {name: max(rel_err(g, r) for g, r in zip(got[name], adopted[name])) for name in adopted}
+    ado_worst = max(ado_err, key=ado_err.get)
     with capsys.disabled():
         print("\nindependent oracle step, batch %d at %dx%d: ReLU mask flips %d of %d (%.2e), MAX-pool argmax flips %d of %d (%.2e); "
-              "parameter-gradient rel. error: median %.2e, max %.2e (%s)" % (
+              "parameter-gradient rel. error: median %.2e, max %.2e (%s); with ONLY the device's argmaxes adopted: median %.2e, max %.2e (%s); "
+              "%s itself %.2e -> %.2e" % (
                   n, size, size, relu_flips, relu_sites, relu_flips / relu_sites, pool_flips, pool_sites, pool_flips / pool_sites,
-                  float(np.median(list(ind_err.values()))), ind_err[worst], worst))
+                  float(np.median(list(ind_err.values()))), ind_err[worst], worst,
+                  float(np.median(list(ado_err.values()))), ado_err[ado_worst], ado_worst, worst, ind_err[worst], ado_err[worst]))
     # measured (MI355X, round 3): 8 of 28.5 M ReLU sites (2.8e-7), 3587 of 13.0 M argmaxes (2.8e-4); gradients: median 2.9e-4, max 1.7e-3
     assert relu_flips <= 1e-5 * relu_sites and pool_flips <= 1e-3 * pool_sites      # a handful of near-zero / near-tied sites ...
-    assert max(ind_err.values()) < 5e-3 and float(np.median(list(ind_err.values()))) < 1e-3      # ... and what they do to the gradients
+    # ... whose whole effect on the gradients is the argmax flips: with the device's argmaxes (and nothing else of the device's)
+    # every parameter gradient of the independent pass is within the north-star tolerance
+    assert max(ado_err.values()) < 1e-3, (ado_worst, ado_err[ado_worst])
+    assert float(np.median(list(ind_err.values()))) < 1e-3
 
     # (a) the whole backward on the device's activations: identical masks and argmaxes, what is left is the backward arithmetic
     adopt_device_activations(ref, eng, spec, keep=data)
     grads = ref.backward()
     assert set(grads) == set(got) and len(grads) == 59
+    worst_elem = (0.0, None)
     for name in grads:
         for g, r in zip(got[name], grads[name]):
             assert g.shape == r.shape and rel_err(g, r) < 1e-3, name
+            e = elem_err(g, r)[0]      # element by element: |a - b| <= 1e-3 |b| + 1e-3 rms(b)
+            assert e <= 1.0, (name, e)
+            worst_elem = max(worst_elem, (e, name))
+    with capsys.disabled():
+        print("whole backward on the device's activations: worst element of any of the 118 parameter blobs uses %.3f of its allowance "
+              "(1e-3 |b| + 1e-3 rms(b)), in %s" % worst_elem)
     # (blob gradients of the stem; a concatenation's gradient is not compared: the device applies the ReLU masks of the four
     #  producing convolutions to it in place, the oracle keeps the gradient of the concatenated blob)
     for name in ("conv1/7x7_s2", "pool1/3x3_s2", "pool1/norm1", "conv2/3x3_reduce", "conv2/3x3", "conv2/norm2", "pool2/3x3_s2"):
