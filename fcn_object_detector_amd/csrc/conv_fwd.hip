@@ -1528,7 +1528,9 @@ bool dot1x1_ok(const ConvP* ps, int n) {
     X(26, 1, 1, 2, 2, 1, 32, 16 + 4, true)  \
     X(27, 1, 1, 1, 1, 4, 32, 16 + 6, true)  \
     X(28, 1, 1, 2, 2, 1, 64, 16 + 4, true)  \
-    X(29, 2, 1, 2, 2, 1, 32, 16 + 4, true)
+    X(29, 2, 1, 2, 2, 1, 32, 16 + 4, true)  \
+    X(30, 1, 1, 1, 1, 8, 64, 16 + 4, true)  \
+    X(31, 1, 1, 2, 1, 4, 64, 16 + 4, true)
 
 struct TileCfg { int bm, bn, bk; bool prefetch; };
 constexpr int kCfgThreads[] = {
@@ -1546,7 +1548,11 @@ constexpr int kCfgWavesK[] = {
     FCN_CONV_CONFIGS(X)
 #undef X
 };
-constexpr int kNumTileCfg = 30;            // configurations of the implicit-GEMM kernel (the X table)
+// Round 4, configurations 30 / 31 - sixteen waves on ONE tile: at M = 784 a launch is one 32 x 32 tile per CU whose K loop is a chain of
+// chunks (barrier, LDS-DMA issue, first-use latency) that a second workgroup on the CU would overlap - but there is no second
+// workgroup (250 tiles for 256 CUs).  Eight multiplying and eight loading waves share a 64-float chunk: half the chunks (barriers)
+// per tile and two multiplier waves per SIMD, i.e. the occupancy of two workgroups spent on one tile's chain (64 / 96 KiB of LDS).
+constexpr int kNumTileCfg = 32;            // configurations of the implicit-GEMM kernel (the X table)
 constexpr int kFirst7Cfg = kNumTileCfg;    // conv_first7_kernel: single 7x7 / stride 2 / 4-channel problems only (first7_ok)
 constexpr int kDot1x1Cfg = kNumTileCfg + 1;  // conv_dot1x1_kernel: groups of narrow 1x1 problems only (dot1x1_ok)
 constexpr int kStreamCfg0 = kNumTileCfg + 2;  // conv_stream_f16 (conv_stream.hip): persistent half-float streaming kernel, configurations 32 ..

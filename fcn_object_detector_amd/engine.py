@@ -535,6 +535,7 @@ class Engine:
             else:
                 lv = i            # strict layer order, one launch per layer
             levels.append(lv)
+        self._move_floaters(tasks, levels, hit)
         order = sorted(range(len(tasks)), key=lambda i: (levels[i], 0 if tasks[i]["kind"] == "op" else 1, i))
 
         def emit_group(chunk: List[dict], fused: List[dict]) -> None:
@@ -772,6 +773,82 @@ class Engine:
             if ms.value < best_ms:
                 best, best_ms = cfg, ms.value
         return best, best_ms / 6.0
+
+    def _move_floaters(self, tasks: List[dict], levels: List[int], hit) -> None:
+        """Float engines: which LEVEL carries a convolution that nobody waits for?  An inception module is two levels -
+        {1x1, 3x3_reduce, 5x5_reduce} (+ the module's pooling) and {3x3, 5x5, pool_proj} - but the plain 1x1 branch is read by
+        nothing before the NEXT module: it may ride in either launch.  In the first it makes a latency-bound launch wider (at
+        28 x 28 the reduce level is one 32 x 32 tile per CU whichever way); in the second its short tiles fill the CUs beside the
+        long 3x3 tiles.  Every placement of a level's floaters is priced - both launches with their fastest configurations, timed
+        once - and the cheapest kept (round 4; the decision rides in the tune cache as a string of 0 / 1 per floater)."""
+        if not (self.autotune and self.group_convs and self.fuse) or self.f16 or self.spec.phase != "TEST" or os.environ.get("FCN_LEVEL_MOVE", "1") == "0":
+            return
+        lib = L.load()
+        nlev = max(levels) + 1 if levels else 0
+        for lv in range(nlev - 1):
+            a_idx = [i for i in range(len(tasks)) if levels[i] == lv and tasks[i]["kind"] == "conv"]
+            b_idx = [i for i in range(len(tasks)) if levels[i] == lv + 1 and tasks[i]["kind"] == "conv"]
+            if len(a_idx) < 2 or not b_idx or len(a_idx) > 8:
+                continue
+
+            def floats(i: int) -> bool:      # nothing of the next level reads or overwrites its output, or overwrites its input
+                ti = tasks[i]
+                return not any(levels[j] == lv + 1 and (hit(tj["reads"], ti["writes"]) or hit(tj["writes"], ti["writes"]) or hit(ti["reads"], tj["writes"]))
+                               for j, tj in enumerate(tasks) if j != i)
+
+            fl = [i for i in a_idx if floats(i)]
+            if not fl or len(fl) > 3 or len(b_idx) + len(fl) > 8:
+                continue
+            key = "move|" + self._tune_key("+".join(tasks[i]["layer"].name for i in a_idx) + ">" + "+".join(tasks[i]["layer"].name for i in b_idx))
+
+            def valid(code) -> bool:
+                return isinstance(code, str) and len(code) == len(fl) and set(code) <= {"0", "1"} and (len(fl) < len(a_idx) or "0" in code)
+
+            choice = None
+            if self._tune_from is not None and valid(self._tune_from._chosen_cfgs.get(key)):
+                choice = self._tune_from._chosen_cfgs[key]
+            else:
+                cache = self._load_tune_cache()
+                if cache is not None and valid(cache.get(key)):
+                    choice = cache[key]
+            if choice is None:
+                pools = {l2: [t["pool_desc"] for j, t in enumerate(tasks) if levels[j] == l2 and t["kind"] == "op" and t.get("pool_desc") is not None][:2]
+                         for l2 in (lv, lv + 1)}
+                memo: Dict[Tuple[int, Tuple[int, ...]], float] = {}
+
+                def cost(l2: int, sub: Tuple[int, ...]) -> float:
+                    if (l2, sub) not in memo:
+                        arr = (L.ConvDesc * len(sub))(*[tasks[i]["desc"] for i in sub])
+                        pl = pools[l2]
+                        parr = (L.PoolDesc * max(len(pl), 1))(*pl)
+                        ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(sub))), zero=False)
+                        memo[(l2, sub)] = min(self._time_conv_cfgs(arr, len(sub), ws, parr, len(pl))[1] for _ in range(2))
+                        L.call("fcn_conv2d_group_release", ws.ptr)
+                        ws.free()
+                    return memo[(l2, sub)]
+
+                best, best_ms, base_ms = "0" * len(fl), None, None
+                for code in range(1 << len(fl)):
+                    moved = [fl[b] for b in range(len(fl)) if code >> b & 1]
+                    stay = tuple(i for i in a_idx if i not in moved)
+                    if not stay:
+                        continue
+                    ms = cost(lv, stay) + cost(lv + 1, tuple(b_idx + moved))
+                    if code == 0:
+                        base_ms = ms
+                    if best_ms is None or ms < best_ms:
+                        best, best_ms = "".join("1" if code >> b & 1 else "0" for b in range(len(fl))), ms
+                if base_ms is not None and best_ms > 0.97 * base_ms:      # (timing noise: a move must be worth 3 % of the pair)
+                    best = "0" * len(fl)
+                choice = best
+                cache = self._load_tune_cache()
+                if cache is not None:
+                    cache[key] = choice
+                    self._save_tune_cache()
+            self._chosen_cfgs[key] = choice
+            for b, i in enumerate(fl):
+                if choice[b] == "1":
+                    levels[i] = lv + 1
 
     def _split_level(self, chunk: List[dict]) -> List[List[dict]]:
         """Half-float engines: which launches carry a level's convolutions?  The streaming kernel's configurations are shaped for one

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import CFG_STREAM0, rel_err
 from fcn_object_detector_amd import lib as L
 from fcn_object_detector_amd.engine import DeviceBuffer
 from gpu_util import conv_desc, dev_from, dev_to
@@ -51,13 +51,16 @@ def f16_conv(x, wt, b, pad, stride, flags, out_f32, y_cstride=None, y_coffset=0)
     return y
 
 
-STREAM_CFGS = [32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42]      # conv_stream_f16: persistent workgroups, 256-pixel tiles x 128 / 64 channels, 128 x 192
-# (slab rows, slab buffers) per configuration: 32/33 take 3x3 and 5x5 launches, 34/35 1x1 launches, 36/37 mixed 1x1 + 3x3, 38 all three
-_STREAM_SHAPE = {32: (304, 2, 256), 33: (304, 2, 256), 34: (256, 3, 256), 35: (256, 4, 256), 36: (288, 3, 256), 37: (288, 3, 256), 38: (304, 3, 256),
-                 39: (160, 2, 128), 40: (160, 3, 128), 41: (160, 3, 128), 42: (160, 4, 128)}      # (slab rows, slab buffers, pixels per tile)
+# conv_stream_f16 (configurations CFG_STREAM0 ..): persistent workgroups, 256-pixel tiles x 128 / 64 channels, 128 x 192
+# (slab rows, slab buffers, pixels per tile) per configuration, in order: +0/+1 take 3x3 and 5x5 launches, +2/+3 1x1 launches, +4/+5 mixed 1x1 + 3x3,
+# +6 all three, +7 .. +10 the 128-pixel tiles
+_STREAM_SHAPES = [(304, 2, 256), (304, 2, 256), (256, 3, 256), (256, 4, 256), (288, 3, 256), (288, 3, 256), (304, 3, 256),
+                  (160, 2, 128), (160, 3, 128), (160, 3, 128), (160, 4, 128)]
+STREAM_CFGS = [CFG_STREAM0 + i for i in range(len(_STREAM_SHAPES))]
+_STREAM_SHAPE = dict(zip(STREAM_CFGS, _STREAM_SHAPES))
 
 
-@pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15", "23", "24", "26", "29"])
+@pytest.mark.parametrize("cfg", [None, "2", "5", "8", "10", "13", "14", "15", "23", "24", "26", "29", "30", "31"])
 @pytest.mark.parametrize("case", CASES)
 def test_f16_conv_matches_oracle_on_the_same_rounded_inputs(gpu, monkeypatch, case, cfg):
     if cfg is None:
@@ -196,19 +199,19 @@ def test_stream_kernel_refuses_what_it_does_not_cover(gpu):
     ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(1)), zero=False)
     grp = L.ConvGroup()
     q = _stream_problem(rng, 64, 33, 1, 0, 8, 8, 1, y_cstride=40)        # Cout not a multiple of 8
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 34, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, CFG_STREAM0 + 2, C.byref(grp)) != 0
     q = _stream_problem(rng, 8, 64, 7, 3, 40, 40, 1)                      # 7x7 filters
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, CFG_STREAM0, C.byref(grp)) != 0
     q = _stream_problem(rng, 64, 64, 3, 1, 20, 8, 1)                      # image rows of 8:  the padded slab of a tile does not fit
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, CFG_STREAM0, C.byref(grp)) != 0
     q = _stream_problem(rng, 64, 64, 1, 0, 8, 8, 1)                       # 1x1 filters need three slab buffers
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 32, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, CFG_STREAM0, C.byref(grp)) != 0
     q["desc"].flags |= L.CONV_OUT_F32                                     # float32 output (the detection heads)
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, 34, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(q["desc"]), 1, ws.ptr, CFG_STREAM0 + 2, C.byref(grp)) != 0
     x = dev_from(np.zeros((1, 8, 8, 64), np.float32))                     # float32 problems never take it
     wt, yd = dev_from(np.zeros((64, 1, 1, 64), np.float32)), dev_from(np.zeros((1, 8, 8, 64), np.float32))
     d = conv_desc(x, wt, None, yd, 1, 8, 8, 64, 64, 64, 1, 0, 1, 8, 8, 64, 0, 0)
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d), 1, ws.ptr, 34, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d), 1, ws.ptr, CFG_STREAM0 + 2, C.byref(grp)) != 0
 
 
 def test_f16_group_with_fused_pool_and_sigmoid_head(gpu):

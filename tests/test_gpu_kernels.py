@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import CFG_DOT1X1, CFG_FIRST7, N_TILE_CFGS, rel_err
 from fcn_object_detector_amd import lib as L
 from fcn_object_detector_amd.engine import DeviceBuffer
 from gpu_util import conv_desc, dev_from, dev_to, nchw, nhwc, pack_ohwi
@@ -53,7 +53,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [str(i) for i in range(30)] + [None])      # every tile configuration, the split-role ones (23..29) included
+@pytest.mark.parametrize("cfg", [str(i) for i in range(N_TILE_CFGS)] + [None])      # every tile configuration, the split-role ones (23..31) included
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_matches_oracle(gpu, monkeypatch, case, cfg):
     cin, cout, k, s, p, h, w, n = case
@@ -308,7 +308,7 @@ def test_first_layer_kernel_matches_oracle(gpu, n, h, w, cout, relu):
     ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(1)), zero=False)
     grp = L.ConvGroup()
     L.call("fcn_conv2d_group_prepare", arr, 1, ws.ptr, 30, C.byref(grp))
-    assert grp.cfg == 30 and grp.total_tiles == n * ((oh + 7) // 8) * ((ow + 31) // 32)
+    assert grp.cfg == CFG_FIRST7 and grp.total_tiles == n * ((oh + 7) // 8) * ((ow + 31) // 32)
     L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
     full = dev_to(yd, (n, oh, ow, cout + 4))
     ref = R.conv2d(x, wt, b, 3, 2)
@@ -318,7 +318,7 @@ def test_first_layer_kernel_matches_oracle(gpu, n, h, w, cout, relu):
     assert np.all(full[..., :4] == 7.0)      # the channels in front of the slice are not touched
     # auto-selection (no autotune) picks it for this shape; a 3x3 problem is refused for configuration 30
     L.call("fcn_conv2d_group_prepare", arr, 1, ws.ptr, -1, C.byref(grp))
-    assert grp.cfg == 30
+    assert grp.cfg == CFG_FIRST7
     d3 = conv_desc(xd, wd, bd, yd, n, h, w, 4, 4, cout, 3, 1, 1, h, w, cout + 4, 4, 0)
     assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d3), 1, ws.ptr, 30, C.byref(grp)) != 0
     L.call("fcn_conv2d_group_release", ws.ptr)
@@ -326,7 +326,7 @@ def test_first_layer_kernel_matches_oracle(gpu, n, h, w, cout, relu):
 
 @pytest.mark.parametrize("n,h,w,cin,couts", [(1, 28, 28, 1024, (4, 16)), (2, 5, 7, 480, (1, 4)), (1, 3, 3, 36, (8, 8, 8, 3)), (1, 9, 5, 1024, (20,))])
 def test_lane_split_1x1_kernel_matches_oracle(gpu, n, h, w, cin, couts):
-    """Configuration 31 = conv_dot1x1_kernel (the detection heads: narrow 1x1 convolutions, K spread over the lanes of a wave):
+    """Configuration CFG_DOT1X1 = conv_dot1x1_kernel (the detection heads: narrow 1x1 convolutions, K spread over the lanes of a wave):
     groups of up to four 8-channel slices, pixel counts that are not multiples of 4, K that is not a multiple of 256, the
     sigmoid second output and ReLU; groups it does not take must be refused."""
     lib = L.load()
@@ -349,8 +349,8 @@ def test_lane_split_1x1_kernel_matches_oracle(gpu, n, h, w, cin, couts):
     arr = (L.ConvDesc * len(descs))(*descs)
     ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(descs))), zero=False)
     grp = L.ConvGroup()
-    L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, 31, C.byref(grp))
-    assert grp.cfg == 31 and grp.total_tiles == (n * h * w + 3) // 4
+    L.call("fcn_conv2d_group_prepare", arr, len(descs), ws.ptr, CFG_DOT1X1, C.byref(grp))
+    assert grp.cfg == CFG_DOT1X1 and grp.total_tiles == (n * h * w + 3) // 4
     L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
     for yd, y2d, cout, ref in refs:
         full = dev_to(yd, (n, h, w, cout + 4))
@@ -360,10 +360,10 @@ def test_lane_split_1x1_kernel_matches_oracle(gpu, n, h, w, cin, couts):
             assert rel_err(nchw(dev_to(y2d, (n, h, w, cout)), cout), R.sigmoid(ref)) < 1e-5
     # a 3x3 problem, or more than four slices, is refused for this configuration
     d3 = conv_desc(xd, keep[1], keep[2], keep[3], n, h, w, cin, cin, couts[0], 3, 1, 1, h, w, couts[0] + 4, 4, 0)
-    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d3), 1, ws.ptr, 31, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare((L.ConvDesc * 1)(d3), 1, ws.ptr, CFG_DOT1X1, C.byref(grp)) != 0
     five = (L.ConvDesc * 5)(*([descs[0]] * 5))
     ws5 = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(5)), zero=False)
-    assert lib.fcn_conv2d_group_prepare(five, 5, ws5.ptr, 31, C.byref(grp)) != 0
+    assert lib.fcn_conv2d_group_prepare(five, 5, ws5.ptr, CFG_DOT1X1, C.byref(grp)) != 0
     L.call("fcn_conv2d_group_release", ws.ptr)
 
 

@@ -50,3 +50,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, os.path.join(dp, f)
+
+
+def test_configuration_numbers_the_tests_name_are_the_librarys():
+    """tests/conftest.py names the convolution configurations (tile family, first-layer, lane-split 1x1, streaming): hold the names to the library."""
+    from conftest import CFG_DOT1X1, CFG_FIRST7, CFG_STREAM0, N_TILE_CFGS
+    from fcn_object_detector_amd import lib as L
+    lib = L.load()
+    assert int(lib.fcn_conv2d_first_layer_config()) == CFG_FIRST7 == N_TILE_CFGS and CFG_DOT1X1 == CFG_FIRST7 + 1
+    assert int(lib.fcn_conv2d_num_configs()) == CFG_STREAM0 + 11
+    assert int(lib.fcn_conv2d_config_waves_k(30)) == 8 and int(lib.fcn_conv2d_config_lds_bytes(30)) == 64 * 1024
+    assert int(lib.fcn_conv2d_config_lds_bytes(CFG_STREAM0)) > 100 * 1024 and int(lib.fcn_conv2d_config_lds_bytes(CFG_STREAM0 + 11)) == -1

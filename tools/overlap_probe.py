@@ -46,7 +46,7 @@ def main():
         ws = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(3)), zero=False)
         py = DeviceBuffer(n * h * h * cin * 2, zero=False)
         best = None
-        for cfg in range(32, int(lib.fcn_conv2d_num_configs())):      # the streaming configuration the tuner would pick
+        for cfg in range(int(lib.fcn_conv2d_first_layer_config()) + 2, int(lib.fcn_conv2d_num_configs())):      # the streaming configuration the tuner would pick
             grp = L.ConvGroup()
             if lib.fcn_conv2d_group_prepare(arr, 3, ws.ptr, cfg, C.byref(grp)) != 0:
                 continue
