@@ -36,7 +36,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3
 HBM_PEAK_GBS = 8000.0
 F16_ACT_MB = 253.7 / 2      # the f32 path's algorithmic activation bytes per frame, stored as halves
 F16_WEIGHT_MB = 24.0 / 2    # weights once per batch
-PROFILE_TAG = "r03"         # profiles/<tag>_*: the round's committed rocprofv3 summaries (tools/profile_bench.sh)
+PROFILE_TAG = "r04"         # profiles/<tag>_*: the round's committed rocprofv3 summaries (tools/profile_bench.sh)
 
 
 def kernel_source_hash() -> str:
@@ -146,7 +146,17 @@ def synth_boxes(rng, n_images, size=448):
     return rects, labels
 
 
-def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
+def profile_json(name: str):
+    """profiles/<PROFILE_TAG>_<name>.json with a `stale` flag (kernel sources changed since it was measured), or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_TAG, name))))
+        d["stale"] = d.get("kernel_source_hash") != kernel_source_hash()
+        return d
+    except (OSError, ValueError):
+        return None
+
+
+def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup, trace_clean=False):
     """One data-parallel training step = target generation (device) + forward + backward + all-reduce + SGD update on
     `per_gpu_batch` synthetic 448x448 images per GPU (BASELINE configs[2] at N=1, configs[3] at N=8)."""
     from fcn_object_detector_amd import dp, lib as L, models, proto
@@ -188,14 +198,27 @@ def bench_train(cp, rank, world, local, per_gpu_batch, steps, warmup):
     res["achieved_tflops"] = round(45.9e-3 * res["imgs_per_s"], 2)
     # roofline of the step's dominant kernel family: the MFMA weight gradient (conv_wgrad_group_kernel + its fixed-order
     # reduction of the pixel-split partials), HIP events per launch on the engine's stream
-    wg = [r for r in eng.time_ops(reps=3, ops=eng.bwd_ops) if r[0] == "wgrad"]
+    # (a kernel-trace pass wants whole steps only: no isolated launches in the trace)
+    wg = [] if trace_clean else [r for r in eng.time_ops(reps=3, ops=eng.bwd_ops) if r[0] == "wgrad"]
     wg_ms, wg_fl = sum(r[2] for r in wg), sum(r[3] for r in wg)
     if wg_ms > 0:
+        iso = {"achieved": round(wg_fl / wg_ms / 1e9, 2), "frac": round(wg_fl / wg_ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4), "ms_per_step": round(wg_ms, 3),
+               "note": "every weight-gradient launch timed ALONE, repeated back to back (HIP events): in the real step these kernels share the chip "
+                       "with the data-gradient stream, so the in-step figure is lower"}
+        prof = profile_json("train_roofline") if world == 1 else None
+        if prof is not None and not prof["stale"]:
+            # first-class: the kernel trace of the REAL two-stream step (tools/roofline_from_profile.py over profiles/<tag>_train_kernel_stats.csv)
+            ach, frac, src = prof["achieved_tflops"], prof["frac"], prof["source"]
+            ms_step = prof["wgrad_ms_per_step"]
+        else:
+            ach, frac, src, ms_step = iso["achieved"], iso["frac"], "live: isolated launches (no fresh profile of the step: %s)" % (
+                "kernel sources changed since profiles/%s_train_roofline.json" % PROFILE_TAG if prof else "none committed"), iso["ms_per_step"]
         res["roofline"] = {"bound": "mfma", "kernel": "conv_wgrad_split_kernel / conv_wgrad_group_kernel (f32 MFMA, reduction over pixels; per launch the faster of the two, timed at plan time) + reduce_partials_group_kernel; %d launches" % len(wg),
-                           "achieved": round(wg_fl / wg_ms / 1e9, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(wg_fl / wg_ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                           "ms_per_step": round(wg_ms, 3), "whole_step_frac": round(res["achieved_tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
-                           "note": "achieved = 2*Cout*K*M per layer / HIP-event time of its launch; whole_step_frac = 45.9 GFLOP/img over the whole step"}
+                           "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": frac, "traffic": None, "source": src,
+                           "ms_per_step": ms_step, "isolated_launches": iso,
+                           "whole_step_frac": round(res["achieved_tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                           "note": "achieved = weight-gradient FLOPs of a step (2*Cout*K*M per layer) / the family's kernel time per step in the "
+                                   "rocprofv3 kernel trace of the two-stream step; whole_step_frac = 45.9 GFLOP/img over the driver-timed step"}
     if comm is not None:
         # the collective by itself, and how much of it the backward pass hides.  "dry" = the same step
         # with every bucket's hand-off (events, stream waits) but no ncclAllReduce behind it.
@@ -465,9 +488,8 @@ def main() -> None:
                                                              "(1 = one stream, launches strictly serial)")
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timing is repeated this many times inside the run: `value` is the median, "
                                                            "the spread rides beside it (a 200-step window is 40 ms: one sample says little)")
-    ap.add_argument("--no-io-region", action="store_true", help="skip SURVEY 8(d) config 2's own timed region (the hipGraph with the H2D / D2H copy nodes): "
-                    "the four-in-flight kernel-trace pass of tools/profile_bench.sh - that graph's launch segfaulted inside the HIP runtime "
-                    "under rocprofv3 on three of five runs in round 3 (never without the profiler); DESIGN.md 5")
+    ap.add_argument("--no-io-region", action="store_true", help="experiments: skip SURVEY 8(d) config 2's timed region (the hipGraph with the H2D / D2H copy nodes); "
+                    "`value` is then the kernels-only figure")
     ap.add_argument("--trace-clean", action="store_true", help="kernel-trace passes of tools/profile_bench.sh: whole forwards only - no per-launch "
                                                                "event timing loops, one repeat - so that every kernel's calls = frames x its launches per frame")
     ap.add_argument("--no-secondary", action="store_true", help="skip the VGG16-FCN (train/fcn_bbox) measurements reported under 'secondary'")
@@ -522,12 +544,12 @@ def main() -> None:
     L.call("fcn_device_sync")
     serial_s = time.perf_counter() - t0
 
-    # headline: the same K batch-1 steps with `depth` frames in flight (replica engines on their own streams), repeated R times
+    # kernels only, inputs resident in HBM: the same K batch-1 steps with `depth` frames in flight (replica engines on their own streams), repeated R times
     pipe.run_resident(max(args.warmup, 1))                        # W untimed warm-up steps (also captures the hipGraphs)
     depth = pipe.calibrate((depth - 1, depth)) if depth > 1 else 1    # untimed: 3 or 4 replicas, whichever packs better here
     if args.trace_clean:
         args.repeats = 1
-    rep_s = []
+    rep_k = []
     for _ in range(max(args.repeats, 1)):
         L.call("fcn_device_sync")
         cp.barrier()
@@ -536,19 +558,36 @@ def main() -> None:
         L.call("fcn_device_sync")
         t_local = time.perf_counter() - t0
         cp.barrier()
-        rep_s.append(cp.max(t_local))
-    t_max = float(np.median(rep_s))
+        rep_k.append(cp.max(t_local))
+    t_k = float(np.median(rep_k))
+
+    # headline (round 4): SURVEY 8(d) config 2's own timed region - H2D of the (3,448,448) f32 frame from pinned host
+    # memory + layout change + all kernels + D2H of the two head blobs - with `depth` frames in flight: a frame's copies ride on its
+    # replica's stream and overlap the other replicas' kernels.  Every rank runs it; K steps between barrier + device sync on both sides.
+    rep_s = []
+    if not args.no_io_region:
+        pipe.warm_io(depth)                                       # untimed: captures every replica's graph with the copy nodes
+        pipe.run_io(max(args.warmup, 1), depth)
+        for _ in range(max(args.repeats, 1)):
+            L.call("fcn_device_sync")
+            cp.barrier()
+            t0 = time.perf_counter()
+            pipe.run_io(args.steps, depth)                        # exactly K steps
+            L.call("fcn_device_sync")
+            t_local = time.perf_counter() - t0
+            cp.barrier()
+            rep_s.append(cp.max(t_local))
+    t_max = float(np.median(rep_s)) if rep_s else t_k
 
     out = None
     if rank == 0:
         ms_per_step = t_max * 1e3 / args.steps
         frames = args.steps * args.batch * world
         value = frames / t_max
-        # SURVEY 8(d) config 2's own timed region: H2D of the (3,448,448) f32 frame from pinned host memory + layout change + all
-        # kernels + D2H of the two head blobs - one frame at a time, and with `depth` frames in flight (every frame's copies ride on
-        # its replica's stream and overlap the other replicas' kernels).  Never `value` (inputs resident in HBM there).
+        value_k = frames / t_k
+        # the same region one frame at a time (the latency form of config 2)
         n_io = max(min(args.steps, 200), 10) if not args.trace_clean else 5
-        io_one, io_fly = ([], []) if not args.no_io_region else ([0.0], [0.0])
+        io_one = [] if not args.no_io_region else [0.0]
         for _ in range(5 if not args.no_io_region else 0):
             eng.forward()
         for _ in range(max(args.repeats, 1) if not args.no_io_region else 0):
@@ -556,8 +595,7 @@ def main() -> None:
             for _ in range(n_io):
                 eng.forward()
             io_one.append(n_io * args.batch / (time.perf_counter() - t1))
-            io_fly.append(n_io * args.batch / pipe.run_io(n_io, depth))
-        pcie_fps, pcie_fly_fps = float(np.median(io_one)), float(np.median(io_fly))
+        pcie_fps = float(np.median(io_one))
 
         # dominant kernel family = the MFMA implicit-GEMM convolution: per-launch HIP-event timing on the engine's stream
         # `roofline.achieved`: HIP events on the engine's stream around each launch repeated back to back (20 reps: the launch floor and the
@@ -579,32 +617,44 @@ def main() -> None:
             for (k, n, ms, fl, by), w in zip(ops, ops_seq):
                 sys.stderr.write("%-10s %-60s %8.2f us (in sequence, with event cost %7.2f) %7.2f TF/s %7.1f GB/s\n" % (k, n[:60], ms * 1e3, w[2] * 1e3, fl / ms / 1e9 if ms else 0,
                                                                                                                       by / ms / 1e6 if ms else 0))
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
+        live = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
         tr = profile_traffic(PROFILE_TAG + "_bench")      # HBM bytes per conv launch from the committed PMC passes (stamped with the sources' hash)
         traffic = tr["bytes_per_launch"] if tr else None
-        prof_roof = None
-        try:      # the same figure derived from the committed kernel trace alone (tools/roofline_from_profile.py)
-            prof_roof = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_bench_roofline.json")))
-            prof_roof = {k: prof_roof[k] for k in ("frac", "achieved_tflops", "conv_us_per_frame", "mfma_busy_frac", "clock_ghz_assumed", "source") if k in prof_roof}
-        except (OSError, ValueError):
-            pass
-        roofline = {"bound": "mfma", "kernel": "conv_fwd_group + conv_first7 (f32 MFMA convolution family; %d launches covering the 59 convolutions)" % len(conv),
-                    "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": tr, "algorithmic_bytes_per_launch": round(sum(o[4] for o in conv) / max(len(conv), 1)),
-                    "traffic_note": "HBM bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this "
-                                    "command; 'stale' = the kernel sources changed since that profile",
-                    "frames_in_flight": 1,
-                    "conv_us_per_frame": round(conv_ms * 1e3, 2),
-                    "in_sequence_events": {"conv_us_per_frame": round(conv_ms_seq * 1e3, 2), "event_pair_floor_us": round(getattr(eng, "event_pair_floor_ms", 0.0) * 1e3, 2),
-                                           "note": "each launch once, in the cache state of a forward, between two events: includes event handling "
-                                                   "(an empty pair reads event_pair_floor_us); reference only"},
-                    "from_profile": prof_roof,
-                    "avg_launch_us": round(conv_ms * 1e3 / max(len(conv), 1), 2), "launches_per_step": len(ops),
-                    "sum_kernel_ms_per_step": round(all_ms, 4),
-                    "measured_on": "one stream, HIP events on the engine's stream around each launch repeated back to back; kernel durations are not "
-                                   "comparable once frames overlap",
-                    "whole_step_tflops": round(FWD_GFLOP * args.batch / ms_per_step, 3)}
+        prof_roof = profile_json("bench_roofline")        # the family's time per frame from the committed kernel trace alone (tools/roofline_from_profile.py)
+        if prof_roof is not None:
+            prof_roof = {k: prof_roof[k] for k in ("frac", "achieved_tflops", "conv_us_per_frame", "mfma_busy_frac", "clock_ghz_assumed", "source", "stale") if k in prof_roof}
+        live_d = {"achieved": round(live, 3), "frac": round(live / F32_MFMA_PEAK_TFLOPS, 4), "conv_us_per_frame": round(conv_ms * 1e3, 2),
+                  "note": "HIP events on the engine's stream around each launch repeated back to back (20 reps): the launch's filters are warm in L2, "
+                          "inside a forward they are cold - 1-4 % faster than the kernel trace of whole forwards"}
+        if args.trace_clean:
+            roofline = {"placeholder": True, "note": "--trace-clean: a kernel-trace pass times no launch by itself; the roofline of this command is derived "
+                                                     "from the trace (tools/roofline_from_profile.py)"}
+        else:
+            fresh = prof_roof is not None and not prof_roof.get("stale", True)
+            achieved = prof_roof["achieved_tflops"] if fresh else live
+            roofline = {"bound": "mfma", "kernel": "conv_fwd_group + conv_first7 (f32 MFMA convolution family; %d launches covering the 59 convolutions)" % len(conv),
+                        "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "source": ("profiles/%s_bench_kernel_stats.csv: rocprofv3 --kernel-trace --stats of this command with one frame in flight, the family's "
+                                   "TotalDurationNs / frames (tools/roofline_from_profile.py)" % PROFILE_TAG) if fresh else
+                                  "live back-to-back launches (the committed kernel trace is %s)" % ("stale: kernel sources changed since" if prof_roof else "missing"),
+                        "traffic_source": tr, "algorithmic_bytes_per_launch": round(sum(o[4] for o in conv) / max(len(conv), 1)),
+                        "traffic_note": "HBM bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes of this "
+                                        "command; 'stale' = the kernel sources changed since that profile",
+                        "frames_in_flight": 1,
+                        "conv_us_per_frame": prof_roof["conv_us_per_frame"] if fresh else round(conv_ms * 1e3, 2),
+                        "live_back_to_back": live_d,
+                        "in_sequence_events": {"conv_us_per_frame": round(conv_ms_seq * 1e3, 2), "event_pair_floor_us": round(getattr(eng, "event_pair_floor_ms", 0.0) * 1e3, 2),
+                                               "note": "each launch once, in the cache state of a forward, between two events: includes event handling "
+                                                       "(an empty pair reads event_pair_floor_us); reference only"},
+                        "from_profile": prof_roof,
+                        "avg_launch_us": round(conv_ms * 1e3 / max(len(conv), 1), 2), "launches_per_step": len(ops),
+                        "sum_kernel_ms_per_step": round(all_ms, 4),
+                        "measured_on": "one stream; kernel durations are not comparable once frames overlap",
+                        "whole_step_tflops": round(FWD_GFLOP * args.batch / (dev_ms / args.steps), 3)}
+        region = ("SURVEY 8(d) config 2: H2D of the (3,448,448) f32 frame from pinned host memory + layout change + all kernels + D2H of the two head "
+                  "blobs") if rep_s else "kernels only (--no-io-region)"
+        rep_v = rep_s or rep_k
         out = {"metric": "frames/sec forward 448x448 @1 GPU; train imgs/sec @1/2/4/8 GPUs", "value": round(value, 2),
                "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -612,29 +662,35 @@ def main() -> None:
                "config": {"workload": "configs[1]: single-GPU forward, DetectNet GoogLeNet conv stack + coverage/bbox heads "
                                       "(graph of models/deploy.prototxt), batch=%d, 448x448, random-init weights" % args.batch,
                           "global_batch": args.batch * world, "parallelism": "replicas x%d" % world, "frames_in_flight": depth,
-                          "timed_region": "`value`: kernels only, inputs resident in HBM, hipGraph replay, %d frames in flight, median of %d repeats of K "
-                                          "steps; `config2_*`: SURVEY 8(d) config 2's region (H2D + kernels + D2H)" % (depth, len(rep_s))},
-               "repeats": {"R": len(rep_s), "frames_per_s": [round(frames / t, 1) for t in rep_s],
-                           "min": round(frames / max(rep_s), 1), "max": round(frames / min(rep_s), 1),
-                           "spread_pct": round(100.0 * (max(rep_s) - min(rep_s)) / t_max, 2)},
+                          "timed_region": "`value`: %s, hipGraph replay, %d frames in flight (a frame's copies ride on its replica's stream and overlap "
+                                          "the other replicas' kernels), median of %d repeats of K steps; `value_kernels_only`: the same K steps on inputs "
+                                          "already resident in HBM (rounds 1-3's `value`); `config2_frames_per_s`: the region one frame at a time"
+                                          % (region, depth, len(rep_v))},
+               "repeats": {"R": len(rep_v), "frames_per_s": [round(frames / t, 1) for t in rep_v],
+                           "min": round(frames / max(rep_v), 1), "max": round(frames / min(rep_v), 1),
+                           "spread_pct": round(100.0 * (max(rep_v) - min(rep_v)) / t_max, 2)},
+               "value_kernels_only": round(value_k, 2),
+               "kernels_only": {"frames_per_s": round(value_k, 2), "ms_per_step": round(t_k * 1e3 / args.steps, 4), "frames_in_flight": depth,
+                                "repeats": [round(frames / t, 1) for t in rep_k],
+                                "includes": "all kernels of the forward, inputs resident in HBM, outputs left in HBM (no copies in the timed region)"},
                "config2_frames_per_s": round(pcie_fps, 2),
-               "config2_frames_per_s_in_flight": round(pcie_fly_fps, 2),
+               "config2_frames_per_s_in_flight": round(value, 2) if rep_s else None,
                "config2_timed_region": {"frames_per_s": round(pcie_fps, 2), "ms_per_frame": round(1e3 / pcie_fps, 4) if pcie_fps else None,
-                                        "frames_per_s_in_flight": round(pcie_fly_fps, 2), "frames_in_flight": depth,
-                                        "repeats": {"one_at_a_time": [round(v, 1) for v in io_one], "in_flight": [round(v, 1) for v in io_fly]},
+                                        "frames_per_s_in_flight": round(value, 2) if rep_s else None, "frames_in_flight": depth,
+                                        "repeats": {"one_at_a_time": [round(v, 1) for v in io_one]},
                                         "includes": "SURVEY 8(d) config 2: H2D of the (3,448,448) f32 frame (pinned host memory) + layout change + all kernels + "
-                                                    "D2H of the two head blobs; one frame at a time, and with the copies of a frame overlapping the kernels of "
-                                                    "the others (never `value`: inputs resident in HBM there)"},
+                                                    "D2H of the two head blobs; one frame at a time here, with frames in flight it is `value`"},
                "single_stream": {"frames_per_s": round(args.steps * args.batch / serial_s, 2),
                                  "latency_ms_per_frame": round(serial_s * 1e3 / args.steps, 4),
                                  "device_ms_per_step": round(dev_ms / args.steps, 4)},
                "pcie_inclusive_fps": round(pcie_fps, 2),
                "roofline": roofline,
-               "roofline_in_flight": {"bound": "mfma", "frames_in_flight": depth, "achieved": round(FWD_GFLOP * value / 1e3, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-                                      "unit": "TFLOP/s", "frac": round(FWD_GFLOP * value / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
-                                      "note": "the mode `value` is measured in: conv FLOPs of a frame x frames/s over the wall clock of the K steps (kernels "
-                                              "of different frames overlap, so per-kernel durations are not comparable; profiles/r03_bench_inflight_kernel_stats.csv "
-                                              "holds the kernel trace of this mode: GPU-busy time / wall time there)"}}
+               "roofline_in_flight": {"bound": "mfma", "frames_in_flight": depth, "achieved": round(FWD_GFLOP * value_k / 1e3, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                                      "unit": "TFLOP/s", "frac": round(FWD_GFLOP * value_k / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
+                                      "with_copies": {"achieved": round(FWD_GFLOP * value / 1e3, 3), "frac": round(FWD_GFLOP * value / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)},
+                                      "note": "conv FLOPs of a frame x frames/s over the wall clock of the K steps with frames in flight - kernels only "
+                                              "(`value_kernels_only`) and, under `with_copies`, config 2's region (`value`); kernels of different frames overlap, so "
+                                              "per-kernel durations are not comparable: profiles/%s_bench_inflight_kernel_stats.csv holds the kernel trace of this mode" % PROFILE_TAG}}
         if world == 1 and not args.no_cpu_baseline:
             base, ref_blobs = cpu_baseline(msg, params, x)
             out["cpu_baseline"] = base
@@ -643,7 +699,8 @@ def main() -> None:
             out["parity_rel_err"] = {k: float("%.3e" % v) for k, v in errs.items()}
             if max(errs.values()) >= 1e-3:
                 raise SystemExit("bench: GPU output differs from the oracle: %s" % errs)
-            out["speedup_vs_cpu"] = round(value / base["value"], 1)
+            out["speedup_vs_cpu"] = round(value / base["value"], 1)      # (config 2's region with frames in flight against the CPU port's forward)
+            out["speedup_vs_cpu_kernels_only"] = round(value_k / base["value"], 1)
     cp.barrier()
     pipe.close()
     if out is not None and world == 1 and not args.no_secondary:
@@ -670,7 +727,7 @@ def main() -> None:
             watchdog.daemon = True
             watchdog.start()
         try:
-            tr = bench_train(cp, rank, world, local, args.train_batch, tsteps, max(min(args.warmup, 5), 2))
+            tr = bench_train(cp, rank, world, local, args.train_batch, tsteps, max(min(args.warmup, 5), 2), trace_clean=args.trace_clean)
         except Exception as e:      # the headline measured above must survive a failure in the secondary measurement
             tr = {"error": "%s: %s" % (type(e).__name__, e)}
         if watchdog is not None:

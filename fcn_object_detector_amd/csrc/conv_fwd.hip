@@ -130,17 +130,21 @@ __device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
 template <int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF_, bool PF>
 struct Cfg {
     static constexpr bool ROLES = NBUF_ >= 16;
-    static constexpr int NBUF = ROLES ? NBUF_ - 16 : NBUF_;
+    // Ring slots >= 32 (round 4): split roles with TWICE the loading waves - the first NW of them stage the A rows, the second NW
+    // the B rows, one LDS-DMA piece per wave and chunk where the plain split gives every loading wave an A and a B piece.
+    static constexpr int LOADX = NBUF_ >= 32 ? 2 : 1;
+    static constexpr int NBUF = NBUF_ % 16;
     static constexpr int BM = 32 * WTM * WAVES_M;
     static constexpr int BN = 32 * WTN * WAVES_N;
-    static constexpr int NW = WAVES_M * WAVES_N * WAVES_K;   // multiplying waves (= loading waves) per workgroup
-    static constexpr int NT = 64 * NW * (ROLES ? 2 : 1);
+    static constexpr int NW = WAVES_M * WAVES_N * WAVES_K;   // multiplying waves per workgroup (loading waves: NW, or 2 NW with LOADX = 2)
+    static constexpr int NT = 64 * NW * (ROLES ? 1 + LOADX : 1);
     static constexpr int SEGS = BK / 4;                 // 16-byte slots per staged row
     static constexpr int RPI = 256 / BK;                // rows one LDS-DMA wave-instruction (1 KiB) fills
     static constexpr int STEP = RPI * NW;               // rows between two consecutive instructions of one wave
     static constexpr int IA = BM / STEP;                // A-row instructions per wave per chunk
     static constexpr int IB = BN / STEP;                // B-row instructions per wave per chunk
-    static constexpr int INST = IA + IB;
+    static constexpr int INST = LOADX == 2 ? IA : IA + IB;   // LDS-DMA instructions one loading wave issues per chunk
+    static_assert(LOADX == 1 || IA == IB, "doubled loaders: the A waves and the B waves issue the same number of pieces");
     static constexpr int D = NBUF - 1;                  // chunks in flight
     static constexpr int KS = BK / 8 / WAVES_K;         // k-steps of 8 each wave runs per chunk
     static constexpr int BUF_FLOATS = (BM + BN) * BK;   // one ring slot: A rows then B rows, unpadded
@@ -200,7 +204,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (LDS-DMA base goes through M0)
     // split roles: waves 0 .. NW-1 multiply, waves NW .. 2NW-1 load; otherwise every wave does both
     const bool is_loader = !ROLES || wid_all >= C::NW, is_mult = !ROLES || wid_all < C::NW;
-    const int wid = ROLES && wid_all >= C::NW ? wid_all - C::NW : wid_all;      // index within the role
+    const bool loads_b = C::LOADX == 2 && wid_all >= 2 * C::NW;                   // doubled loaders: this wave stages B rows (else A rows)
+    const int wid = ROLES && wid_all >= C::NW ? (wid_all - C::NW) % C::NW : wid_all;      // index within the role
     const int wk = wid % WAVES_K;
     const int wn = (wid / WAVES_K) % WAVES_N;
     const int wm = wid / (WAVES_K * WAVES_N);
@@ -367,10 +372,20 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // waits can count on.
     auto issue_chunk = [&](const int buf) {
         issue_pre(buf);
+        if constexpr (C::LOADX == 2) {      // (wave-uniform: a scalar branch)
+            if (loads_b) {
 #pragma unroll
-        for (int i = 0; i < IA; ++i) issue_a(i);
+                for (int i = 0; i < IB; ++i) issue_b(i);
+            } else {
 #pragma unroll
-        for (int i = 0; i < IB; ++i) issue_b(i);
+                for (int i = 0; i < IA; ++i) issue_a(i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < IA; ++i) issue_a(i);
+#pragma unroll
+            for (int i = 0; i < IB; ++i) issue_b(i);
+        }
         issue_post();
     };
     int buf_issue = 0;                 // ring slot of the next chunk to issue
@@ -397,7 +412,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 wait_vmcnt<INST*(D - 2)>();    // chunk c + 1 landed
                 __builtin_amdgcn_s_barrier();  // the multipliers are done with chunk c - 1: its slot takes chunk c + D
                 asm volatile("" ::: "memory");
+#ifndef FCN_EXP_NOLOAD      // (elimination build, make exp EXP=-DFCN_EXP_NOLOAD EXPSRC=conv_fwd: the loop without its staging)
                 issue_chunk(buf_issue);
+#endif
                 buf_issue = next(buf_issue);
             }
             wait_vmcnt<0>();                   // the all-zero chunks issued past K must land before the ring is reused
@@ -801,14 +818,22 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
     // round draw long tiles in every round and the launch ends on them (inception_3b's 3x3 group: 141 chunk-units on the
     // fullest CU against an average of 117).  So the rounds are dealt like cards in a snake: the last (partial) round forward,
     // the one before it backward, and so on; round 0 (where the poolings sit) always forward.
-    // snake = rounds << 8 | log2(#CUs), 0 = off; scalar unit only.
+    // snake = rounds << 8 | log2(#CUs), 0 = off, negative = the two-round rotation below; scalar unit only.
     int pos = blockIdx.x;
-    if (snake) {
+    if (snake > 0) {
         const int sh = snake & 255, rounds = snake >> 8;
         const int r = pos >> sh, j = pos & ((1 << sh) - 1);
         if (r > 0 && r < rounds - 1 && ((rounds - 1 - r) & 1)) pos = (r << sh) + ((1 << sh) - 1 - j);
     }
-    const int tile = pos - pool_wgs;
+    int tile = pos - pool_wgs;
+    if (snake < 0) {
+        // Two rounds (round 4): -snake = E workgroups more than CUs, so CUs 0 .. E-1 take two tiles each - positions j and #CUs + j -
+        // and in index order (longest problem first) those are E of the LONGEST tiles plus the E shortest: the launch ends on
+        // them (inception_4a's 3x3 level: 27 + 13 chunks on 19 CUs, 27 or less on the others).  Rotated by E, positions 0 .. E-1 take
+        // the E shortest tiles and positions #CUs .. take the next-shortest: the doubled CUs hold two short tiles.
+        tile += snake;
+        tile += tile < 0 ? te7 : 0;      // (te7 = the group's tile count: tile_end of problems past nprob repeats the last one)
+    }
     int pi = 0, begin = 0;
 #pragma unroll
     for (int i = 0; i < kMaxGroup - 1; ++i) {      // tile_end is increasing: count the problems that end at or before this tile
@@ -1529,8 +1554,8 @@ bool dot1x1_ok(const ConvP* ps, int n) {
     X(27, 1, 1, 1, 1, 4, 32, 16 + 6, true)  \
     X(28, 1, 1, 2, 2, 1, 64, 16 + 4, true)  \
     X(29, 2, 1, 2, 2, 1, 32, 16 + 4, true)  \
-    X(30, 1, 1, 1, 1, 8, 64, 16 + 4, true)  \
-    X(31, 1, 1, 2, 1, 4, 64, 16 + 4, true)
+    X(30, 1, 1, 1, 1, 4, 32, 32 + 4, true)  \
+    X(31, 1, 1, 2, 2, 1, 32, 32 + 4, true)
 
 struct TileCfg { int bm, bn, bk; bool prefetch; };
 constexpr int kCfgThreads[] = {
@@ -1548,10 +1573,10 @@ constexpr int kCfgWavesK[] = {
     FCN_CONV_CONFIGS(X)
 #undef X
 };
-// Round 4, configurations 30 / 31 - sixteen waves on ONE tile: at M = 784 a launch is one 32 x 32 tile per CU whose K loop is a chain of
-// chunks (barrier, LDS-DMA issue, first-use latency) that a second workgroup on the CU would overlap - but there is no second
-// workgroup (250 tiles for 256 CUs).  Eight multiplying and eight loading waves share a 64-float chunk: half the chunks (barriers)
-// per tile and two multiplier waves per SIMD, i.e. the occupancy of two workgroups spent on one tile's chain (64 / 96 KiB of LDS).
+// Round 4, configurations 30 / 31 - the split-role shapes 23 / 26 with TWICE the loading waves (Cfg::LOADX): a loading wave issues one
+// LDS-DMA piece per chunk instead of two.  (Tried first and dropped: sixteen waves on one tile with 64-float chunks - K over eight
+// waves, or a 64 x 32 tile - 5-15 % slower than configuration 23 on every batch-1 launch, like every other 64-float-chunk shape:
+// profiles/experiments/r04_sweep_cfg_16waves.txt.)
 constexpr int kNumTileCfg = 32;            // configurations of the implicit-GEMM kernel (the X table)
 constexpr int kFirst7Cfg = kNumTileCfg;    // conv_first7_kernel: single 7x7 / stride 2 / 4-channel problems only (first7_ok)
 constexpr int kDot1x1Cfg = kNumTileCfg + 1;  // conv_dot1x1_kernel: groups of narrow 1x1 problems only (dot1x1_ok)
@@ -1998,6 +2023,8 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
                 int sh = 0;
                 while ((1 << sh) < cus) ++sh;
                 snake = ((grid + cus - 1) / cus) << 8 | sh;
+            } else if (snake_ok && ga.nprob > 1 && pool_wgs == 0 && grid > cus && grid <= 2 * cus) {
+                snake = -(grid - cus);      // two rounds: rotate the tile order by the overhang (conv_fwd_group)
             }
         }
         if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, pool_wgs, snake, grid, as_stream(s));

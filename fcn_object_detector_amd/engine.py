@@ -1478,9 +1478,6 @@ class ForwardPipeline:
         copies ride on its replica's stream, so they overlap the kernels of the other replicas.  Wall-clock seconds."""
         import time
         engines = self.engines[:depth or getattr(self, "active", None) or len(self.engines)]
-        for e in engines:
-            e.forward_begin()
-            e.forward_end()
         pending: List[Engine] = []
         t0 = time.perf_counter()
         for i in range(iters):
@@ -1492,6 +1489,12 @@ class ForwardPipeline:
         while pending:
             pending.pop(0).forward_end()
         return time.perf_counter() - t0
+
+    def warm_io(self, depth: Optional[int] = None) -> None:
+        """One untimed forward with transfers per replica: captures each replica's graph with the copy nodes (benchmarks call it before run_io)."""
+        for e in self.engines[:depth or getattr(self, "active", None) or len(self.engines)]:
+            e.forward_begin()
+            e.forward_end()
 
     def _run_resident(self, engines, iters, lib, time) -> float:
         for e in engines:

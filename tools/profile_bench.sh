@@ -19,13 +19,13 @@ prof() {      # prof <dir> <rocprofv3 options...> -- <program...>   (the program
     local d=$1; shift
     rm -rf "$OUT/$d"
     local err="$OUT/$d.$(date +%H%M%S).err"      # never overwritten: a failing pass keeps its traceback (round 3 lost one to a later clean run)
-    ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d "$OUT/$d" -o run "$@" ) 2> "$err" || { echo "pass $d FAILED ($err):"; tail -5 "$err"; cp "$err" "$OUT/FAILED_$(basename "$err")"; return 0; }
+    ( cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --output-format csv -d "$OUT/$d" -o run "$@" ) 2> "$err" || { echo "pass $d FAILED ($err):"; tail -5 "$err"; cp "$err" "$OUT/FAILED_$(basename "$err")"; return 0; }
 }
 ONE="$ARGS --in-flight 1"      # ONE frame in flight: per-kernel durations only mean something when launches do not overlap
 export PYTHONFAULTHANDLER=1
 export FCN_NO_GRAPH=1          # plain launches: the training step, the counter passes, and a kernel trace of the forward
 prof ${TAG}_pstats --stats -- python3 "$ROOT/bench.py" $ONE --no-train --trace-clean > "$OUT/${TAG}_bench_plain_under_rocprof.json"
-prof ${TAG}_tstats --stats -- python3 "$ROOT/bench.py" $ONE > "$OUT/${TAG}_train_under_rocprof.json"
+prof ${TAG}_tstats --stats -- python3 "$ROOT/bench.py" $ONE --trace-clean > "$OUT/${TAG}_train_under_rocprof.json"      # whole steps only: train.roofline is derived from this trace
 prof ${TAG}_fetch --pmc FETCH_SIZE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
 prof ${TAG}_write --pmc WRITE_SIZE -- python3 "$ROOT/bench.py" $ONE --no-train > /dev/null
 # matrix-core counters (SQ block, own pass): busy cycles of the MFMA pipes against the SQ's busy cycles, MFMA op counts

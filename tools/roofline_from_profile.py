@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Derive bench.py's `roofline.frac` for the f32 batch-1 convolution family from the committed rocprofv3 summaries ALONE.
 
-usage: roofline_from_profile.py <tag>            (reads profiles/<tag>_bench_kernel_stats.csv [+ <tag>_bench_pmc_mfma.json],
-                                                  writes profiles/<tag>_bench_roofline.json)
+usage: roofline_from_profile.py <tag> [train batch]   (reads profiles/<tag>_bench_kernel_stats.csv [+ <tag>_bench_pmc_mfma.json] and
+                                                       profiles/<tag>_train_kernel_stats.csv; writes profiles/<tag>_bench_roofline.json and
+                                                       profiles/<tag>_train_roofline.json)
 
   conv_us_per_frame = sum of TotalDurationNs of the forward convolution kernels (conv_fwd_group*, conv_fwd_one*, conv_first7*,
                       conv_dot1x1*) / frames, frames = calls of the first-layer kernel (it runs once per forward)
@@ -56,9 +57,53 @@ def main():
             out["kernel_source_hash"] = pmc.get("kernel_source_hash")
     except (OSError, KeyError, ValueError):
         pass
+    if "kernel_source_hash" not in out:
+        try:
+            out["kernel_source_hash"] = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.json"))).get("kernel_source_hash")
+        except (OSError, ValueError):
+            pass
     dst = os.path.join(ROOT, "profiles", tag + "_bench_roofline.json")
     json.dump(out, open(dst, "w"), indent=1)
     print("wrote", dst, "frac", out["frac"], "mfma_busy_frac", out.get("mfma_busy_frac"))
+    train_roofline(tag, int(sys.argv[2]) if len(sys.argv) > 2 else 8)
+
+
+def train_roofline(tag, batch):
+    """bench.py's `train.roofline` from the kernel trace of the REAL two-stream training step (profiles/<tag>_train_kernel_stats.csv, a
+    `bench.py --trace-clean` pass: whole steps only): the weight-gradient family = conv_wgrad_* + reduce_partials_* kernels, steps = calls of
+    the solver kernel (one per step), FLOPs of a step = 2 * Cout * K * M over the 59 convolutions = 15.608 GFLOP x batch."""
+    stats = os.path.join(ROOT, "profiles", tag + "_train_kernel_stats.csv")
+    if not os.path.isfile(stats):
+        return
+    wg_ns, red_ns, steps, rows = 0, 0, 0, []
+    for r in csv.DictReader(open(stats)):
+        name = r["Name"]
+        if "conv_wgrad" in name or "reduce_partials" in name:
+            if "reduce_partials" in name:
+                red_ns += int(r["TotalDurationNs"])
+            else:
+                wg_ns += int(r["TotalDurationNs"])
+            rows.append({"kernel": name.replace("(anonymous namespace)::", "")[:90], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2)})
+        if "sgd_kernel" in name or "adam_kernel" in name:
+            steps += int(r["Calls"])
+    if not steps:
+        print("no solver kernel in %s: cannot count the steps" % stats)
+        return
+    ms = (wg_ns + red_ns) / 1e6 / steps
+    gflop = FWD_GFLOP * batch
+    out = {"source": "profiles/%s_train_kernel_stats.csv" % tag, "steps": steps, "batch": batch, "wgrad_ms_per_step": round(ms, 4),
+           "wgrad_kernels_ms_per_step": round(wg_ns / 1e6 / steps, 4), "reduce_partials_ms_per_step": round(red_ns / 1e6 / steps, 4),
+           "wgrad_gflop_per_step": round(gflop, 2), "achieved_tflops": round(gflop / ms, 2), "peak_tflops": PEAK_TF, "frac": round(gflop / ms / PEAK_TF, 4),
+           "kernels": rows,
+           "note": "kernel durations inside the two-stream step: the weight-gradient kernels share the chip with the data-gradient stream, so their "
+                   "durations are longer than when each launch is timed alone (bench.py train.roofline.isolated_launches)"}
+    try:
+        out["kernel_source_hash"] = json.load(open(os.path.join(ROOT, "profiles", tag + "_train_kernel_stats.json"))).get("kernel_source_hash")
+    except (OSError, ValueError):
+        pass
+    dst = os.path.join(ROOT, "profiles", tag + "_train_roofline.json")
+    json.dump(out, open(dst, "w"), indent=1)
+    print("wrote", dst, "frac", out["frac"], "ms per step", out["wgrad_ms_per_step"])
 
 
 if __name__ == "__main__":
