@@ -214,8 +214,12 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     // instruction cache: the launch prologue uses host-computed multipliers instead)
     const int tile_m = fast_div(tile, p.tiles_n_magic);
     const int tile_n = tile - tile_m * p.tiles_n;
+#ifdef FCN_EXP_SAMETILE      // (elimination build: every workgroup stages - and stores - tile (0, 0): all loads hit in L2)
+    const int m0 = 0, n0 = 0;
+#else
     const int m0 = tile_m * BM;
     const int n0 = tile_n * C::BN;
+#endif
 
     // ---- loader state: this lane stages slot (lane % SEGS) of rows STEP*i + RPI*wid + lane / SEGS ------------
     const int lrow = RPI * wid + lane / SEGS;                  // row of instruction 0
@@ -826,7 +830,12 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
         if (r > 0 && r < rounds - 1 && ((rounds - 1 - r) & 1)) pos = (r << sh) + ((1 << sh) - 1 - j);
     }
     int tile = pos - pool_wgs;
-    if (snake < 0) {
+    if (snake == (int)0x80000000) {
+        // (experiment, FCN_CONV_XCD=1) workgroup p runs on XCD p % 8: give every XCD a CONTIGUOUS run of the tile list, so that the tiles
+        // sharing A rows (consecutive indices: tile_m = index / tiles_n) meet in one L2 instead of eight
+        const int x = pos & 7, sl = pos >> 3, q = te7 >> 3, r = te7 & 7;
+        tile = x * q + (x < r ? x : r) + sl;
+    } else if (snake < 0) {
         // Two rounds (round 4): -snake = E workgroups more than CUs, so CUs 0 .. E-1 take two tiles each - positions j and #CUs + j -
         // and in index order (longest problem first) those are E of the LONGEST tiles plus the E shortest: the launch ends on
         // them (inception_4a's 3x3 level: 27 + 13 chunks on 19 CUs, 27 or less on the others).  Rotated by E, positions 0 .. E-1 take
@@ -1553,9 +1562,7 @@ bool dot1x1_ok(const ConvP* ps, int n) {
     X(26, 1, 1, 2, 2, 1, 32, 16 + 4, true)  \
     X(27, 1, 1, 1, 1, 4, 32, 16 + 6, true)  \
     X(28, 1, 1, 2, 2, 1, 64, 16 + 4, true)  \
-    X(29, 2, 1, 2, 2, 1, 32, 16 + 4, true)  \
-    X(30, 1, 1, 1, 1, 4, 32, 32 + 4, true)  \
-    X(31, 1, 1, 2, 2, 1, 32, 32 + 4, true)
+    X(29, 2, 1, 2, 2, 1, 32, 16 + 4, true)
 
 struct TileCfg { int bm, bn, bk; bool prefetch; };
 constexpr int kCfgThreads[] = {
@@ -1573,11 +1580,11 @@ constexpr int kCfgWavesK[] = {
     FCN_CONV_CONFIGS(X)
 #undef X
 };
-// Round 4, configurations 30 / 31 - the split-role shapes 23 / 26 with TWICE the loading waves (Cfg::LOADX): a loading wave issues one
-// LDS-DMA piece per chunk instead of two.  (Tried first and dropped: sixteen waves on one tile with 64-float chunks - K over eight
-// waves, or a 64 x 32 tile - 5-15 % slower than configuration 23 on every batch-1 launch, like every other 64-float-chunk shape:
-// profiles/experiments/r04_sweep_cfg_16waves.txt.)
-constexpr int kNumTileCfg = 32;            // configurations of the implicit-GEMM kernel (the X table)
+// Round 4, tried and dropped (profiles/experiments/r04_sweep_cfg_16waves.txt, r04_sweep_loadx.txt): sixteen waves on one tile with
+// 64-float chunks (K over eight waves, or a 64 x 32 tile) - 5-15 % slower than configuration 23 on every batch-1 launch, like every
+// other 64-float-chunk shape; and the split-role shapes 23 / 26 with TWICE the loading waves, one LDS-DMA piece per wave and chunk
+// (Cfg::LOADX, kept: ring slots >= 32) - 40-60 % slower: the loop is not bound by a loading wave's issue rate.
+constexpr int kNumTileCfg = 30;            // configurations of the implicit-GEMM kernel (the X table)
 constexpr int kFirst7Cfg = kNumTileCfg;    // conv_first7_kernel: single 7x7 / stride 2 / 4-channel problems only (first7_ok)
 constexpr int kDot1x1Cfg = kNumTileCfg + 1;  // conv_dot1x1_kernel: groups of narrow 1x1 problems only (dot1x1_ok)
 constexpr int kStreamCfg0 = kNumTileCfg + 2;  // conv_stream_f16 (conv_stream.hip): persistent half-float streaming kernel, configurations 32 ..
@@ -2023,6 +2030,8 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
                 int sh = 0;
                 while ((1 << sh) < cus) ++sh;
                 snake = ((grid + cus - 1) / cus) << 8 | sh;
+            } else if (getenv("FCN_CONV_XCD") && atoi(getenv("FCN_CONV_XCD")) == 1 && pool_wgs == 0 && first == 0 && hg.n <= kMaxGroup) {
+                snake = (int)0x80000000;
             } else if (snake_ok && ga.nprob > 1 && pool_wgs == 0 && grid > cus && grid <= 2 * cus) {
                 snake = -(grid - cus);      // two rounds: rotate the tile order by the overhang (conv_fwd_group)
             }

@@ -18,7 +18,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 MODELS = os.path.join(ROOT, "tests", "golden", "nets")
 # convolution configuration numbers (csrc/conv_fwd.hip): 0 .. N_TILE_CFGS-1 the tiled implicit-GEMM family, then the first-layer kernel,
 # the lane-split 1x1 kernel, then the persistent half-float streaming kernel's.  tests/test_lib_abi.py holds them to the library.
-N_TILE_CFGS = 32
+N_TILE_CFGS = 30
 CFG_FIRST7, CFG_DOT1X1, CFG_STREAM0 = N_TILE_CFGS, N_TILE_CFGS + 1, N_TILE_CFGS + 2
 
 

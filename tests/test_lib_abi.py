@@ -59,5 +59,5 @@ def test_configuration_numbers_the_tests_name_are_the_librarys():
     lib = L.load()
     assert int(lib.fcn_conv2d_first_layer_config()) == CFG_FIRST7 == N_TILE_CFGS and CFG_DOT1X1 == CFG_FIRST7 + 1
     assert int(lib.fcn_conv2d_num_configs()) == CFG_STREAM0 + 11
-    assert int(lib.fcn_conv2d_config_waves_k(30)) == 4 and int(lib.fcn_conv2d_config_lds_bytes(30)) == 32 * 1024
+    assert int(lib.fcn_conv2d_config_waves_k(23)) == 4 and int(lib.fcn_conv2d_config_lds_bytes(23)) == 32 * 1024
     assert int(lib.fcn_conv2d_config_lds_bytes(CFG_STREAM0)) > 100 * 1024 and int(lib.fcn_conv2d_config_lds_bytes(CFG_STREAM0 + 11)) == -1
