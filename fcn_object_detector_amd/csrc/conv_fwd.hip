@@ -599,9 +599,80 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             const int n = n0 + STEP * i + lrow;
             b_vo[i] = n < p.Cout ? (n * p.K + lane_c) * ESZ : OOB;
         }
+        float* dst = smem;
+        if constexpr (ROLES) {
+            // ---- round 4: the same loader with its bookkeeping off the critical path.  Elimination builds of the split-role 32 x 32
+            // shape (profiles/experiments/r04_elimination_cfg23.txt): 0.125 us per chunk with the staging compiled out (the four MFMAs
+            // are 0.117), 0.159 us with the MFMAs compiled out, 0.179 us as built - and the same with every workgroup staging the SAME
+            // tile (all loads L2 hits), with a deeper ring, with two workgroups per CU: the loading waves' own instruction stream sets
+            // the pace.  Per chunk it was ~45 scalar and 9 vector instructions around two LDS-DMA pieces - the generic (tap, channel)
+            // state machine - and the scalar unit is shared by all waves of a CU.  Here a filter tap is entered once: its halo tests and
+            // per-lane offsets are computed THEN (vector ALU, once per tap), the chunks of the tap differ only in the SCALAR offset of
+            // the buffer instruction, and the partial last chunk of a tap (Cin not a multiple of the chunk) swaps in pre-masked offsets.
+            // Per chunk: ~16 scalar instructions, no vector instruction, two LDS-DMA pieces.
+            const int cpt = (p.Cin + BKE - 1) / BKE;                 // chunks per tap
+            const int rem = p.Cin - (cpt - 1) * BKE;                 // channels the last chunk of a tap covers
+            const bool partial = rem != BKE;
+            int a_full[IA], a_last[IA], a_cur[IA], b_last[IB], b_cur[IB];
+#pragma unroll
+            for (int i = 0; i < IB; ++i) b_last[i] = lane_c < rem ? b_vo[i] : OOB;
+            int s_j = 0, s_kr = 0, s_kq = -1, s_aoff = 0, s_boff = 0, s_tapb = -p.Cin * ESZ, s_taps = taps + 1;
+            auto tap_advance = [&]() {
+                --s_taps;
+                if (s_taps <= 0) {                                   // past K: all-zero chunks from here on
+#pragma unroll
+                    for (int i = 0; i < IA; ++i) a_cur[i] = OOB;
+#pragma unroll
+                    for (int i = 0; i < IB; ++i) b_cur[i] = OOB;
+                    s_j = 0x7fffffff;
+                    return;
+                }
+                ++s_kq;
+                const bool wq = s_kq == p.kw;
+                s_kq = wq ? 0 : s_kq;
+                s_kr += wq ? 1 : 0;
+                s_aoff = (s_kr * p.W + s_kq) * p.x_cstride * ESZ;
+                s_tapb += p.Cin * ESZ;
+                s_boff = s_tapb;
+                s_j = cpt;
+                const bool last_now = partial && cpt == 1;
+#pragma unroll
+                for (int i = 0; i < IA; ++i) {
+                    const bool ok = (int)((unsigned)(a_iy0[i] + s_kr) < (unsigned)p.H) & (int)((unsigned)(a_ix0[i] + s_kq) < (unsigned)p.W);
+                    a_full[i] = ok ? a_vo[i] : OOB;
+                    a_last[i] = lane_c < rem ? a_full[i] : OOB;
+                    a_cur[i] = last_now ? a_last[i] : a_full[i];
+                }
+#pragma unroll
+                for (int i = 0; i < IB; ++i) b_cur[i] = last_now ? b_last[i] : b_vo[i];
+            };
+            tap_advance();
+            auto lpre = [&](const int buf) { dst = smem + buf * BUF_FLOATS + lds_wave_base; };
+            auto la = [&](const int i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dst + STEP * i * BK), 16, a_cur[i], s_aoff, 0, 0);
+            };
+            auto lb = [&](const int i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + (BM + STEP * i) * BK), 16, b_cur[i], s_boff, 0, 0);
+            };
+            auto lpost = [&]() {
+                s_aoff += BKE * ESZ;
+                s_boff += BKE * ESZ;
+                --s_j;
+                if (__builtin_expect(s_j <= 1, 0)) {      // (one rarely taken branch on the common path)
+                    if (s_j == 0) {
+                        tap_advance();
+                    } else if (partial) {
+#pragma unroll
+                        for (int i = 0; i < IA; ++i) a_cur[i] = a_last[i];
+#pragma unroll
+                        for (int i = 0; i < IB; ++i) b_cur[i] = b_last[i];
+                    }
+                }
+            };
+            pipeline(lpre, la, lb, lpost);
+        } else {
         int s_kr = 0, s_kq = 0, s_kc = 0, s_koff = 0, s_kb = 0, s_left = nchunks;      // wave-uniform K position of the next chunk
         bool cvalid = false;
-        float* dst = smem;
         auto lpre = [&](const int buf) {
             const int thr = s_left > 0 ? p.Cin - s_kc : 0;      // channels of this tap the chunk still covers (0: past the end)
             cvalid = lane_c < thr;
@@ -632,6 +703,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             s_koff = nt ? (s_kr * p.W + s_kq) * p.x_cstride * ESZ : s_koff + BKE * ESZ;
         };
         pipeline(lpre, la, lb, lpost);
+        }
     } else {
         // ---- per-lane loader: any geometry (chunks may straddle taps: Cin = 3 + 1 pad of conv1, 16, ...) -----------------
         // k position of this lane's segment, kept as (tap, channel) and advanced by BK per chunk without branches
