@@ -648,11 +648,16 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             };
             tap_advance();
             auto lpre = [&](const int buf) { dst = smem + buf * BUF_FLOATS + lds_wave_base; };
+            // (the host pass of hipcc type-checks this builtin too and insists on a constant scalar offset there: device code only)
             auto la = [&](const int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dst + STEP * i * BK), 16, a_cur[i], s_aoff, 0, 0);
+#endif
             };
             auto lb = [&](const int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(dst + (BM + STEP * i) * BK), 16, b_cur[i], s_boff, 0, 0);
+#endif
             };
             auto lpost = [&]() {
                 s_aoff += BKE * ESZ;
