@@ -617,6 +617,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
             for (int i = 0; i < IB; ++i) b_last[i] = lane_c < rem ? b_vo[i] : OOB;
             int s_j = 0, s_kr = 0, s_kq = -1, s_aoff = 0, s_boff = 0, s_tapb = -p.Cin * ESZ, s_taps = taps + 1;
+            const int s_dq = p.x_cstride * ESZ, s_dr = (p.W - p.kw + 1) * p.x_cstride * ESZ;      // next tap of the row / first tap of the next row
+            int tap_off = -s_dq;
             auto tap_advance = [&]() {
                 --s_taps;
                 if (s_taps <= 0) {                                   // past K: all-zero chunks from here on
@@ -631,7 +633,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 const bool wq = s_kq == p.kw;
                 s_kq = wq ? 0 : s_kq;
                 s_kr += wq ? 1 : 0;
-                s_aoff = (s_kr * p.W + s_kq) * p.x_cstride * ESZ;
+                // (a lane's own offset may be NEGATIVE - the window origin of a padded convolution lies above / left of the image - and the
+                //  buffer instruction range-checks the per-lane offset as unsigned: the tap's offset is added per lane, once per tap, so
+                //  that a valid lane's offset is never negative; the scalar offset carries the channel position inside the tap only)
+                tap_off += wq ? s_dr : s_dq;                         // byte offset of tap (s_kr, s_kq) from the window origin
+                s_aoff = 0;
                 s_tapb += p.Cin * ESZ;
                 s_boff = s_tapb;
                 s_j = cpt;
@@ -639,7 +645,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
                 for (int i = 0; i < IA; ++i) {
                     const bool ok = (int)((unsigned)(a_iy0[i] + s_kr) < (unsigned)p.H) & (int)((unsigned)(a_ix0[i] + s_kq) < (unsigned)p.W);
-                    a_full[i] = ok ? a_vo[i] : OOB;
+                    a_full[i] = ok ? a_vo[i] + tap_off : OOB;
                     a_last[i] = lane_c < rem ? a_full[i] : OOB;
                     a_cur[i] = last_now ? a_last[i] : a_full[i];
                 }
