@@ -105,6 +105,33 @@ __device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
             m[e] = sizeof(T) == 2 ? (T)-65504.f : (T)-3.402823466e+38f;      // lowest finite value of the element type
             mi[e] = -1;
         }
+        if (q.k == 3) {
+            // 3x3 windows (every pooling of the reference nets that rides in a convolution launch): all nine loads in flight before the
+            // first compare.  The loop below waits for each load in turn - 18 dependent round trips per thread made the 92 pooling
+            // workgroups of an inception level (2 us of work) the LONGEST workgroups of a 5 us launch (round 4).  Taps outside the image
+            // load the nearest pixel inside (a valid address) and are skipped by the compares, so the maximum and the first-maximum
+            // index are exactly the loop's.
+            const int y0 = oy * q.stride - q.pad, x0 = ox * q.stride - q.pad;
+            vec_t v[9];
+            int id[9];
+            bool in[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = min(max(y0 + r, 0), q.H - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int ix = min(max(x0 + c, 0), q.W - 1);
+                    in[3 * r + c] = (int)((unsigned)(y0 + r) < (unsigned)q.H) & (int)((unsigned)(x0 + c) < (unsigned)q.W);
+                    id[3 * r + c] = iy * q.W + ix;
+                    v[3 * r + c] = *(const vec_t*)(xb + (size_t)id[3 * r + c] * q.x_cstride);
+                }
+            }
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+                for (int e = 0; e < EPS; ++e)
+                    if ((int)in[t9] & (int)(v[t9][e] > m[e])) { m[e] = v[t9][e]; mi[e] = id[t9]; }
+        } else
         for (int iy = hs; iy < he; ++iy)
             for (int ix = ws; ix < we; ++ix) {
                 const vec_t v = *(const vec_t*)(xb + ((size_t)iy * q.W + ix) * q.x_cstride);
@@ -610,13 +637,37 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             // per-lane offsets are computed THEN (vector ALU, once per tap), the chunks of the tap differ only in the SCALAR offset of
             // the buffer instruction, and the partial last chunk of a tap (Cin not a multiple of the chunk) swaps in pre-masked offsets.
             // Per chunk: ~16 scalar instructions, no vector instruction, two LDS-DMA pieces.
+            // A vector instruction of a loading wave is the expensive kind here: v_mfma_f32_32x32x2_f32 occupies the vector ALU the
+            // loading wave shares with a multiplying wave, so each one waits for a gap between MFMAs (a tap change of ~10 vector
+            // instructions measured 0.26 us against 0.14 us for a plain chunk: tools/conv_timeline.py on a 3x3 with one chunk per
+            // tap).  So the halo tests of ALL taps are made once, in the prologue, into one bit per tap and lane (taps <= 32:
+            // plan_tiles_cfg), the buffer's base is moved back by the largest negative window offset so that the tap offset can ride
+            // in the scalar offset too, and a tap change is and + compare + select per staged row.
             const int cpt = (p.Cin + BKE - 1) / BKE;                 // chunks per tap
             const int rem = p.Cin - (cpt - 1) * BKE;                 // channels the last chunk of a tap covers
             const bool partial = rem != BKE;
-            int a_full[IA], a_last[IA], a_cur[IA], b_last[IB], b_cur[IB];
+            const int bias = (p.pad * p.W + p.pad) * p.x_cstride * ESZ;      // bytes: the most negative (window origin - image origin)
+            const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<T*>(px) - bias / ESZ, 0, (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * ESZ) + bias, 0x00020000);
+            unsigned okmask[IA];
+            int a_vb[IA], a_cur[IA], b_last[IB], b_cur[IB];
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                a_vb[i] = a_vo[i] + bias;                            // >= 0 for every lane whose tap is inside the image
+                if (taps == 1) {
+                    okmask[i] = (unsigned)((int)((unsigned)a_iy0[i] < (unsigned)p.H) & (int)((unsigned)a_ix0[i] < (unsigned)p.W));
+                } else {
+                    unsigned rows = 0, cols = 0;                     // bit r * kw of rows: filter row r inside; bit q of cols: filter column q inside
+                    for (int r = 0; r < p.kh; ++r) rows |= ((unsigned)(a_iy0[i] + r) < (unsigned)p.H ? 1u : 0u) << (r * p.kw);
+                    for (int q = 0; q < p.kw; ++q) cols |= ((unsigned)(a_ix0[i] + q) < (unsigned)p.W ? 1u : 0u) << q;
+                    okmask[i] = rows * cols;                         // bit r * kw + q (no carries: cols < 2^kw, the row bits are kw apart)
+                }
+            }
 #pragma unroll
             for (int i = 0; i < IB; ++i) b_last[i] = lane_c < rem ? b_vo[i] : OOB;
-            int s_j = 0, s_kr = 0, s_kq = -1, s_aoff = 0, s_boff = 0, s_tapb = -p.Cin * ESZ, s_taps = taps + 1;
+            const bool lane_in_rem = lane_c < rem;
+            int s_j = 0, s_kq = -1, s_aoff = 0, s_boff = 0, s_tapb = -p.Cin * ESZ, s_taps = taps + 1;
+            unsigned s_bit = 0;
             const int s_dq = p.x_cstride * ESZ, s_dr = (p.W - p.kw + 1) * p.x_cstride * ESZ;      // next tap of the row / first tap of the next row
             int tap_off = -s_dq;
             auto tap_advance = [&]() {
@@ -632,32 +683,31 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 ++s_kq;
                 const bool wq = s_kq == p.kw;
                 s_kq = wq ? 0 : s_kq;
-                s_kr += wq ? 1 : 0;
-                // (a lane's own offset may be NEGATIVE - the window origin of a padded convolution lies above / left of the image - and the
-                //  buffer instruction range-checks the per-lane offset as unsigned: the tap's offset is added per lane, once per tap, so
-                //  that a valid lane's offset is never negative; the scalar offset carries the channel position inside the tap only)
-                tap_off += wq ? s_dr : s_dq;                         // byte offset of tap (s_kr, s_kq) from the window origin
-                s_aoff = 0;
+                tap_off += wq ? s_dr : s_dq;                         // byte offset of this tap from the window origin
+                s_bit = s_bit ? s_bit << 1 : 1u;
+                s_aoff = tap_off;
                 s_tapb += p.Cin * ESZ;
                 s_boff = s_tapb;
                 s_j = cpt;
                 const bool last_now = partial && cpt == 1;
+                if (last_now) {                                      // (uniform: one chunk per tap and that chunk is partial)
 #pragma unroll
-                for (int i = 0; i < IA; ++i) {
-                    const bool ok = (int)((unsigned)(a_iy0[i] + s_kr) < (unsigned)p.H) & (int)((unsigned)(a_ix0[i] + s_kq) < (unsigned)p.W);
-                    a_full[i] = ok ? a_vo[i] + tap_off : OOB;
-                    a_last[i] = lane_c < rem ? a_full[i] : OOB;
-                    a_cur[i] = last_now ? a_last[i] : a_full[i];
+                    for (int i = 0; i < IA; ++i) a_cur[i] = ((int)((okmask[i] & s_bit) != 0) & (int)lane_in_rem) ? a_vb[i] : OOB;
+#pragma unroll
+                    for (int i = 0; i < IB; ++i) b_cur[i] = b_last[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < IA; ++i) a_cur[i] = (okmask[i] & s_bit) != 0 ? a_vb[i] : OOB;
+#pragma unroll
+                    for (int i = 0; i < IB; ++i) b_cur[i] = b_vo[i];
                 }
-#pragma unroll
-                for (int i = 0; i < IB; ++i) b_cur[i] = last_now ? b_last[i] : b_vo[i];
             };
             tap_advance();
             auto lpre = [&](const int buf) { dst = smem + buf * BUF_FLOATS + lds_wave_base; };
             // (the host pass of hipcc type-checks this builtin too and insists on a constant scalar offset there: device code only)
             auto la = [&](const int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(dst + STEP * i * BK), 16, a_cur[i], s_aoff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rxb, (lds_ptr)(dst + STEP * i * BK), 16, a_cur[i], s_aoff, 0, 0);
 #endif
             };
             auto lb = [&](const int i) {
@@ -672,9 +722,9 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 if (__builtin_expect(s_j <= 1, 0)) {      // (one rarely taken branch on the common path)
                     if (s_j == 0) {
                         tap_advance();
-                    } else if (partial) {
+                    } else if (partial) {                   // the tap's last chunk covers `rem` channels only
 #pragma unroll
-                        for (int i = 0; i < IA; ++i) a_cur[i] = a_last[i];
+                        for (int i = 0; i < IA; ++i) a_cur[i] = lane_in_rem ? a_cur[i] : OOB;
 #pragma unroll
                         for (int i = 0; i < IB; ++i) b_cur[i] = b_last[i];
                     }
@@ -1845,7 +1895,7 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
         const int taps = ps[i].kh * ps[i].kw, cpt = cdiv(ps[i].Cin, bke);
         const long long xb = (((long long)ps[i].N * ps[i].H * ps[i].W - 1) * ps[i].x_cstride + ps[i].Cin) * esz;
         const long long wb = (long long)ps[i].Cout * ps[i].K * esz;
-        const bool lean = lean_ok && xb < (1ll << 31) && wb < (1ll << 31) && (taps == 1 || 2ll * cpt * bke <= 3ll * ps[i].Cin);
+        const bool lean = lean_ok && xb < (1ll << 31) && wb < (1ll << 31) && taps <= 32 && (taps == 1 || 2ll * cpt * bke <= 3ll * ps[i].Cin);      // (one bit per tap)
         ps[i].lean_chunks = lean ? taps * cpt : 0;
     }
     return total;
