@@ -627,7 +627,12 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             b_vo[i] = n < p.Cout ? (n * p.K + lane_c) * ESZ : OOB;
         }
         float* dst = smem;
-        if constexpr (ROLES) {
+        // which of the two scalar-addressed loaders: plan_tiles_cfg marks the problems that take the scalar-light one (kw_magic, which only the
+        // per-lane loader reads, is -1 then) - 1x1 filters and filters whose taps span several chunks; split-role shapes only
+        bool light = false;
+        if constexpr (ROLES) light = p.kw_magic == -1;
+        if (light) {
+          if constexpr (ROLES) {
             // ---- round 4: the same loader with its bookkeeping off the critical path.  Elimination builds of the split-role 32 x 32
             // shape (profiles/experiments/r04_elimination_cfg23.txt): 0.125 us per chunk with the staging compiled out (the four MFMAs
             // are 0.117), 0.159 us with the MFMAs compiled out, 0.179 us as built - and the same with every workgroup staging the SAME
@@ -731,6 +736,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 }
             };
             pipeline(lpre, la, lb, lpost);
+          }
         } else {
         int s_kr = 0, s_kq = 0, s_kc = 0, s_koff = 0, s_kb = 0, s_left = nchunks;      // wave-uniform K position of the next chunk
         bool cvalid = false;
@@ -1708,6 +1714,11 @@ constexpr int kCfgLdsBytes[] = {
     FCN_CONV_CONFIGS(X)
 #undef X
 };
+constexpr bool kCfgRoles[] = {
+#define X(I, A, B, C_, D, E, F, G, H) Cfg<A, B, C_, D, E, F, G, H>::ROLES,
+    FCN_CONV_CONFIGS(X)
+#undef X
+};
 constexpr int kCfgWavesK[] = {
 #define X(I, A, B, C_, D, E, F, G, H) E,
     FCN_CONV_CONFIGS(X)
@@ -1897,6 +1908,13 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
         const long long wb = (long long)ps[i].Cout * ps[i].K * esz;
         const bool lean = lean_ok && xb < (1ll << 31) && wb < (1ll << 31) && taps <= 32 && (taps == 1 || 2ll * cpt * bke <= 3ll * ps[i].Cin);      // (one bit per tap)
         ps[i].lean_chunks = lean ? taps * cpt : 0;
+        // The scalar-light form of that loader (conv_body; split-role shapes): a tap change costs it a few vector instructions and its
+        // prologue one bit per tap, a chunk inside a tap nothing - it pays for 1x1 filters and for taps of several chunks (measured, cfg 23,
+        // M = 784, N = 320, 3x3: one chunk per tap 4.9 -> 5.5 us, two 6.5 -> 7.2, five 11.3 -> 10.7, ten 19.3 -> 16.6;
+        // profiles/experiments/r04_sweep_loader.txt).  $FCN_CONV_LIGHT: the least chunks per tap that take it (0: never).
+        static const int light_min = getenv("FCN_CONV_LIGHT") ? atoi(getenv("FCN_CONV_LIGHT")) : 4;
+        ps[i].kw_magic = (65536 + ps[i].kw - 1) / ps[i].kw;      // (what fill() set: this array may have been planned for another configuration before)
+        if (lean && kCfgRoles[cfg] && light_min > 0 && (taps == 1 || cpt >= light_min)) ps[i].kw_magic = -1;
     }
     return total;
 }
