@@ -72,7 +72,10 @@ const float* zero_page_for_current_device(int* rc) {
 
 namespace {
 
-constexpr int kPoolItemsPerThread = 2;
+#ifndef FCN_POOL_ITEMS
+#define FCN_POOL_ITEMS 2      // (experiments: make exp EXP=-DFCN_POOL_ITEMS=1 EXPSRC=conv_fwd)
+#endif
+constexpr int kPoolItemsPerThread = FCN_POOL_ITEMS;
 
 // MAX pooling riding in a convolution launch (Caffe semantics as in pointwise.hip: window clipped to the image, strict
 // '>' so the first maximum in raster order wins).  One work item = 4 channels of one output pixel.
@@ -655,6 +658,8 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<T*>(px) - bias / ESZ, 0, (int)((((long long)p.N * p.H * p.W - 1) * p.x_cstride + p.Cin) * ESZ) + bias, 0x00020000);
             unsigned okmask[IA];
+            unsigned row_bits = 0;                                   // (scalar) bit r * kw for every filter row r
+            for (int r = 0; r < p.kh; ++r) row_bits |= 1u << (r * p.kw);
             int a_vb[IA], a_cur[IA], b_last[IB], b_cur[IB];
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
@@ -662,10 +667,14 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                 if (taps == 1) {
                     okmask[i] = (unsigned)((int)((unsigned)a_iy0[i] < (unsigned)p.H) & (int)((unsigned)a_ix0[i] < (unsigned)p.W));
                 } else {
-                    unsigned rows = 0, cols = 0;                     // bit r * kw of rows: filter row r inside; bit q of cols: filter column q inside
-                    for (int r = 0; r < p.kh; ++r) rows |= ((unsigned)(a_iy0[i] + r) < (unsigned)p.H ? 1u : 0u) << (r * p.kw);
-                    for (int q = 0; q < p.kw; ++q) cols |= ((unsigned)(a_ix0[i] + q) < (unsigned)p.W ? 1u : 0u) << q;
-                    okmask[i] = rows * cols;                         // bit r * kw + q (no carries: cols < 2^kw, the row bits are kw apart)
+                    // the filter rows inside the image are a RANGE [lo, hi) of r (likewise the columns), so both masks are bit fields in
+                    // closed form - straight-line code, no loop over the taps: bit r * kw of `rows`, bit q of `cols`, and their product
+                    // has bit r * kw + q (no carries: cols < 2^kw, the row bits are kw apart; taps <= 31)
+                    const int lo_r = min(max(-a_iy0[i], 0), p.kh), hi_r = min(max(p.H - a_iy0[i], 0), p.kh);
+                    const int lo_q = min(max(-a_ix0[i], 0), p.kw), hi_q = min(max(p.W - a_ix0[i], 0), p.kw);
+                    const unsigned rows = row_bits & (((1u << (max(hi_r - lo_r, 0) * p.kw)) - 1u) << (lo_r * p.kw));
+                    const unsigned cols = ((1u << max(hi_q - lo_q, 0)) - 1u) << lo_q;
+                    okmask[i] = rows * cols;
                 }
             }
 #pragma unroll
@@ -1906,7 +1915,7 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
         const int taps = ps[i].kh * ps[i].kw, cpt = cdiv(ps[i].Cin, bke);
         const long long xb = (((long long)ps[i].N * ps[i].H * ps[i].W - 1) * ps[i].x_cstride + ps[i].Cin) * esz;
         const long long wb = (long long)ps[i].Cout * ps[i].K * esz;
-        const bool lean = lean_ok && xb < (1ll << 31) && wb < (1ll << 31) && taps <= 32 && (taps == 1 || 2ll * cpt * bke <= 3ll * ps[i].Cin);      // (one bit per tap)
+        const bool lean = lean_ok && xb < (1ll << 31) && wb < (1ll << 31) && taps <= 31 && (taps == 1 || 2ll * cpt * bke <= 3ll * ps[i].Cin);      // (one bit per tap)
         ps[i].lean_chunks = lean ? taps * cpt : 0;
         // The scalar-light form of that loader (conv_body; split-role shapes): a tap change costs it a few vector instructions and its
         // prologue one bit per tap, a chunk inside a tap nothing - it pays for 1x1 filters and for taps of several chunks (measured, cfg 23,
