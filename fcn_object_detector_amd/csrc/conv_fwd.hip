@@ -677,44 +677,39 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
                     okmask[i] = rows * cols;
                 }
             }
-#pragma unroll
-            for (int i = 0; i < IB; ++i) b_last[i] = lane_c < rem ? b_vo[i] : OOB;
             const bool lane_in_rem = lane_c < rem;
+            const bool last_always = partial && cpt == 1;            // one chunk per tap and that chunk is partial: every chunk is a "last" one
+            int b_tap[IB];                                           // what a tap's first chunk uses for the B rows
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                b_last[i] = lane_in_rem ? b_vo[i] : OOB;
+                b_tap[i] = last_always ? b_last[i] : b_vo[i];
+            }
+            if (last_always) {
+#pragma unroll
+                for (int i = 0; i < IA; ++i) okmask[i] = lane_in_rem ? okmask[i] : 0u;
+            }
             int s_j = 0, s_kq = -1, s_aoff = 0, s_boff = 0, s_tapb = -p.Cin * ESZ, s_taps = taps + 1;
             unsigned s_bit = 0;
             const int s_dq = p.x_cstride * ESZ, s_dr = (p.W - p.kw + 1) * p.x_cstride * ESZ;      // next tap of the row / first tap of the next row
             int tap_off = -s_dq;
+            // straight-line (selects, no branches): past K the tap bit is 0, which turns every A lane into an out-of-range offset by itself
             auto tap_advance = [&]() {
                 --s_taps;
-                if (s_taps <= 0) {                                   // past K: all-zero chunks from here on
-#pragma unroll
-                    for (int i = 0; i < IA; ++i) a_cur[i] = OOB;
-#pragma unroll
-                    for (int i = 0; i < IB; ++i) b_cur[i] = OOB;
-                    s_j = 0x7fffffff;
-                    return;
-                }
+                const bool live = s_taps > 0;
                 ++s_kq;
                 const bool wq = s_kq == p.kw;
                 s_kq = wq ? 0 : s_kq;
                 tap_off += wq ? s_dr : s_dq;                         // byte offset of this tap from the window origin
-                s_bit = s_bit ? s_bit << 1 : 1u;
+                s_bit = live ? (s_bit ? s_bit << 1 : 1u) : 0u;
                 s_aoff = tap_off;
                 s_tapb += p.Cin * ESZ;
                 s_boff = s_tapb;
-                s_j = cpt;
-                const bool last_now = partial && cpt == 1;
-                if (last_now) {                                      // (uniform: one chunk per tap and that chunk is partial)
+                s_j = live ? cpt : 0x7fffffff;
 #pragma unroll
-                    for (int i = 0; i < IA; ++i) a_cur[i] = ((int)((okmask[i] & s_bit) != 0) & (int)lane_in_rem) ? a_vb[i] : OOB;
+                for (int i = 0; i < IA; ++i) a_cur[i] = (okmask[i] & s_bit) != 0 ? a_vb[i] : OOB;
 #pragma unroll
-                    for (int i = 0; i < IB; ++i) b_cur[i] = b_last[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < IA; ++i) a_cur[i] = (okmask[i] & s_bit) != 0 ? a_vb[i] : OOB;
-#pragma unroll
-                    for (int i = 0; i < IB; ++i) b_cur[i] = b_vo[i];
-                }
+                for (int i = 0; i < IB; ++i) b_cur[i] = live ? b_tap[i] : OOB;
             };
             tap_advance();
             auto lpre = [&](const int buf) { dst = smem + buf * BUF_FLOATS + lds_wave_base; };
