@@ -72,10 +72,11 @@ const float* zero_page_for_current_device(int* rc) {
 
 namespace {
 
-#ifndef FCN_POOL_ITEMS
-#define FCN_POOL_ITEMS 2      // (experiments: make exp EXP=-DFCN_POOL_ITEMS=1 EXPSRC=conv_fwd)
-#endif
-constexpr int kPoolItemsPerThread = FCN_POOL_ITEMS;
+// work items (16 bytes of one output pixel) a pooling thread takes: one while the pooling is small - its workgroups are the launch's first
+// and a convolution tile shares their CUs, so they should be gone quickly (the 28 x 28 inception poolings: A levels 6.7 -> 6.1 us) - two
+// for the large ones, where twice the workgroups cost more than they save (56 x 56: 7.2 -> 7.7 us with one)
+constexpr int kPoolItemsPerThread = 2;
+constexpr int kPoolSmallItems = 128 * 1024;
 
 // MAX pooling riding in a convolution launch (Caffe semantics as in pointwise.hip: window clipped to the image, strict
 // '>' so the first maximum in raster order wins).  One work item = 4 channels of one output pixel.
@@ -86,9 +87,11 @@ __device__ __forceinline__ void pool_body(const PoolP& q, int wg) {
     const int cg = q.C / EPS;
     const T* x = reinterpret_cast<const T*>(q.x);
     T* y = reinterpret_cast<T*>(q.y);
+    const int ipt = q.items <= kPoolSmallItems ? 1 : kPoolItemsPerThread;      // (uniform; the host sizes wg_end the same way)
 #pragma unroll
     for (int it = 0; it < kPoolItemsPerThread; ++it) {
-        const int t = (wg * kPoolItemsPerThread + it) * NT + (int)threadIdx.x;
+        if (it >= ipt) return;
+        const int t = (wg * ipt + it) * NT + (int)threadIdx.x;
         if (t >= q.items) return;
         const int pix = t / cg;
         const int g = t - pix * cg;
@@ -2165,11 +2168,11 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
         int grid = ga.tile_end[ga.nprob - 1];
         int pool_wgs = 0;
         if (hg.npool > 0) {      // only with n <= kMaxGroup: a single launch
-            const int per_wg = kCfgThreads[g->cfg] * kPoolItemsPerThread;
             int end = 0;
             ga.npool = hg.npool;
             for (int i = 0; i < kMaxPool; ++i) {
                 ga.pool[i] = hg.pools[i < hg.npool ? i : hg.npool - 1];
+                const int per_wg = kCfgThreads[g->cfg] * (ga.pool[i].items <= kPoolSmallItems ? 1 : kPoolItemsPerThread);
                 if (i < hg.npool) end += (ga.pool[i].items + per_wg - 1) / per_wg;
                 ga.pool[i].wg_end = end;
             }
