@@ -103,26 +103,31 @@ def test_first_launch_of_every_kernel_happens_outside_the_stream_capture(gpu, mo
     real_call = L.call
 
     def spy(name, *a):
-        if name in ("fcn_graph_begin", "fcn_graph_end"):
+        if name in ("fcn_graph_begin", "fcn_graph_end", "fcn_graph_launch"):
             events.append(name)
         return real_call(name, *a)
 
     for i, op in enumerate(eng.ops):
         op.run = (lambda st, f=op.run, i=i: (events.append(("op", i)), f(st))[1])
-    # the graph with the copy nodes also holds the layout converters of the upload and of the download (round 4: the download's
-    # kernel used to be launched for the first time INSIDE the capture - nothing else runs it before the first forward())
-    up, down = eng._enqueue_upload, eng._enqueue_download
-    eng._enqueue_upload = lambda nm, st: (events.append(("up", nm)), up(nm, st))[1]
-    eng._enqueue_download = lambda nm, st: (events.append(("down", nm)), down(nm, st))[1]
+    # the graph behind forward() also holds the layout kernels of the upload and of the download (round 4: the download's kernel
+    # used to be launched for the first time INSIDE the capture - nothing else runs it before the first forward()); the copies
+    # themselves are plain async calls in front of and behind the graph launch, never graph nodes
+    for nm in ("_upload_convert", "_download_convert", "_upload_copy", "_download_copy"):
+        real = getattr(eng, nm)
+        setattr(eng, nm, (lambda name, st, real=real, nm=nm: (events.append((nm, name)), real(name, st))[1]))
     monkeypatch.setattr(L, "call", spy)
     x = np.random.default_rng(0).random((1, 3, 96, 128), dtype=np.float32)
     eng.host_array("data")[...] = x
     out = {k: v.copy() for k, v in eng.forward().items()}
-    begin = events.index("fcn_graph_begin")
+    begin, end = events.index("fcn_graph_begin"), len(events) - 1 - events[::-1].index("fcn_graph_end")
     n_ops = len(eng.ops)
-    io = [("up", "data")] + [("down", nm) for nm in eng.outputs]
-    assert [e for e in events[:begin] if e != "fcn_graph_end"] == [("op", i) for i in range(n_ops)] + io      # one eager pass of everything first
-    assert events[begin + 1:begin + 2 + n_ops + len(eng.outputs)] == [("up", "data")] + [("op", i) for i in range(n_ops)] + io[1:]      # then the captured one
+    ops = [("op", i) for i in range(n_ops)]
+    up = [("_upload_copy", "data"), ("_upload_convert", "data")]
+    down = [e for nm in eng.outputs for e in (("_download_convert", nm), ("_download_copy", nm))]
+    assert [e for e in events[:begin] if e != "fcn_graph_end"] == ops + up + down      # one eager pass of everything first
+    assert events[begin + 1:end] == [("_upload_convert", "data")] + ops + [("_download_convert", nm) for nm in eng.outputs]      # the capture: kernels only
+    tail = [e for e in events[end + 1:] if e != "fcn_graph_launch"]
+    assert tail == [("_upload_copy", "data")] + [("_download_copy", nm) for nm in eng.outputs]      # the frame itself: copy, graph, copies
     assert np.isfinite(out["coverage"]).all()
     again = eng.forward()                                   # a replay of the captured graph gives the same frame the same result
     assert all(np.array_equal(again[k], out[k]) for k in out)
