@@ -114,6 +114,59 @@ class GridDecoder:
         return out
 
 
+class ScoreMasks:
+    """Device side of what run_detector2 does with its score maps after net.forward() (scripts/fcn_object_detector.py:208-236 and
+    create_mask_labels :279-303; csrc/mask.hip): threshold, x 255, cv.resize to the window, uint8 cast, OR into the frame-sized
+    probability map, and per (window, class) the bounding rectangle of the largest contour."""
+
+    def __init__(self, n_windows: int, num_classes: int, w: int, h: int, frame_h: int, frame_w: int):
+        self.n, self.C, self.w, self.h, self.frame_h, self.frame_w = int(n_windows), int(num_classes), int(w), int(h), int(frame_h), int(frame_w)
+        lib = L.load()
+        self.maps = self.n * (self.C - 1)
+        self.ws = DeviceBuffer(max(int(lib.fcn_score_masks_workspace_bytes(self.n, self.C, self.w, self.h)), 16), zero=False)
+        self.d_pmap = DeviceBuffer((self.frame_h * self.frame_w + 3) // 4 * 4, zero=True)
+        self.d_out = DeviceBuffer(max(self.maps, 1) * 5 * 4, zero=True)
+        self._pinned = [PinnedArray(((self.frame_h * self.frame_w + 3) // 4,)), PinnedArray((max(self.maps, 1) * 5,))]
+        self.h_pmap = self._pinned[0].array.view(np.uint8)[:self.frame_h * self.frame_w].reshape(self.frame_h, self.frame_w)
+        self.h_out = self._pinned[1].array.view(np.int32).reshape(-1, 5)
+
+    def launch(self, score_ptr: int, H: int, W: int, cstride: int, coffset: int, rects: np.ndarray, prob_thresh: float,
+               stream: Optional[int]) -> None:
+        rects = np.ascontiguousarray(rects, np.int32).reshape(self.n, 4)
+        L.call("fcn_memset_async", self.d_pmap.ptr, 0, self.d_pmap.nbytes, stream)
+        L.call("fcn_score_masks", score_ptr, self.n, self.C, H, W, cstride, coffset, rects.ctypes.data, float(np.float32(prob_thresh)),
+               self.d_pmap.ptr, self.frame_h, self.frame_w, self.ws.ptr, self.d_out.ptr, stream)
+        L.call("fcn_memcpy_d2h_async", self.h_pmap.ctypes.data, self.d_pmap.ptr, self.frame_h * self.frame_w, stream)
+        L.call("fcn_memcpy_d2h_async", self.h_out.ctypes.data, self.d_out.ptr, self.maps * 20, stream)
+        self._rects = rects
+
+    def fetch(self, stream: Optional[int], padding: int = 10):
+        """-> (pmap (frame_h, frame_w) uint8, [(np.array([x, y, w, h]), class index), ...]) in the reference's order (:218-236)."""
+        L.call("fcn_stream_sync", stream)
+        bboxs = []
+        for n in range(self.n):
+            x, y = int(self._rects[n, 0]), int(self._rects[n, 1])
+            for c in range(1, self.C):
+                found, rx, ry, rw, rh = (int(v) for v in self.h_out[n * (self.C - 1) + c - 1])
+                if found:
+                    bboxs.append((np.array([rx + x - padding, ry + y - padding, rw + 2 * padding, rh + 2 * padding]), c))
+        return self.h_pmap.copy(), bboxs
+
+
+def score_masks_from_maps(feature_maps: np.ndarray, rects, frame_hw: Tuple[int, int], prob_thresh: float = 0.5, padding: int = 10):
+    """Run the device kernels of ScoreMasks on host score maps (N, C, H, W) float32 (NCHW, as net.blobs['score'].data)."""
+    fm = np.ascontiguousarray(feature_maps, F32)
+    n, c, h, w = fm.shape
+    rects = np.ascontiguousarray(rects, np.int32).reshape(n, 4)
+    L.call("fcn_init", 0)
+    nhwc = np.ascontiguousarray(fm.transpose(0, 2, 3, 1))
+    d = DeviceBuffer(nhwc.nbytes, zero=False)
+    L.call("fcn_memcpy_h2d_async", d.ptr, nhwc.ctypes.data, nhwc.nbytes, None)
+    sm = ScoreMasks(n, c, int(rects[0, 2]), int(rects[0, 3]), frame_hw[0], frame_hw[1])
+    sm.launch(d.ptr, h, w, c, 0, rects, prob_thresh, None)
+    return sm.fetch(None, padding)
+
+
 def detect_from_maps(cvg: np.ndarray, bbox: np.ndarray, im_w: int, im_h: int, prob_thresh: float = 0.5,
                      min_boxes: int = 3, eps: float = 0.2, min_height: int = 20,
                      round_mode: int = L.RECT_ROUND_NEAREST_EVEN) -> List[Tuple[np.ndarray, np.ndarray]]:
@@ -339,6 +392,46 @@ class FCNObjectDetector:
                 boxes[:, 1] += y; boxes[:, 3] += y
             out.append((boxes, labels))
         return rects, out
+
+    def run_detector2_masks(self, frame: np.ndarray, stride: int = 1, score_blob: str = "score", padding: int = 10):
+        """run_detector2 as the node runs it (scripts/fcn_object_detector.py:178-236; it calls detection_window_roi with stride 1): the
+        frame is normalised as a whole and cut into stride^2 + 1 windows, ONE batched forward, then - on the device - the score maps
+        of `score_blob` (the node reads net.blobs['score']) are thresholded at detection_threshold, scaled to 0..255, resized to their
+        windows, OR-ed into the frame-sized probability map the node publishes on /fcn_object_detector/..., and every (window, class)
+        map gives the padded bounding rectangle of its largest contour.  -> (pmap (h, w) uint8, [(np.array([x, y, w, h]), class), ...])."""
+        eng = self.engine
+        frame = np.ascontiguousarray(frame, np.uint8)
+        if frame.ndim != 3 or frame.shape[2] != 3:
+            raise ValueError("expected a BGR uint8 frame")
+        rects = detection_window_roi(frame.shape, stride)
+        if len(rects) != self.batch:
+            raise ValueError("stride %d makes %d windows; the engine's batch is %d" % (stride, len(rects), self.batch))
+        sb = eng.blobs[score_blob]
+        if sb.esize != 4 or len(sb.shape) != 4:
+            raise NotImplementedError("score blob %s must be a 4-d float32 blob" % score_blob)
+        h, w, _c = frame.shape
+        _n, C_, sh, sw = sb.shape
+        key = (len(rects), C_, int(rects[0][2]), int(rects[0][3]), h, w)
+        if getattr(self, "_score_masks_key", None) != key:
+            self._score_masks = ScoreMasks(*key)
+            self._score_masks_key = key
+        with eng.lock:
+            L.call("fcn_init", eng.device)
+            if self._frame_dev is None or self._frame_dev.nbytes < frame.nbytes:
+                self._frame_dev = DeviceBuffer(frame.nbytes, zero=False)
+                self._frame_pinned = PinnedArray(((frame.nbytes + 3) // 4,))
+            stage = self._frame_pinned.array.view(np.uint8)[:frame.nbytes]
+            stage[...] = frame.reshape(-1)
+            data = eng.blobs["data"]
+            L.call("fcn_memcpy_h2d_async", self._frame_dev.ptr, stage.ctypes.data, frame.nbytes, eng.stream)
+            L.call("fcn_preprocess_bgr8_rois", self._frame_dev.ptr, h, w, rects.ctypes.data, len(rects), data.ptr, self._half_flag(data),
+                   self.im_height, self.im_width, data.cstride, data.upload_shift, self._minmax.ptr, eng.stream)
+            eng.forward_enqueue()
+            for op in eng._lazy_blob_ops.get(score_blob, ()):
+                op.run(eng.stream)
+            self._score_masks.launch(sb.buf.ptr, sh, sw, sb.cstride, sb.coffset, rects, self.prob_thresh, eng.stream)
+            data.host_valid = False
+            return self._score_masks.fetch(eng.stream, padding)
 
     def collect_batch(self) -> List[Tuple[np.ndarray, np.ndarray]]:
         if getattr(self, "_outstanding", None) is None:

@@ -138,6 +138,8 @@ PROTOTYPES = {
     "fcn_preprocess_bgr8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp]),
     "fcn_detect_workspace_bytes": (_sz, [C.POINTER(DetectParams), _i]),
     "fcn_detect_decode_group": (_i, [_vp, _vp, _i, _sz, _sz, C.POINTER(DetectParams), _vp, _vp, _vp, _vp, _vp]),
+    "fcn_score_masks_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "fcn_score_masks": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _i, _i, _vp, _vp, _vp]),
     "fcn_gen_targets": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fcn_gen_targets_nhwc": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "fcn_conv2d_wgrad_workspace_floats": (_sz, [C.POINTER(ConvDesc), C.POINTER(_i)]),

@@ -333,6 +333,20 @@ int  fcn_detect_decode_group(const float* cvg, const float* bbox, int batch,
                              int32_t* out_rects, int32_t* out_weights,
                              int32_t* out_count, fcn_stream_t s);
 
+/* ---- run_detector2 after net.forward(): the node's score maps -> the frame-sized probability map and one box per (window, class)
+ *      (scripts/fcn_object_detector.py:208-236 with create_mask_labels :279-303; OpenCV's cv.resize / findContours / contourArea /
+ *      boundingRect restated in oracle/mask_ref.py).  score: NHWC float32 blob of N windows (the node's net.blobs['score']), classes at
+ *      channels coffset .. coffset + C - 1 of cstride; class 0 is the background and is skipped, as in the reference.  h_rects: HOST
+ *      array N x (x, y, w, h), the windows' places in the frame - all of one size (detection_window_roi :257-277), N <= 32.
+ *      For every window n and class c = 1 .. C-1: values below prob_thresh become 0, x 255, bilinear resize to (w, h), truncating
+ *      uint8 cast; the map is OR-ed into pmap (frame_h x frame_w bytes on the device, 4-byte aligned, zeroed by the caller) at the
+ *      window's place, and out[(n * (C - 1) + c - 1) * 5 ..] = found, x, y, w, h: the bounding rectangle, in WINDOW coordinates, of the
+ *      contour with the largest area (found = 0: no contour of positive area; the reference's 10-pixel padding and the window's origin
+ *      are added by the caller).  d_workspace: fcn_score_masks_workspace_bytes() bytes. ---- */
+size_t fcn_score_masks_workspace_bytes(int n_windows, int num_classes, int w, int h);
+int  fcn_score_masks(const float* score, int N, int C, int H, int W, int cstride, int coffset, const int32_t* h_rects, float prob_thresh,
+                     uint8_t* pmap, int frame_h, int frame_w, void* d_workspace, int32_t* out, fcn_stream_t s);
+
 /* ---- DetectNet target generation: ArgumentationEngine.bounding_box_parameterized_labels
  *      (argumentation_engine.py:69-109, 26-55, 272-292) ---- */
 /* rects: [total][4] int32 (x, y, w, h); labels: [total] int32; rect_offsets: [batch+1] int32 prefix.

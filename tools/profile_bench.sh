@@ -41,9 +41,11 @@ prof ${TAG}_f16_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU
 # the hipGraph replay itself, the launch path `value` is measured on: one frame in flight (what `roofline` is computed from), then four
 unset FCN_NO_GRAPH
 prof ${TAG}_stats --stats -- python3 "$ROOT/bench.py" $ONE --no-train --trace-clean > "$OUT/${TAG}_bench_under_rocprof.json"
-# four frames in flight, config 2's region (the hipGraph with the copy nodes) included: round 3 ran this pass with --no-io-region after three
-# segmentation faults in that graph's launch; round 4 launches the I/O kernels eagerly before the capture (Engine._capture) and runs it whole, ONCE
-prof ${TAG}_inflight --stats -- python3 "$ROOT/bench.py" $ARGS --no-train > "$OUT/${TAG}_bench_inflight_under_rocprof.json"
+# four frames in flight: kernels only (--no-io-region).  With config 2's region in it - async copies + graph launches on four replica streams -
+# hipGraphLaunch dies with SIGSEGV inside the runtime under rocprofv3 --kernel-trace, and ONLY there: three of five runs in round 3 (graph
+# with memcpy nodes), again in round 4 after every kernel of the graph was launched eagerly before its capture, and again with the copies moved
+# out of the graph (tracebacks: profiles/experiments/r04_graph_*segv*.txt).  One frame in flight passes under the profiler; four pass without it.
+prof ${TAG}_inflight --stats -- python3 "$ROOT/bench.py" $ARGS --no-train --no-io-region > "$OUT/${TAG}_bench_inflight_under_rocprof.json"
 [ -d "$OUT/${TAG}_stats" ] || { echo "graph-replay trace missing: using the plain-launch trace for the kernel statistics"; cp -r "$OUT/${TAG}_pstats" "$OUT/${TAG}_stats"; }
 for pair in stats:bench_kernel_stats pstats:bench_plain_kernel_stats tstats:train_kernel_stats fetch:bench_pmc_fetch write:bench_pmc_write mfma:bench_pmc_mfma tmfma:train_pmc_mfma \
             inflight:bench_inflight_kernel_stats f16_stats:infer32_f16_kernel_stats f16_fetch:infer32_f16_pmc_fetch f16_write:infer32_f16_pmc_write f16_mfma:infer32_f16_pmc_mfma; do
