@@ -523,7 +523,9 @@ def main() -> None:
     spec.infer()
     params = fill_params(spec, seed=1234)
     depth = max(args.in_flight, 1)
-    pipe = ForwardPipeline(lambda: NetSpec(msg, "TEST"), params=params, device=local, depth=depth)
+    # (one frame in flight - the profiled single-stream mode - has no reason to cap the tiles' LDS footprint: the cap buys co-residency of
+    #  DIFFERENT frames' workgroups on a CU)
+    pipe = ForwardPipeline(lambda: NetSpec(msg, "TEST"), params=params, device=local, depth=depth, max_lds_kb=36 if depth > 1 else None)
     eng = pipe.engines[0]
 
     # synthetic frame: random uint8 BGR -> the node's demean/min-max normalisation (values in [0,1])

@@ -1931,7 +1931,10 @@ int plan_tiles_cfg(int cfg, ConvP* ps, int n) {
         // profiles/experiments/r04_sweep_loader.txt).  $FCN_CONV_LIGHT: the least chunks per tap that take it (0: never).
         static const int light_min = getenv("FCN_CONV_LIGHT") ? atoi(getenv("FCN_CONV_LIGHT")) : 4;
         ps[i].kw_magic = (65536 + ps[i].kw - 1) / ps[i].kw;      // (what fill() set: this array may have been planned for another configuration before)
-        if (lean && kCfgRoles[cfg] && light_min > 0 && (taps == 1 || cpt >= light_min)) ps[i].kw_magic = -1;
+        // (larger split-role tiles stage two or more pieces per wave and operand: the old loader pays its per-piece vector instructions for
+        //  each, and the scalar-light one wins at every chunk count - 64 x 32, conv2/3x3 with two chunks per tap: 37.1 -> 32.9 us)
+        const bool big_tile = bm * bn > 32 * 32;
+        if (lean && kCfgRoles[cfg] && light_min > 0 && (taps == 1 || cpt >= light_min || big_tile)) ps[i].kw_magic = -1;
     }
     return total;
 }
