@@ -249,6 +249,29 @@ class Net(object):
                     res[b] = eng.read_blob(b)
             return res
 
+    def score_masks(self, rects, frame_hw, prob_thresh, score_blob="score", padding=10):
+        """Extension (not in pycaffe): what run_detector2 does with net.blobs['score'].data after net.forward() (reference:
+        scripts/fcn_object_detector.py:208-236 with create_mask_labels :279-303), on the device: -> (pmap (h, w) uint8,
+        [(np.array([x, y, w, h]), class index), ...]).  `rects`: the windows' (x, y, w, h) in the frame, one per image of the batch."""
+        from fcn_object_detector_amd.detector import ScoreMasks
+        with self._lock:
+            _L.call("fcn_init", self._device)
+            eng = self._engine
+            sb = eng.blobs[score_blob]
+            if sb.esize != 4 or len(sb.shape) != 4:
+                raise NotImplementedError("score blob %s must be a 4-d float32 blob" % score_blob)
+            rects = np.ascontiguousarray(rects, np.int32).reshape(-1, 4)
+            n, c, sh, sw = sb.shape
+            if len(rects) != n:
+                raise ValueError("%d windows for a batch of %d" % (len(rects), n))
+            key = (n, c, int(rects[0, 2]), int(rects[0, 3]), int(frame_hw[0]), int(frame_hw[1]))
+            if getattr(self, "_score_masks_key", None) != key:
+                self._score_masks, self._score_masks_key = ScoreMasks(*key), key
+            for op in eng._lazy_blob_ops.get(score_blob, ()):
+                op.run(eng.stream)
+            self._score_masks.launch(sb.buf.ptr, sh, sw, sb.cstride, sb.coffset, rects, prob_thresh, eng.stream)
+            return self._score_masks.fetch(eng.stream, padding)
+
     def backward(self, **kwargs):
         raise NotImplementedError("Net.backward(): training runs through the `caffe train` tool")
 

@@ -110,3 +110,23 @@ def test_run_detector2_masks_through_the_engine(gpu):
     with pytest.raises(ValueError):
         det.run_detector2_masks(frame, stride=2, score_blob="pool_score")
     eng.close()
+
+
+def test_pycaffe_front_end_score_masks(gpu, tmp_path):
+    """The node-side form: net.forward() then net.score_masks(rects, frame shape, threshold) == the oracle on net.blobs[...].data."""
+    import sys
+    from conftest import PYCAFFE
+    if PYCAFFE not in sys.path:
+        sys.path.insert(0, PYCAFFE)
+    import caffe
+    path = str(tmp_path / "deploy.prototxt")
+    with open(path, "w") as f:
+        f.write(models.vgg16_fcn_bbox_deploy(2, 64, 96, 4))
+    caffe.set_device(0); caffe.set_mode_gpu()
+    net = caffe.Net(path, caffe.TEST)
+    net.blobs["data"].data[...] = np.random.default_rng(2).random((2, 3, 64, 96))
+    net.forward()
+    rects = detection_window_roi((50, 70, 3), 1)
+    pmap, boxes = net.score_masks(rects, (50, 70), 0.25, score_blob="pool_score")
+    want = M.run_detector2_post(net.blobs["pool_score"].data, rects, (50, 70), np.float32(0.25))
+    assert same((pmap, boxes), want) >= 0 and pmap.shape == (50, 70)
