@@ -155,7 +155,7 @@ class Engine:
     def __init__(self, spec: NetSpec, data_shapes: Optional[Dict[str, Tuple[int, ...]]] = None,
                  params: Optional[Dict[str, List[np.ndarray]]] = None, device: int = 0,
                  fuse: bool = True, group_convs: bool = True, autotune: bool = True, dtype: str = "f32",
-                 tune_from: Optional["Engine"] = None, tune_max_lds_kb: Optional[int] = None):
+                 tune_from: Optional["Engine"] = None, tune_max_lds_kb: Optional[int] = None, tune_streams: Optional[int] = None):
         if dtype not in ("f32", "f16"):
             raise ValueError("dtype must be 'f32' or 'f16'")
         if dtype == "f16" and spec.phase != "TEST":
@@ -171,6 +171,7 @@ class Engine:
         # autotuner: only tile configurations whose workgroup holds at most this much LDS (engines that share the GPU with
         # other streams: small footprints let workgroups of concurrent launches fit on a CU side by side)
         self._tune_max_lds = int(tune_max_lds_kb if tune_max_lds_kb is not None else os.environ.get("FCN_TUNE_MAX_LDS_KB", "160")) * 1024
+        self._tune_streams = int(tune_streams if tune_streams is not None else os.environ.get("FCN_TUNE_STREAMS", "1"))      # > 1: throughput timing
         L.call("fcn_init", device)
         sp = C.c_void_p()
         L.call("fcn_stream_create", C.byref(sp))
@@ -715,6 +716,8 @@ class Engine:
             key += "|f16"
         if self._tune_max_lds < 160 * 1024:
             key += "|lds%d" % (self._tune_max_lds // 1024)
+        if self._tune_streams > 1:
+            key += "|x%d" % self._tune_streams
         return key
 
     def _tuned_cfg(self, name: str, arr, n: int, ws: DeviceBuffer, parr=None, npool: int = 0) -> int:
@@ -771,7 +774,29 @@ class Engine:
             if lib.fcn_conv2d_group_prepare_fused(arr, n, parr, npool, ws.ptr, cfg, C.byref(grp)) != 0:
                 continue      # a configuration that does not take this group (the first-layer kernel is shape-specific)
             ms = C.c_float()
-            if cold:
+            if self._tune_streams > 1:
+                # Throughput timing (engines that share the GPU with other frames, ForwardPipeline): the launch is issued on K streams
+                # at once, several times over - what is timed is how fast the chip gets through K concurrent copies, i.e. the
+                # configuration's cost in a saturated machine (its instructions per FLOP), not its latency on an empty one.  The
+                # copies write the same values into the same outputs.
+                if not hasattr(self, "_tune_side"):
+                    self._tune_side = []
+                    for _ in range(self._tune_streams - 1):
+                        sp = C.c_void_p()
+                        L.call("fcn_stream_create", C.byref(sp))
+                        self._tune_side.append(int(sp.value))
+                import time as _time
+                streams = [self.stream] + self._tune_side
+                for st in streams:
+                    L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), st))
+                L.call("fcn_device_sync")
+                t0 = _time.perf_counter()
+                for _ in range(8):
+                    for st in streams:
+                        L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), st))
+                L.call("fcn_device_sync")
+                t = (_time.perf_counter() - t0) * 1e3 * 6.0 / (8 * len(streams))
+            elif cold:
                 L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))      # (code object, kernel arguments)
                 samples = []
                 for _ in range(5):

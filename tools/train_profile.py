@@ -42,7 +42,7 @@ def main():
         for k, (c, ms, fl) in sorted(by_kind.items(), key=lambda kv: -kv[1][1]):
             print("   %-14s %3d launches %8.3f ms  %6.1f TF/s" % (k, c, ms, fl / ms / 1e9 if ms else 0))
         for kind, name, ms, fl, by in sorted(rows, key=lambda r: -r[2])[:25]:
-            print("      %-12s %-70s %8.1f us %6.1f TF/s" % (kind, name[:70], ms * 1e3, fl / ms / 1e9 if ms else 0))
+            print("      %-12s %-110s %8.1f us %6.1f TF/s" % (kind, name[:110], ms * 1e3, fl / ms / 1e9 if ms else 0))
         tot[label] = t
     print(tot)
 
