@@ -199,6 +199,7 @@ class Engine:
         self._plan_buffers()
         self._alloc_params(params)
         self._build_ops()
+        self._release_tuning_resources()
 
     # ------------------------------------------------------------------ buffers
     def _plan_buffers(self) -> None:
@@ -897,6 +898,21 @@ class Engine:
             for b, i in enumerate(fl):
                 if choice[b] == "1":
                     levels[i] = lv + 1
+
+    def _release_tuning_resources(self) -> None:
+        """Streams and scratch the autotuner made: an idle stream still holds a hardware queue (streams are dealt to the queues in creation
+        order), so they must be gone before the replicas of a pipeline create theirs."""
+        lib = L.load()
+        for st in getattr(self, "_tune_side", []):
+            lib.fcn_stream_sync(st)
+            lib.fcn_stream_destroy(st)
+        self._tune_side = []
+        if hasattr(self, "_tune_side"):
+            del self._tune_side
+        fl = getattr(self, "_tune_flush", None)
+        if fl is not None:
+            fl.free()
+            del self._tune_flush
 
     def _split_level(self, chunk: List[dict]) -> List[List[dict]]:
         """Half-float engines: which launches carry a level's convolutions?  The streaming kernel's configurations are shaped for one
