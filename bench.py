@@ -550,7 +550,11 @@ def main() -> None:
     pipe.run_resident(max(args.warmup, 1))                        # W untimed warm-up steps (also captures the hipGraphs)
     depth = pipe.calibrate((depth - 1, depth)) if depth > 1 else 1    # untimed: 3 or 4 replicas, whichever packs better here
     if args.trace_clean:
+        # (kernel-trace passes: one repeat, and no config-2 region - hipGraphLaunch between async copies on the same stream dies with SIGSEGV
+        #  inside the runtime under rocprofv3 --kernel-trace after a few hundred frames, with one frame in flight as with four, with the
+        #  copies inside the graph as outside it, never without the profiler: profiles/experiments/r04_graph_*segv*.txt)
         args.repeats = 1
+        args.no_io_region = True
     rep_k = []
     for _ in range(max(args.repeats, 1)):
         L.call("fcn_device_sync")
