@@ -967,8 +967,11 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
     // The poolings fused into this launch take the FIRST pool_wgs workgroups: they are short (a microsecond or two) and start
     // at once, beside the convolution tiles' set-up and first memory latency - queued behind the tiles, as in round 1, they
     // were the launch's tail (inception_4a's 1x1 group: 6.1 us alone, 7.3 us with the module's pool behind it).
-    if ((int)blockIdx.x < pool_wgs) {
-        const int w = blockIdx.x;
+    // (pool_wgs < 0, $FCN_POOL_LAST=1: the poolings take the LAST workgroups instead - an experiment repeated in round 4 with the faster
+    //  pooling body; pool_wgs is then minus their number and te7 the number of tiles in front of them)
+    const int pool_first = pool_wgs > 0 ? pool_wgs : 0;
+    if ((int)blockIdx.x < pool_first || (pool_wgs < 0 && (int)blockIdx.x >= te7)) {
+        const int w = pool_wgs < 0 ? (int)blockIdx.x - te7 : (int)blockIdx.x;
         if (w < a.pool[0].wg_end) pool_body<T, Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT>(a.pool[0], w);
         else pool_body<T, Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT>(a.pool[1], w - a.pool[0].wg_end);
         return;
@@ -985,7 +988,7 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
         const int r = pos >> sh, j = pos & ((1 << sh) - 1);
         if (r > 0 && r < rounds - 1 && ((rounds - 1 - r) & 1)) pos = (r << sh) + ((1 << sh) - 1 - j);
     }
-    int tile = pos - pool_wgs;
+    int tile = pos - pool_first;
     if (snake == (int)0x80000000) {
         // (experiment, FCN_CONV_XCD=1) workgroup p runs on XCD p % 8: give every XCD a CONTIGUOUS run of the tile list, so that the tiles
         // sharing A rows (consecutive indices: tile_m = index / tiles_n) meet in one L2 instead of eight
@@ -2190,14 +2193,15 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
                 ga.pool[i].wg_end = end;
             }
             grid += end;
-            pool_wgs = end;
+            static const bool pool_last = getenv("FCN_POOL_LAST") && atoi(getenv("FCN_POOL_LAST")) == 1;
+            pool_wgs = pool_last ? -end : end;
         }
         // snake dealing of the rounds (conv_fwd_group): mixed tile lengths, at least three rounds, a power-of-two CU count
         int snake = 0;
         {
             static const bool snake_ok = !(getenv("FCN_CONV_SNAKE") && atoi(getenv("FCN_CONV_SNAKE")) == 0);
             const int cus = device_cus();
-            if (snake_ok && ga.nprob > 1 && (cus & (cus - 1)) == 0 && grid > 2 * cus && pool_wgs < cus) {
+            if (snake_ok && ga.nprob > 1 && (cus & (cus - 1)) == 0 && grid > 2 * cus && pool_wgs >= 0 && pool_wgs < cus) {
                 int sh = 0;
                 while ((1 << sh) < cus) ++sh;
                 snake = ((grid + cus - 1) / cus) << 8 | sh;
