@@ -640,18 +640,35 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(const WgradGroupA
             asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value));
         };
         // CNT pairs; ALL: every pair is whole (no branch in the MFMA stream)
+        // Round 4: the fragments of TWO consecutive steps come with one instruction.  A lane's operand of step s and of step s + 1 are
+        // 1024 (dY) / 2048 (im2col) bytes apart - whole multiples of 256 - so ds_read2st64_b32 (two dwords at base + 256 * offset0 / offset1)
+        // fetches both: 48 fragment reads per chunk and pair list instead of 96.  The multiplying waves' stream was 1540 cycles per
+        // chunk where 1024 are MFMA: the reads' issue slots were a third of the rest.  The accumulation order per
+        // accumulator is unchanged (steps ascending), so the gradients are the same bits.
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        auto ds_read2 = [](v2f& dst, unsigned addr, auto o0, auto o1) __attribute__((always_inline)) {
+#ifdef FCN_WS_NOREAD
+            asm volatile("" : "=v"(dst) : "v"(addr));
+            return;
+#endif
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(decltype(o0)::value), "n"(decltype(o1)::value));
+        };
         auto run = [&](auto cnt_c, auto all_c) __attribute__((always_inline)) {
             constexpr int CNT = decltype(cnt_c)::value;
             constexpr bool ALL = decltype(all_c)::value;
-            float fa[2][CNT], fb[2][CNT][2];
+            constexpr int SS = WS_STEPS / 2;      // super-steps of two MFMA steps
+            v2f fa[2][CNT], fb[2][CNT][2];        // .x: the even step, .y: the odd one
+            unsigned b1_ad[CNT];                  // the pair's second sub-tile: 32 floats on
+#pragma unroll
+            for (int t = 0; t < CNT; ++t) b1_ad[t] = b_ad[t] + 128u;
             unsigned slot = 0;
             __builtin_amdgcn_s_barrier();      // B(-1)
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int t = 0; t < CNT; ++t) {
-                ds_read32(fa[0][t], a_ad[t], std::integral_constant<int, 0>{});
-                ds_read32(fb[0][t][0], b_ad[t], std::integral_constant<int, 0>{});
-                ds_read32(fb[0][t][1], b_ad[t], std::integral_constant<int, 128>{});
+                ds_read2(fa[0][t], a_ad[t], std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+                ds_read2(fb[0][t][0], b_ad[t], std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+                ds_read2(fb[0][t][1], b1_ad[t], std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
             }
 #pragma unroll 1
             for (int c = 0; c < nchunks; ++c) {
@@ -664,49 +681,50 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(const WgradGroupA
                 ws_wait += WS_CYC() - w0;
 #endif
                 const unsigned slot_next = slot + SLOT_BYTES == (unsigned)(WS_NBUF * SLOT_BYTES) ? 0u : slot + SLOT_BYTES;
-                unsigned aa[CNT], bb[CNT];
+                unsigned aa[CNT], bb[CNT], bb1[CNT];
 #pragma unroll
                 for (int t = 0; t < CNT; ++t) {
                     aa[t] = a_ad[t] + slot;
                     bb[t] = b_ad[t] + slot;
+                    bb1[t] = b1_ad[t] + slot;
                 }
-                auto step = [&](auto st_c) __attribute__((always_inline)) {
-                    constexpr int st = decltype(st_c)::value, par = st & 1;
-                    // the next step's fragments (behind the last step: the first ones of the next chunk)
+                auto sstep = [&](auto ss_c) __attribute__((always_inline)) {
+                    constexpr int ss = decltype(ss_c)::value, par = ss & 1;
+                    // the next super-step's fragments (behind the last one: the first ones of the next chunk)
 #pragma unroll
                     for (int t = 0; t < CNT; ++t) {
-                        if constexpr (st < WS_STEPS - 1) {
-                            ds_read32(fa[par ^ 1][t], aa[t], std::integral_constant<int, (st + 1) * 2 * 128 * 4>{});
-                            ds_read32(fb[par ^ 1][t][0], bb[t], std::integral_constant<int, (st + 1) * 2 * 256 * 4>{});
-                            ds_read32(fb[par ^ 1][t][1], bb[t], std::integral_constant<int, (st + 1) * 2 * 256 * 4 + 128>{});
+                        if constexpr (ss < SS - 1) {
+                            ds_read2(fa[par ^ 1][t], aa[t], std::integral_constant<int, 8 * (ss + 1)>{}, std::integral_constant<int, 8 * (ss + 1) + 4>{});
+                            ds_read2(fb[par ^ 1][t][0], bb[t], std::integral_constant<int, 16 * (ss + 1)>{}, std::integral_constant<int, 16 * (ss + 1) + 8>{});
+                            ds_read2(fb[par ^ 1][t][1], bb1[t], std::integral_constant<int, 16 * (ss + 1)>{}, std::integral_constant<int, 16 * (ss + 1) + 8>{});
                         } else {
-                            ds_read32(fa[0][t], a_ad[t] + slot_next, std::integral_constant<int, 0>{});
-                            ds_read32(fb[0][t][0], b_ad[t] + slot_next, std::integral_constant<int, 0>{});
-                            ds_read32(fb[0][t][1], b_ad[t] + slot_next, std::integral_constant<int, 128>{});
+                            ds_read2(fa[par ^ 1][t], a_ad[t] + slot_next, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
+                            ds_read2(fb[par ^ 1][t][0], b_ad[t] + slot_next, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+                            ds_read2(fb[par ^ 1][t][1], b1_ad[t] + slot_next, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
                         }
                     }
-                    // LDS operations return in order: this step's fragments are back once only the 3 CNT just issued are outstanding
+                    // LDS operations return in order: this super-step's fragments are back once only the 3 CNT just issued are outstanding
                     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * CNT) : "memory");
 #pragma unroll
                     for (int t = 0; t < CNT; ++t) asm volatile("" : "+v"(fa[par][t]), "+v"(fb[par][t][0]), "+v"(fb[par][t][1]));
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef FCN_WS_NOMFMA
 #pragma unroll
-                    for (int t = 0; t < CNT; ++t) {
-                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][t], fb[par][t][0], acc[t][0], 0, 0, 0);
-                        if (ALL || ((full >> t) & 1)) acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][t], fb[par][t][1], acc[t][1], 0, 0, 0);
-                    }
+                    for (int e = 0; e < 2; ++e)      // the even step of every pair, then the odd one: per accumulator the steps stay in order
+#pragma unroll
+                        for (int t = 0; t < CNT; ++t) {
+                            acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][t][e], fb[par][t][0][e], acc[t][0], 0, 0, 0);
+                            if (ALL || ((full >> t) & 1)) acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][t][e], fb[par][t][1][e], acc[t][1], 0, 0, 0);
+                        }
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 };
-                step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{}); step(std::integral_constant<int, 2>{});
-                step(std::integral_constant<int, 3>{}); step(std::integral_constant<int, 4>{}); step(std::integral_constant<int, 5>{});
-                step(std::integral_constant<int, 6>{}); step(std::integral_constant<int, 7>{});
-                if constexpr (WS_STEPS == 16) {
-                    step(std::integral_constant<int, 8 % WS_STEPS>{}); step(std::integral_constant<int, 9 % WS_STEPS>{});
-                    step(std::integral_constant<int, 10 % WS_STEPS>{}); step(std::integral_constant<int, 11 % WS_STEPS>{});
-                    step(std::integral_constant<int, 12 % WS_STEPS>{}); step(std::integral_constant<int, 13 % WS_STEPS>{});
-                    step(std::integral_constant<int, 14 % WS_STEPS>{}); step(std::integral_constant<int, 15 % WS_STEPS>{});
+                static_assert(SS % 2 == 0, "the fragment parity of a chunk's first super-step must be 0");
+                sstep(std::integral_constant<int, 0>{}); sstep(std::integral_constant<int, 1>{});
+                sstep(std::integral_constant<int, 2>{}); sstep(std::integral_constant<int, 3>{});
+                if constexpr (SS == 8) {
+                    sstep(std::integral_constant<int, 4 % SS>{}); sstep(std::integral_constant<int, 5 % SS>{});
+                    sstep(std::integral_constant<int, 6 % SS>{}); sstep(std::integral_constant<int, 7 % SS>{});
                 }
                 slot = slot_next;
             }

@@ -50,6 +50,15 @@ SHAPES = [
     ("4a_B_no5", [(96, 208, 3, 1, 1, 28, 28), (480, 64, 1, 0, 1, 28, 28)]),
     ("4e_B", [(160, 320, 3, 1, 1, 28, 28), (32, 128, 5, 2, 1, 28, 28)]),
     ("4e_5x5", [(32, 128, 5, 2, 1, 28, 28)]),
+    # round 4: what would ONE launch for a module's 3x3 level and the next module's reduce level cost, dependencies aside (an upper bound
+    # on what sharing a launch can save: no waiting is modelled)
+    ("4b_A", [(512, 160, 1, 0, 1, 28, 28), (512, 112, 1, 0, 1, 28, 28), (512, 24, 1, 0, 1, 28, 28)]),
+    ("4aB+4bA", [(96, 208, 3, 1, 1, 28, 28), (16, 48, 5, 2, 1, 28, 28), (480, 64, 1, 0, 1, 28, 28),
+                 (512, 160, 1, 0, 1, 28, 28), (512, 112, 1, 0, 1, 28, 28), (512, 24, 1, 0, 1, 28, 28)]),
+    ("5a_A", [(832, 256, 1, 0, 1, 28, 28), (832, 160, 1, 0, 1, 28, 28), (832, 32, 1, 0, 1, 28, 28)]),
+    ("4eB+5aA", [(160, 320, 3, 1, 1, 28, 28), (32, 128, 5, 2, 1, 28, 28), (528, 128, 1, 0, 1, 28, 28),
+                 (832, 256, 1, 0, 1, 28, 28), (832, 160, 1, 0, 1, 28, 28), (832, 32, 1, 0, 1, 28, 28)]),
+    ("4e_Bfull", [(160, 320, 3, 1, 1, 28, 28), (32, 128, 5, 2, 1, 28, 28), (528, 128, 1, 0, 1, 28, 28)]),
 ]
 
 
