@@ -458,6 +458,7 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
+            // (tried in round 4: s_setprio 3 for the multiplying waves, so that they win the SIMD's issue arbitration - no change on any launch)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             FCN_STAMP(2);      // first chunk usable

@@ -62,6 +62,45 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const S* __restrict__
     }
 }
 
+// The net's input: at most four channels into 4-float pixels (the image of models/deploy.prototxt is 3 + 1 pad).  The tile transpose
+// above spends a 32 x 32 tile on three channels and stores 12 bytes per pixel; here a lane owns a pixel - C coalesced plane reads, one
+// 16-byte store (the pad channels are written as zeros: they belong to this blob) - 9.6 -> ~3 us for a 448 x 448 frame, a layout
+// kernel of every frame of SURVEY 8(d) config 2's region.
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW, float shift) {
+    const int n = blockIdx.y;
+    const float* s = src + (size_t)n * C * HW;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x = s[p] + shift;
+        if (C > 1) v.y = s[(size_t)HW + p] + shift;
+        if (C > 2) v.z = s[2 * (size_t)HW + p] + shift;
+        if (C > 3) v.w = s[3 * (size_t)HW + p] + shift;
+        *reinterpret_cast<float4*>(dst + ((size_t)n * HW + p) * 4) = v;
+    }
+}
+
+// Several small blobs NHWC -> NCHW in ONE launch (the two head blobs behind every forward: two launches of a few microseconds each
+// were launch floor, not work).  One lane per output element.
+constexpr int kMaxLayoutBlobs = 8;
+struct LayoutBlob { const float* src; float* dst; int C, HW, cstride, coffset, count, end; };      // count = N*C*HW, end = exclusive prefix
+struct LayoutArgs { int n; LayoutBlob b[kMaxLayoutBlobs]; };
+__global__ __launch_bounds__(256) void nhwc_to_nchw_multi_kernel(const LayoutArgs a) {
+    const int total = a.b[a.n - 1].end;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < kMaxLayoutBlobs - 1; ++j) k += (j + 1 < a.n && i >= a.b[j].end) ? 1 : 0;
+        LayoutBlob q = a.b[0];
+#pragma unroll
+        for (int j = 1; j < kMaxLayoutBlobs; ++j)
+            if (k == j) q = a.b[j];
+        const int e = i - (q.end - q.count);            // element of this blob in NCHW order
+        const int p = e % q.HW, nc = e / q.HW;
+        const int c = nc % q.C, n = nc / q.C;
+        q.dst[e] = q.src[((size_t)n * q.HW + p) * q.cstride + q.coffset + c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // MAX pooling (Caffe semantics: window clipped to the image, strict '>' so the first maximum in
 // raster order wins, start value -FLT_MAX).  One lane = 4 channels of one output pixel.
@@ -755,9 +794,38 @@ int fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int 
     FCN_REQUIRE(dst_coffset >= 0 && dst_cstride >= dst_coffset + C, FCN_E_ARG, "nchw_to_nhwc: slice exceeds dst_cstride");
     FCN_REQUIRE(N <= 65535, FCN_E_UNSUPPORTED, "nchw_to_nhwc: batch too large");
     const int HW = H * W;
+    if (C <= 4 && dst_cstride == 4 && dst_coffset == 0 && ((uintptr_t)dst & 15) == 0) {      // the image: a lane per pixel
+        hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(cdiv(HW, 256) < 4096 ? cdiv(HW, 256) : 4096, N), dim3(256), 0, as_stream(s), src, dst, C, HW, shift);
+        FCN_LAUNCH_CHECK("nchw_to_nhwc4");
+        return 0;
+    }
     dim3 grid(cdiv(HW, 32), cdiv(C, 32), N);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, as_stream(s), src, dst, C, HW, dst_cstride, dst_coffset, shift);
     FCN_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+int fcn_nhwc_to_nchw_multi_f32(const fcn_layout_desc* h_descs, int n, fcn_stream_t s) {
+    FCN_REQUIRE(h_descs && n > 0 && n <= kMaxLayoutBlobs, FCN_E_ARG, "nhwc_to_nchw_multi: 1..%d blobs", kMaxLayoutBlobs);
+    LayoutArgs a;
+    a.n = n;
+    long long end = 0;
+    for (int i = 0; i < kMaxLayoutBlobs; ++i) {
+        const fcn_layout_desc& d = h_descs[i < n ? i : n - 1];
+        if (i < n) {
+            FCN_REQUIRE(d.src && d.dst && d.N > 0 && d.C > 0 && d.H > 0 && d.W > 0, FCN_E_ARG, "nhwc_to_nchw_multi: bad blob %d", i);
+            FCN_REQUIRE(d.src_coffset >= 0 && d.src_cstride >= d.src_coffset + d.C, FCN_E_ARG, "nhwc_to_nchw_multi: slice of blob %d exceeds its stride", i);
+            end += (long long)d.N * d.C * d.H * d.W;
+            FCN_REQUIRE(end < (1ll << 30), FCN_E_UNSUPPORTED, "nhwc_to_nchw_multi: meant for small blobs");
+        }
+        LayoutBlob& b = a.b[i];
+        b.src = d.src; b.dst = d.dst; b.C = d.C; b.HW = d.H * d.W; b.cstride = d.src_cstride; b.coffset = d.src_coffset;
+        b.count = i < n ? d.N * d.C * d.H * d.W : 0;
+        b.end = (int)end;
+    }
+    const int blocks = cdiv(end, 256) < 2048 ? cdiv(end, 256) : 2048;
+    hipLaunchKernelGGL(nhwc_to_nchw_multi_kernel, dim3(blocks), dim3(256), 0, as_stream(s), a);
+    FCN_LAUNCH_CHECK("nhwc_to_nchw_multi");
     return 0;
 }
 

@@ -45,6 +45,10 @@ class SolverSeg(C.Structure):
     _fields_ = [("offset", C.c_uint64), ("count", C.c_uint64), ("lr_mult", C.c_float), ("decay_mult", C.c_float)]
 
 
+class LayoutDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p)] + [(k, C.c_int32) for k in ("N", "C", "H", "W", "src_cstride", "src_coffset")]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("idx", C.c_void_p)] + [(k, C.c_int32) for k in (
         "N", "H", "W", "C", "x_cstride", "k", "stride", "pad", "OH", "OW", "y_cstride", "y_coffset", "f16")]
@@ -114,6 +118,7 @@ PROTOTYPES = {
     "fcn_graph_destroy": (_i, [_vp]),
     "fcn_nchw_to_nhwc_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "fcn_nhwc_to_nchw_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fcn_nhwc_to_nchw_multi_f32": (_i, [C.POINTER(LayoutDesc), _i, _vp]),
     "fcn_conv2d_fwd_f32": (_i, [C.POINTER(ConvDesc), _vp]),
     "fcn_conv2d_group_workspace_bytes": (_sz, [_i]),
     "fcn_conv2d_num_configs": (_i, []),

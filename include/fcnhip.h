@@ -84,6 +84,13 @@ int  fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int
                           int dst_cstride, int dst_coffset, float shift, fcn_stream_t s);
 int  fcn_nhwc_to_nchw_f32(const float* src, float* dst, int N, int C, int H, int W,
                           int src_cstride, int src_coffset, fcn_stream_t s);
+/* several (small) blobs in ONE launch - net.forward() hands back both head blobs of models/deploy.prototxt with it (up to 8 blobs) */
+typedef struct fcn_layout_desc {
+    const float* src;   /* NHWC, channel stride src_cstride, the blob's channels at src_coffset .. */
+    float* dst;         /* NCHW, dense */
+    int32_t N, C, H, W, src_cstride, src_coffset;
+} fcn_layout_desc;
+int  fcn_nhwc_to_nchw_multi_f32(const fcn_layout_desc* h_descs, int n, fcn_stream_t s);
 
 /* ---- Convolution (+bias, fused in-place ReLU / Sigmoid):
  *      Caffe ConvolutionLayer::Forward_gpu, ReLULayer, SigmoidLayer as run by

@@ -112,9 +112,11 @@ def test_first_launch_of_every_kernel_happens_outside_the_stream_capture(gpu, mo
     # the graph behind forward() also holds the layout kernels of the upload and of the download (round 4: the download's kernel
     # used to be launched for the first time INSIDE the capture - nothing else runs it before the first forward()); the copies
     # themselves are plain async calls in front of and behind the graph launch, never graph nodes
-    for nm in ("_upload_convert", "_download_convert", "_upload_copy", "_download_copy"):
+    for nm in ("_upload_convert", "_upload_copy", "_download_copy"):
         real = getattr(eng, nm)
         setattr(eng, nm, (lambda name, st, real=real, nm=nm: (events.append((nm, name)), real(name, st))[1]))
+    real_all = eng._download_convert_all      # (the layout kernels of all outputs: one launch for the two head blobs)
+    eng._download_convert_all = lambda st: (events.append("_download_convert_all"), real_all(st))[1]
     monkeypatch.setattr(L, "call", spy)
     x = np.random.default_rng(0).random((1, 3, 96, 128), dtype=np.float32)
     eng.host_array("data")[...] = x
@@ -123,9 +125,9 @@ def test_first_launch_of_every_kernel_happens_outside_the_stream_capture(gpu, mo
     n_ops = len(eng.ops)
     ops = [("op", i) for i in range(n_ops)]
     up = [("_upload_copy", "data"), ("_upload_convert", "data")]
-    down = [e for nm in eng.outputs for e in (("_download_convert", nm), ("_download_copy", nm))]
+    down = ["_download_convert_all"] + [("_download_copy", nm) for nm in eng.outputs]
     assert [e for e in events[:begin] if e != "fcn_graph_end"] == ops + up + down      # one eager pass of everything first
-    assert events[begin + 1:end] == [("_upload_convert", "data")] + ops + [("_download_convert", nm) for nm in eng.outputs]      # the capture: kernels only
+    assert events[begin + 1:end] == [("_upload_convert", "data")] + ops + ["_download_convert_all"]      # the capture: kernels only
     tail = [e for e in events[end + 1:] if e != "fcn_graph_launch"]
     assert tail == [("_upload_copy", "data")] + [("_download_copy", nm) for nm in eng.outputs]      # the frame itself: copy, graph, copies
     assert np.isfinite(out["coverage"]).all()
