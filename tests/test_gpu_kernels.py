@@ -414,6 +414,40 @@ def test_layout_roundtrip(gpu):
     assert np.array_equal(dev_to(zd, x.shape), x)
 
 
+@pytest.mark.parametrize("c", [1, 2, 3, 4])
+def test_image_upload_layout_kernel(gpu, c):
+    """The lane-per-pixel form of fcn_nchw_to_nhwc_f32 (at most four channels into 4-float pixels: the net's image): the
+    blob's channels shifted, the pad channels zero, odd sizes, a batch."""
+    rng = np.random.default_rng(40 + c)
+    x = rng.standard_normal((2, c, 17, 23)).astype(np.float32)
+    xd = dev_from(x)
+    yd = dev_from(np.full((2, 17, 23, 4), 7.0, np.float32))
+    L.call("fcn_nchw_to_nhwc_f32", xd.ptr, yd.ptr, 2, c, 17, 23, 4, 0, -127.0, None)
+    y = dev_to(yd, (2, 17, 23, 4))
+    assert np.array_equal(y[..., :c], x.transpose(0, 2, 3, 1) + np.float32(-127.0)) and np.all(y[..., c:] == 0)
+
+
+def test_several_blobs_nhwc_to_nchw_in_one_launch(gpu):
+    """fcn_nhwc_to_nchw_multi_f32: three blobs of different shapes, channel slices of wider buffers, one launch; and its refusals."""
+    import ctypes as C
+    rng = np.random.default_rng(44)
+    shapes = [(1, 4, 28, 28, 4, 0), (1, 16, 28, 28, 16, 0), (2, 5, 7, 9, 12, 3)]      # N, C, H, W, cstride, coffset
+    srcs, dsts, want = [], [], []
+    arr = (L.LayoutDesc * len(shapes))()
+    for d, (n, c, h, w, cs, co) in zip(arr, shapes):
+        buf = rng.standard_normal((n, h, w, cs)).astype(np.float32)
+        sd, dd = dev_from(buf), dev_from(np.zeros((n, c, h, w), np.float32))
+        srcs.append(sd); dsts.append(dd); want.append(buf[..., co:co + c].transpose(0, 3, 1, 2))
+        d.src, d.dst, d.N, d.C, d.H, d.W, d.src_cstride, d.src_coffset = sd.ptr, dd.ptr, n, c, h, w, cs, co
+    L.call("fcn_nhwc_to_nchw_multi_f32", arr, len(shapes), None)
+    for dd, wv in zip(dsts, want):
+        assert np.array_equal(dev_to(dd, wv.shape), wv)
+    lib = L.load()
+    assert lib.fcn_nhwc_to_nchw_multi_f32(arr, 0, None) != 0 and lib.fcn_nhwc_to_nchw_multi_f32(arr, 9, None) != 0
+    arr[1].src_cstride = 8                                   # a slice wider than its stride
+    assert lib.fcn_nhwc_to_nchw_multi_f32(arr, 3, None) != 0
+
+
 def test_unary_eltwise_copy(gpu):
     rng = np.random.default_rng(13)
     a = rng.standard_normal(1003).astype(np.float32)
