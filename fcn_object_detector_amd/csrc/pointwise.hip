@@ -284,6 +284,92 @@ __global__ __launch_bounds__(512) void maxpool_lrn5_kernel(const float* __restri
     st4(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + g * 4, m);
 }
 
+// pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce (+ ReLU) of models/deploy.prototxt:54-104 as ONE launch (inference, float32, 64 -> 64
+// channels, 3 x 3 window).  As a launch of its own the 1x1 convolution is two chunks of K behind the whole fixed cost of a convolution
+// launch (5.6 us in the kernel trace at batch 1, 18 TF/s); here the workgroup that has just normalised a 4 x 8 patch of pixels multiplies
+// them by the 64 x 64 filter bank before they leave the CU, so neither pooled nor normalised pixels ever reach HBM:
+//   1. lane (pixel p = tid / 8, q = tid % 8) takes the maximum of channels 8q .. 8q+7 over its window - all 18 loads in flight, taps
+//      outside the image re-read the nearest tap inside (the maximum does not change);
+//   2. LRN: the two channels either side of the lane's eight come from lanes q - 1 / q + 1 (same pixel, same wave) by a lane exchange;
+//      the arithmetic is lrn5_apply's, i.e. the stand-alone kernels' bit for bit;
+//   3. the 32 x 64 normalised tile goes to LDS (pitch 68 floats), and wave w computes output channels 16w .. 16w+15 of the 32 pixels with
+//      v_mfma_f32_16x16x4_f32 as out^T = W . act^T: A = 16 filters x 4 k-values (lane (i, h): filter 16w + i, k = 16h + s in step s -
+//      any bijection of k serves a sum, this one makes a lane's filter values ONE 64-byte run, loaded at the top of the kernel),
+//      B = 4 k-values x 16 pixels (four ds_read_b128 per pixel tile); D's register r of lane (j, h) is channel 16w + 4h + r of pixel j,
+//      so bias, ReLU and a 16-byte store follow straight from the accumulators.
+constexpr int kPLC_C = 64, kPLC_Pitch = 68;
+__global__ __launch_bounds__(256) void pool3_lrn5_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, int H, int W, int x_cstride, int stride, int pad, int OH, int OW,
+                                                                 int y_cstride, int y_coffset, int relu, float alpha_over_n, float beta, float kk) {
+    __shared__ __attribute__((aligned(16))) float act[32 * kPLC_Pitch];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = (int)blockIdx.z;
+    // filter fragments first: their latency hides behind the pooling loads
+    const int fi = lane & 15, fh = lane >> 4;
+    const float* wp = w + (size_t)(16 * wave + fi) * kPLC_C + 16 * fh;
+    float4 wf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = ld4(wp + 4 * j);
+    const float4 bv = bias ? ld4(bias + 16 * wave + 4 * fh) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // 1. pooling
+    const int p = tid >> 3, q = tid & 7;
+    const int oy = min((int)blockIdx.y * 4 + (p >> 3), OH - 1), ox = min((int)blockIdx.x * 8 + (p & 7), OW - 1);
+    const int hs = oy * stride - pad, ws = ox * stride - pad;
+    const int h0 = max(hs, 0), h1 = min(hs + 3, H) - 1, w0 = max(ws, 0), w1 = min(ws + 3, W) - 1;
+    const float* xb = x + (size_t)n * H * W * x_cstride + 8 * q;
+    float4 t0[9], t1[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int iy = min(max(hs + r, h0), h1), ix = min(max(ws + c, w0), w1);
+            const float* xp = xb + ((size_t)iy * W + ix) * x_cstride;
+            t0[3 * r + c] = ld4(xp);
+            t1[3 * r + c] = ld4(xp + 4);
+        }
+    float4 m0 = t0[0], m1 = t1[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+        m0 = max4(m0, t0[i]);
+        m1 = max4(m1, t1[i]);
+    }
+    // 2. LRN over the 64 channels of the pixel: neighbours' groups from lanes tid - 1 / tid + 1 (zeros outside the blob)
+    float4 lft, rgt;
+    lft.x = __shfl_up(m1.x, 1); lft.y = __shfl_up(m1.y, 1); lft.z = __shfl_up(m1.z, 1); lft.w = __shfl_up(m1.w, 1);
+    rgt.x = __shfl_down(m0.x, 1); rgt.y = __shfl_down(m0.y, 1); rgt.z = __shfl_down(m0.z, 1); rgt.w = __shfl_down(m0.w, 1);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q == 0) lft = zero;
+    if (q == 7) rgt = zero;
+    float4 s;
+    const float4 a0 = lrn5_apply(lft, m0, m1, alpha_over_n, beta, kk, s);
+    const float4 a1 = lrn5_apply(m0, m1, rgt, alpha_over_n, beta, kk, s);
+    st4(act + p * kPLC_Pitch + 8 * q, a0);
+    st4(act + p * kPLC_Pitch + 8 * q + 4, a1);
+    __syncthreads();
+    // 3. out^T = W . act^T on the matrix cores
+    typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float* ap = act + (16 * t + fi) * kPLC_Pitch + 16 * fh;
+        float4 af[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[j] = ld4(ap + 4 * j);
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].x, af[j].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].y, af[j].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].z, af[j].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j].w, af[j].w, acc, 0, 0, 0);
+        }
+        float4 o = make_float4(acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w);
+        if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        const int pp = 16 * t + fi;
+        const int py = (int)blockIdx.y * 4 + (pp >> 3), px = (int)blockIdx.x * 8 + (pp & 7);
+        if (py < OH && px < OW) st4(y + ((size_t)(n * OH + py) * OW + px) * y_cstride + y_coffset + 16 * wave + 4 * fh, o);
+    }
+}
+
 // generic window (any odd/even local_size, any C)
 __global__ __launch_bounds__(256) void lrn_generic_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ scale,
                                                           long long pixels, int C, int x_cstride, int y_cstride, int local_size,
@@ -940,6 +1026,26 @@ int fcn_maxpool_lrn5_fwd_f32(const float* x, float* y, int N, int H, int W, int 
         hipLaunchKernelGGL(maxpool_lrn5_kernel<false>, grid, dim3(512), 0, as_stream(s), x, y, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
                            cgroups, aon, beta, lrn_k);
     FCN_LAUNCH_CHECK("maxpool_lrn5");
+    return 0;
+}
+
+int fcn_maxpool_lrn5_conv1x1_fwd_f32(const float* x, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad, int OH, int OW,
+                                     float alpha, float beta, float lrn_k, const float* w, const float* bias, int Cout, int relu, float* y,
+                                     int y_cstride, int y_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && w && N > 0 && H > 0 && W > 0 && stride > 0 && pad >= 0 && OH > 0 && OW > 0 && y_coffset >= 0, FCN_E_ARG,
+                "maxpool_lrn5_conv1x1: bad args");
+    FCN_REQUIRE(pad < k && (OH - 1) * stride - pad < H && (OW - 1) * stride - pad < W, FCN_E_ARG,
+                "maxpool_lrn5_conv1x1: OH/OW too large or pad >= kernel");
+    FCN_REQUIRE(x_cstride >= C && y_cstride >= y_coffset + Cout, FCN_E_ARG, "maxpool_lrn5_conv1x1: channel stride smaller than the channels");
+    FCN_REQUIRE(C == kPLC_C && Cout == 64 && k == 3, FCN_E_UNSUPPORTED,
+                "maxpool_lrn5_conv1x1: 3 x 3 windows, 64 -> 64 channels only (run the three layers separately)");
+    FCN_REQUIRE(x_cstride % 4 == 0 && y_cstride % 4 == 0 && y_coffset % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(w) &&
+                (!bias || aligned16(bias)), FCN_E_UNSUPPORTED, "maxpool_lrn5_conv1x1: needs 16-byte channel groups");
+    FCN_REQUIRE(cdiv(OH, 4) <= 65535 && N <= 65535, FCN_E_UNSUPPORTED, "maxpool_lrn5_conv1x1: grid too large");
+    const dim3 grid(cdiv(OW, 8), cdiv(OH, 4), N);
+    hipLaunchKernelGGL(pool3_lrn5_conv1x1_kernel, grid, dim3(256), 0, as_stream(s), x, w, bias, y, H, W, x_cstride, stride, pad, OH, OW, y_cstride,
+                       y_coffset, relu, alpha / 5.f, beta, lrn_k);
+    FCN_LAUNCH_CHECK("maxpool_lrn5_conv1x1");
     return 0;
 }
 

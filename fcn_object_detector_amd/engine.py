@@ -616,9 +616,44 @@ class Engine:
                 i += 1
                 continue
             self._lazy_blob_ops[a["layer"].tops[0]] = list(a["ops"])
+            c = tasks[i + 2] if i + 2 < len(tasks) else None
+            op3 = self._pool_lrn_conv_op(a["layer"], b["layer"], c) if c is not None and c["kind"] == "conv" else None
+            if op3 is not None:      # ... -> 1x1 convolution in the same launch: the normalised blob is not written either
+                self._lazy_blob_ops[b["layer"].tops[0]] = [op]
+                out.append(dict(kind="op", layer=c["layer"], ops=[op3], reads=a["reads"], writes=c["writes"], pool_desc=None))
+                i += 3
+                continue
             out.append(dict(kind="op", layer=b["layer"], ops=[op], reads=a["reads"], writes=b["writes"], pool_desc=None))
             i += 2
         return out
+
+    def _pool_lrn_conv_op(self, la: Layer, lb: Layer, ct: dict) -> Optional[Op]:
+        """MAX pooling -> LRN -> 1x1 convolution (+ in-place ReLU) as one launch (fcn_maxpool_lrn5_conv1x1_fwd_f32: deploy.prototxt's
+        pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce): as a launch of its own that convolution is two chunks of K behind a whole
+        launch's fixed cost.  The FLOPs of the convolution are booked on this op (kind "pool_lrn_conv")."""
+        if os.environ.get("FCN_FUSE_POOL_LRN_CONV", "1") == "0" or la.type != "Pooling" or self.f16:
+            return None
+        B, lib = self.blobs, L.load()
+        lc, d = ct["layer"], ct["desc"]
+        mid = lb.tops[0]
+        if lc.bottoms != [mid] or [q.name for q in self.consumers.get(mid, [])] != [lc.name] or len(self.producers.get(mid, [])) != 1 \
+                or mid in self.outputs or mid in self.alias:
+            return None
+        xb, nb = B[la.bottoms[0]], B[mid]
+        k, s, pad = kernel_stride_pad(la.sub("pooling_param"))
+        lp = lb.sub("lrn_param")
+        if (d.kh, d.kw, d.stride, d.pad) != (1, 1, 1, 0) or d.Cin != 64 or d.Cout != 64 or xb.channels != 64 or k != 3 or xb.esize != 4 \
+                or (d.flags & ~L.CONV_RELU) or d.in_shift != 0.0 or nb.coffset or d.y_cstride % 4 or d.y_coffset % 4:
+            return None
+        n, c, h, w = xb.shape
+        oh, ow = d.OH, d.OW
+        if (oh + 3) // 4 > 65535 or n > 65535:
+            return None
+        al, be, kk = float(lp.get("alpha", 1.0)), float(lp.get("beta", 0.75)), float(lp.get("k", 1.0))
+        relu = 1 if d.flags & L.CONV_RELU else 0
+        return Op("pool_lrn_conv", "%s+%s+%s" % (la.name, lb.name, lc.name), lambda st: L.check(lib.fcn_maxpool_lrn5_conv1x1_fwd_f32(
+            xb.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, al, be, kk, d.w, d.bias, d.Cout, relu, d.y, d.y_cstride, d.y_coffset, st)),
+            ct["flops"], 4.0 * (xb.pixels * c + n * oh * ow * d.Cout))
 
     def _pool_lrn_op(self, la: Layer, lb: Layer) -> Optional[Op]:
         B, lib = self.blobs, L.load()

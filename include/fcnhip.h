@@ -187,6 +187,14 @@ int  fcn_lrn_fwd_f32(const float* x, float* y, float* scale, int pixels, int C, 
  * (FCN_E_UNSUPPORTED otherwise: run fcn_maxpool_fwd_f32 and fcn_lrn_fwd_f32). */
 int  fcn_maxpool_lrn5_fwd_f32(const float* x, float* y, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
                               int OH, int OW, int y_cstride, int lrn_first, float alpha, float beta, float lrn_k, fcn_stream_t s);
+/* pool -> LRN -> 1x1 convolution (+ bias, optional ReLU) in ONE launch: deploy.prototxt pool1/3x3_s2 -> pool1/norm1 ->
+ * conv2/3x3_reduce (:54-104).  y[pixel][y_coffset + co] = act(bias[co] + sum_c w[co][c] * LRN(maxpool(x))[pixel][c]); w is
+ * [Cout][C] row-major.  Neither the pooled nor the normalised blob is written.  3 x 3 windows and 64 -> 64 channels only
+ * (FCN_E_UNSUPPORTED otherwise: fcn_maxpool_lrn5_fwd_f32 + fcn_conv2d_fwd_f32).  Pooling and LRN are bit-identical to
+ * fcn_maxpool_lrn5_fwd_f32(lrn_first = 0); the convolution sums K on the matrix cores in its own order (float32). */
+int  fcn_maxpool_lrn5_conv1x1_fwd_f32(const float* x, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
+                                      int OH, int OW, float alpha, float beta, float lrn_k, const float* w, const float* bias,
+                                      int Cout, int relu, float* y, int y_cstride, int y_coffset, fcn_stream_t s);
 int  fcn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, fcn_stream_t s);
 int  fcn_sigmoid_fwd_f32(const float* x, float* y, size_t count, fcn_stream_t s);
 int  fcn_power_fwd_f32(const float* x, float* y, size_t count, float power, float scale, float shift, fcn_stream_t s);

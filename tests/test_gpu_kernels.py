@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import CFG_DOT1X1, CFG_FIRST7, N_TILE_CFGS, rel_err
+from conftest import CFG_DOT1X1, CFG_FIRST7, N_TILE_CFGS, elem_err, rel_err
 from fcn_object_detector_amd import lib as L
 from fcn_object_detector_amd.engine import DeviceBuffer
 from gpu_util import conv_desc, dev_from, dev_to, nchw, nhwc, pack_ohwi
@@ -396,6 +396,45 @@ def test_maxpool_lrn_single_pass_matches_oracle(gpu, lrn_first, k, s, p, h, w, c
         assert np.allclose(y, two, rtol=1e-6, atol=0)
     else:
         assert np.array_equal(y, two)
+
+
+@pytest.mark.parametrize("s,p,h,w,relu,bias,ycs,yco", [(2, 0, 224, 224, 1, True, 64, 0), (2, 0, 15, 21, 1, True, 64, 0), (1, 1, 9, 7, 0, True, 80, 16),
+                                                       (2, 1, 10, 11, 1, False, 64, 0), (2, 0, 17, 37, 0, True, 128, 64)])
+def test_pool_lrn_conv1x1_single_pass_matches_oracle(gpu, s, p, h, w, relu, bias, ycs, yco):
+    """fcn_maxpool_lrn5_conv1x1_fwd_f32 (pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce + ReLU of deploy.prototxt:54-104 as one launch)
+    against the oracle's three layers, and against the library's own pool + LRN launch followed by its convolution kernel; channels of the
+    output pixel outside the convolution's slice stay untouched."""
+    rng = np.random.default_rng(29)
+    n, c, co, k = 2, 64, 64, 3
+    x = np.maximum(rng.standard_normal((n, c, h, w)) * 30, 0).astype(np.float32)      # (a blob behind a ReLU, like conv1's)
+    wt = (rng.standard_normal((co, c, 1, 1)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(co).astype(np.float32) if bias else None
+    oh, ow = R.pool_out(h, k, p, s), R.pool_out(w, k, p, s)
+    xd = dev_from(nhwc(x, c))
+    wd = dev_from(np.ascontiguousarray(wt.reshape(co, c)))
+    bd = dev_from(b) if bias else None
+    y0 = np.full((n, oh, ow, ycs), 7.0, np.float32)
+    yd = dev_from(y0)
+    L.call("fcn_maxpool_lrn5_conv1x1_fwd_f32", xd.ptr, n, h, w, c, c, k, s, p, oh, ow, 1e-4, 0.75, 1.0, wd.ptr, bd.ptr if bias else None, co, relu,
+           yd.ptr, ycs, yco, None)
+    full = dev_to(yd, (n, oh, ow, ycs))
+    y = np.ascontiguousarray(full[..., yco:yco + co].transpose(0, 3, 1, 2))
+    mid = R.lrn_across(R.max_pool(x, k, s, p), 5, 1e-4, 0.75, 1.0)
+    ref = R.conv2d(mid, wt, b, 0, 1)
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert rel_err(y, ref) < 1e-5
+    assert elem_err(y, ref, tol=1e-4)[0] <= 1.0
+    keep = np.ones(ycs, bool)
+    keep[yco:yco + co] = False
+    assert np.all(full[..., keep] == 7.0)
+    # the library's own two launches: pool + LRN (bit-identical inside the single pass), then the tiled convolution
+    md = dev_from(np.zeros((n, oh, ow, c), np.float32))
+    L.call("fcn_maxpool_lrn5_fwd_f32", xd.ptr, md.ptr, n, h, w, c, c, k, s, p, oh, ow, c, 0, 1e-4, 0.75, 1.0, None)
+    two, _ = run_conv(nchw(dev_to(md, (n, oh, ow, c)), c), wt, b, 0, 1, flags=L.CONV_RELU if relu else 0)
+    assert rel_err(y, two) < 1e-5
+    with pytest.raises(L.FcnError):      # other channel counts: the caller runs the layers separately
+        L.call("fcn_maxpool_lrn5_conv1x1_fwd_f32", xd.ptr, n, h, w, 32, c, k, s, p, oh, ow, 1e-4, 0.75, 1.0, wd.ptr, None, co, relu, yd.ptr, ycs, yco, None)
 
 
 def test_layout_roundtrip(gpu):

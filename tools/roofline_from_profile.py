@@ -8,6 +8,8 @@ usage: roofline_from_profile.py <tag> [train batch]   (reads profiles/<tag>_benc
   conv_us_per_frame = sum of TotalDurationNs of the forward convolution kernels (conv_fwd_group*, conv_fwd_one*, conv_first7*,
                       conv_dot1x1*) / frames, frames = calls of the first-layer kernel (it runs once per forward)
   achieved          = 15.608 GFLOP / conv_us_per_frame          frac = achieved / 157.3 TFLOP/s
+                      (when the trace holds pool3_lrn5_conv1x1_kernel - conv2/3x3_reduce folded into the pool1 + norm1 pass - that
+                      kernel's time is NOT in the family and the 0.103 GFLOP of conv2/3x3_reduce are NOT in the numerator: 15.505 GFLOP)
   mfma_busy_frac    = sum of SQ_VALU_MFMA_BUSY_CYCLES / 1024 (cycles the average matrix pipe of the chip was busy, per frame)
                       / (conv_us_per_frame x clock); the clock is an ASSUMPTION written into the file (2.18 GHz: what the stamped
                       build measured inside these kernels in round 2; 2.4 GHz is what the 157.3 TF peak assumes)
@@ -21,14 +23,19 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FWD_GFLOP, PEAK_TF, CLOCK_GHZ = 15.608, 157.3, 2.18
 CONV = ("conv_fwd_group", "conv_fwd_one", "conv_first7", "conv_dot1x1")
+FOLDED = "pool3_lrn5_conv1x1_kernel"                 # pool1 -> norm1 -> conv2/3x3_reduce in one HBM-bound launch (csrc/pointwise.hip)
+FOLDED_GFLOP = 2.0 * 112 * 112 * 64 * 64 / 1e9       # conv2/3x3_reduce at 448 x 448, batch 1 (deploy.prototxt:77-104)
 
 
 def main():
     tag = sys.argv[1]
     stats = os.path.join(ROOT, "profiles", tag + "_bench_kernel_stats.csv")
-    conv_ns, frames, rows = 0, 0, []
+    conv_ns, frames, rows, folded = 0, 0, [], None
     for r in csv.DictReader(open(stats)):
         name = r["Name"]
+        if FOLDED in name:
+            folded = {"kernel": FOLDED, "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "gflop_not_counted": round(FOLDED_GFLOP, 4),
+                      "note": "conv2/3x3_reduce runs inside the pool1 + norm1 pass: neither this kernel's time nor that convolution's FLOPs are in the family"}
         if any(c in name for c in CONV) and "wgrad" not in name:
             conv_ns += int(r["TotalDurationNs"])
             rows.append({"kernel": name.replace("(anonymous namespace)::", "")[:90], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2)})
@@ -37,9 +44,12 @@ def main():
     if not frames:
         raise SystemExit("no first-layer kernel in %s: cannot count the frames" % stats)
     us = conv_ns / 1e3 / frames
-    out = {"source": "profiles/%s_bench_kernel_stats.csv" % tag, "frames": frames, "conv_us_per_frame": round(us, 2),
-           "achieved_tflops": round(FWD_GFLOP / us * 1e3, 3), "peak_tflops": PEAK_TF, "frac": round(FWD_GFLOP / us * 1e3 / PEAK_TF, 4),
+    gflop = FWD_GFLOP - (FOLDED_GFLOP if folded else 0.0)
+    out = {"source": "profiles/%s_bench_kernel_stats.csv" % tag, "frames": frames, "conv_us_per_frame": round(us, 2), "family_gflop_per_frame": round(gflop, 4),
+           "achieved_tflops": round(gflop / us * 1e3, 3), "peak_tflops": PEAK_TF, "frac": round(gflop / us * 1e3 / PEAK_TF, 4),
            "kernels": rows, "clock_ghz_assumed": CLOCK_GHZ}
+    if folded:
+        out["folded"] = folded
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_pmc_mfma.json")))
         busy, pframes = 0.0, 0
