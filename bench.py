@@ -621,7 +621,7 @@ def main() -> None:
         all_ms = sum(o[2] for o in ops)
         if args.per_op:
             for (k, n, ms, fl, by), w in zip(ops, ops_seq):
-                sys.stderr.write("%-10s %-60s %8.2f us (in sequence, with event cost %7.2f) %7.2f TF/s %7.1f GB/s\n" % (k, n[:60], ms * 1e3, w[2] * 1e3, fl / ms / 1e9 if ms else 0,
+                sys.stderr.write("%-10s %-60s %8.2f us (in sequence, with event cost %7.2f) %7.2f TF/s %7.1f GB/s\n" % (k, n[:160], ms * 1e3, w[2] * 1e3, fl / ms / 1e9 if ms else 0,
                                                                                                                       by / ms / 1e6 if ms else 0))
         live = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms else 0.0
         tr = profile_traffic(PROFILE_TAG + "_bench")      # HBM bytes per conv launch from the committed PMC passes (stamped with the sources' hash)

@@ -52,6 +52,37 @@ struct GroupArgs {
     ConvP p[kMaxGroup];
 };
 
+// A "tail": narrow 1x1 problems (the detection heads cvg/classifier + bbox/regressor of models/deploy.prototxt: 4 + 16 outputs over the
+// 1024 channels of inception_5b/output) evaluated by the launches that PRODUCE their input (conv_fwd.hip, conv_fwd_group<.., TAIL = true>):
+// a tile that has just written 32 channels of a pixel block multiplies them by the heads' filters and leaves 4 * groups partial sums per
+// pixel in scratch[slot = channel / 32][pixel][row]; the tile that arrives LAST at a pixel block (arrival word, no spinning) adds the
+// K / 32 slots in slot order - a fixed order: bit-reproducible - applies bias / ReLU / sigmoid and writes the heads' outputs.  A
+// launch with need == 0 only contributes partial sums (the branch of the module that rides in the earlier launch).
+constexpr int kTailRows = 24;           // output channels of all narrow problems together, at most (whole fours)
+constexpr int kTailMaxSlices = 4;
+constexpr int FCN_CONV_TAILF = 1 << 20; // ConvP.flags (internal): this problem's output tiles contribute to the group's tail
+struct TailSlice {
+    const float* bias;
+    float* y;
+    float* y2;
+    int o0, nout, y_cstride, y_coffset, y2_cstride, y2_coffset, flags, pad_;
+};
+struct TailHdr {                        // 96 bytes: conv_fwd_group fetches it with two wide scalar loads beside the problem's (ONE trip to the kernel arguments)
+    float* scratch;                     // [K / 32][M][rows] partial sums
+    unsigned* arrive;                   // one word per pixel block of the launch's tile height, zero between launches
+    const float* gw[kTailRows / 4];     // filter rows 4j .. 4j+3: row r of group j at gw[j] + r * K
+    int K, rows, need, M, nslices, dbg, pad1_, pad2_;
+};
+static_assert(sizeof(TailHdr) == 96, "conv_fwd_group loads a TailHdr as 16 + 8 dwords");
+struct TailP {
+    TailHdr h;
+    TailSlice s[kTailMaxSlices];
+};
+struct GroupArgsTail {                  // what conv_fwd_group<.., TAIL = true> takes: the group, then its tail
+    GroupArgs g;
+    TailP tail;
+};
+
 // m / d through the host's multiplier ceil(2^32 / d) (exact while m * d < 2^32, which validate() / plan_tiles_cfg guarantee);
 // magic 0 stands for d == 1.  No division fallback on purpose: an integer division is ~30 instructions, and the launch
 // prologue is straight-line code that every workgroup runs once from a cold instruction cache.

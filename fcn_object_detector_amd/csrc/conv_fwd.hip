@@ -217,9 +217,13 @@ __device__ int g_conv_stamps_cap = 0;
 // weights, f32 accumulation, BASELINE configs[4]): v_mfma_f32_32x32x16_f16, 8 elements per segment - the staging, the LDS
 // image, the swizzle and the pipeline are byte-for-byte the same (BK counts 4-byte words), a chunk just covers twice the
 // k range and one MFMA consumes what four f32 MFMAs do.
-template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF_, bool PF>
-__device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem) {
+typedef const TailP __attribute__((address_space(4))) * tail_kptr;      // a group's tail in the kernel-argument segment
+
+template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF_, bool PF, bool TAIL = false>
+__device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem, tail_kptr tp = nullptr) {
     using C = Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF_, PF>;
+    static_assert(!TAIL || (C::ROLES && C::BN == 32 && sizeof(T) == 4 && C::NW * 64 >= kTailRows * 8),
+                  "tails ride in the float32 split-role shapes with 32-channel tiles (the multiplying waves stage the narrow filters)");
     constexpr int NBUF = C::NBUF;
     constexpr bool ROLES = C::ROLES;
     constexpr int BM = C::BM, SEGS = C::SEGS, RPI = C::RPI, STEP = C::STEP, IA = C::IA, IB = C::IB, INST = C::INST;
@@ -391,6 +395,21 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             bias_v[e] = p.bias ? *(const float __attribute__((address_space(1)))*)(p.bias + (nb + e < p.Cout ? nb + e : p.Cout - 1)) : 0.f;
+    }
+
+    if constexpr (TAIL) {
+        // the narrow problems' filters over this tile's 32 channels -> LDS rows behind the ring ([row][32 floats]): the multiplying waves
+        // have nothing to do until the first chunk lands, so the load's latency costs nothing, and the epilogue reads them at LDS speed
+        if ((p.flags & FCN_CONV_TAILF) && is_mult && tid < tp->h.rows * 8 && !(tp->h.dbg & 1)) {
+            const int o = tid >> 3, seg = tid & 7;
+            const float* g = tp->h.gw[0];
+#pragma unroll
+            for (int j = 1; j < kTailRows / 4; ++j)
+                if ((o >> 2) == j) g = tp->h.gw[j];
+            const v4f w4 = *(const v4f*)(g + (size_t)(o & 3) * tp->h.K + p.y_coffset + n0 + 4 * seg);
+            *(v4f*)(smem + C::LDS_FLOATS + o * 32 + 4 * seg) = w4;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // (nothing of this is left in flight when the multiplying waves' counted waits begin)
+        }
     }
 
     FCN_STAMP(7);      // addresses set up
@@ -866,6 +885,137 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
     static_assert(C::NT % C4 == 0, "every thread keeps one float4 column");
     const int c4 = tid % C4;                        // the same for all items of this thread
     const int n = n0 + 4 * c4;
+    if constexpr (TAIL) {
+        if (p.flags & FCN_CONV_TAILF) {
+            // A tail problem (host-checked: float32, bias + ReLU only, Cout and the output slice in whole 32-channel tiles, 16-byte aligned
+            // output).  C4 == 8: thread (it = tid / 8, c4) holds channels n .. n+3 of pixel m0 + it.
+            const int rows = tp->h.rows, tm = tp->h.M;
+            const int it = tid >> 3, m = m0 + it;
+            if (it < BM) {      // (wave-uniform: whole waves)
+                const bool act = m < p.M;
+                const int wm_t = it / (32 * WTM), i_t = (it / 32) % WTM;
+                const int wn_t = (4 * c4) / (32 * WTN), jt = ((4 * c4) / 32) % WTN, lc = (4 * c4) & 31;
+                const float* src = smem + (size_t)(wn_t * WAVES_K * WTM * WTN + jt) * 1024 + lc +
+                                   (size_t)(wm_t * WAVES_N * WAVES_K * WTM * WTN + i_t * WTN) * 1024 + (it & 31) * 32;
+                v4f v = *(const v4f*)src;
+#pragma unroll
+                for (int s = 1; s < WAVES_K; ++s) v += *(const v4f*)(src + (size_t)s * WTM * WTN * 1024);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bias_v[e];
+                if (p.flags & FCN_CONV_RELU)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                if (act) *(v4f*)(p.y + (size_t)m * p.y_cstride + p.y_coffset + n) = v;
+                // partial sums of the narrow problems over these 4 channels, then over the 8 lanes that hold the pixel's 32 channels
+                // (a butterfly: every lane runs the same tree, the sum does not depend on the lane that stores it)
+                float* part = tp->h.scratch + ((size_t)((p.y_coffset + n) >> 5) * tm + (act ? m : 0)) * rows;
+                const float* tw = smem + C::LDS_FLOATS + 4 * c4;
+                // A ROLLED loop over the groups of four rows: straight-line code that runs once is paid in instruction fetch (~1.2 ns per
+                // instruction from a cold instruction cache, the finding behind this epilogue's own shape) - unrolled six times this block
+                // cost the launch 2 us.  The exchanges are DPP moves on the vector ALU - lane ^ 1, lane ^ 2, then the mirror image inside
+                // the 8 lanes (every lane of a quad already holds the quad's sum); __shfl_xor would be an LDS round trip each.
+                auto dpp_add = [](float x, auto ctrl) {
+                    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, false));
+                };
+#pragma unroll 1
+                for (int j = 0; 4 * j < ((tp->h.dbg & 2) ? 0 : rows); ++j) {
+                    v4f t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const v4f w4 = *(const v4f*)(tw + (4 * j + r) * 32);
+                        t[r] = (v[0] * w4[0] + v[1] * w4[1]) + (v[2] * w4[2] + v[3] * w4[3]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = t[r];
+                        x = dpp_add(x, std::integral_constant<int, 0xB1>{});       // quad_perm [1, 0, 3, 2]
+                        x = dpp_add(x, std::integral_constant<int, 0x4E>{});       // quad_perm [2, 3, 0, 1]
+                        x = dpp_add(x, std::integral_constant<int, 0x141>{});      // row_half_mirror: lane i <-> 7 - i of every 8
+                        t[r] = x;
+                    }
+                    // (device-coherent store, sc1: written through the XCD's L2 - the tile that adds the slots up runs on any XCD, and a
+                    //  release fence instead would be an L2 write-back per workgroup: 500 of them made this launch 55 us instead of 18)
+                    if (act && c4 == j && !(tp->h.dbg & 4)) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(part + 4 * j), "v"(t) : "memory");
+                }
+            }
+            const int need = tp->h.need;
+            if (need == 0) return;      // (uniform) an earlier launch of the same blob: partial sums only
+            // arrival: the workgroup that completes a pixel block finishes the narrow problems for it.  Nobody waits for anybody.
+            int* s_last = reinterpret_cast<int*>(smem + C::LDS_FLOATS + kTailRows * 32);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                // every partial sum of this workgroup has been acknowledged by memory (write-through stores, vmcnt(0) in front of the barrier)
+                // before the arrival (a device-scope atomic at the memory side); the sums are read back with device-coherent loads: no fence
+                const unsigned old = atomicAdd(tp->h.arrive + tile_m, 1u);
+                *s_last = old + 1u == (unsigned)need ? 1 : 0;
+            }
+            __syncthreads();
+            if (!*s_last) return;
+            // The last tile of the block: sum[pixel][row] = (slots 0 .. H-1, in order) + (slots H .. 2H-1, in order), H = half the slots - one
+            // thread per (pixel, four rows, half), all of a thread's loads in flight at once (a device-coherent load is a trip to memory:
+            // a loop over the slots in batches was four or five trips long), the two halves meet in LDS.  A fixed order: the same sum in every run.
+            const int groups = rows >> 2, nslots = tp->h.K >> 5, items = BM * groups;
+            constexpr int H = 16;
+            const size_t slot_stride = (size_t)tm * rows;
+            float* halves = smem;      // (the parked accumulators have been read: 2 x items x 4 floats fit in their place)
+            static_assert(2 * BM * (kTailRows / 4) * 4 <= C::EPI_FLOATS, "the half sums borrow the accumulator image");
+            for (int w = tid; w < 2 * items; w += C::NT) {
+                const int hf = w >= items ? 1 : 0, wi = w - hf * items;
+                const int px = wi / groups, g = wi - px * groups, mm = m0 + px;
+                const float* src = tp->h.scratch + (size_t)(mm < p.M ? mm : 0) * rows + 4 * g + (size_t)(hf * H) * slot_stride;
+                v4f q[H];
+#pragma unroll
+                for (int u = 0; u < H; ++u) {
+                    q[u] = v4f{0.f, 0.f, 0.f, 0.f};
+                    if (hf * H + u < nslots)      // device-coherent load: never a stale line of this XCD's L2
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "+v"(q[u]) : "v"(src + (size_t)u * slot_stride) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < H; ++u) asm volatile("" : "+v"(q[u]));
+                __builtin_amdgcn_sched_barrier(0);
+                v4f sum = q[0];
+#pragma unroll
+                for (int u = 1; u < H; ++u) sum += q[u];
+                *(v4f*)(halves + (size_t)w * 4) = sum;
+            }
+            __syncthreads();
+            TailSlice sls[kTailMaxSlices];      // (all slices in one trip to the kernel arguments)
+#pragma unroll
+            for (int si = 0; si < kTailMaxSlices; ++si) {
+                sls[si].bias = tp->s[si].bias; sls[si].y = tp->s[si].y; sls[si].y2 = tp->s[si].y2;
+                sls[si].o0 = tp->s[si].o0; sls[si].nout = tp->s[si].nout; sls[si].flags = tp->s[si].flags;
+                sls[si].y_cstride = tp->s[si].y_cstride; sls[si].y_coffset = tp->s[si].y_coffset;
+                sls[si].y2_cstride = tp->s[si].y2_cstride; sls[si].y2_coffset = tp->s[si].y2_coffset;
+            }
+            for (int w = tid; w < items; w += C::NT) {
+                const int px = w / groups, g = w - px * groups, mm = m0 + px;
+                if (mm >= p.M) continue;
+                const v4f sum = *(const v4f*)(halves + (size_t)w * 4) + *(const v4f*)(halves + (size_t)(items + w) * 4);
+                const int o = 4 * g;
+#pragma unroll
+                for (int si = 0; si < kTailMaxSlices; ++si) {
+                    const TailSlice& sl = sls[si];
+                    if (si >= tp->h.nslices || o < sl.o0 || o >= sl.o0 + sl.nout) continue;
+                    v4f r = sum;
+                    if (sl.bias) r += *(const v4f*)(sl.bias + (o - sl.o0));
+                    if (sl.flags & FCN_CONV_RELU)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+                    *(v4f*)(sl.y + (size_t)mm * sl.y_cstride + sl.y_coffset + (o - sl.o0)) = r;
+                    if ((sl.flags & FCN_CONV_SIGMOID2) && sl.y2) {
+                        v4f sg;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sg[e] = 1.f / (1.f + expf(-r[e]));
+                        *(v4f*)(sl.y2 + (size_t)mm * sl.y2_cstride + sl.y2_coffset + (o - sl.o0)) = sg;
+                    }
+                }
+            }
+            if (tid == 0) tp->h.arrive[tile_m] = 0u;      // (every tile of the block has arrived: the word is ready for the next launch)
+            return;
+        }
+    }
     if (n >= p.Cout) return;
     const bool do_relu = (p.flags & FCN_CONV_RELU) != 0;
     const bool do_sig2 = (p.flags & FCN_CONV_SIGMOID2) != 0 && p.y2 != nullptr;
@@ -947,11 +1097,17 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem)
 #endif
 }
 
-template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
+__device__ __forceinline__ const GroupArgs& group_of(const GroupArgs& a) { return a; }
+__device__ __forceinline__ const GroupArgs& group_of(const GroupArgsTail& a) { return a.g; }
+constexpr int kTailLdsFloats = kTailRows * 32 + 4;      // the narrow problems' filters over a tile's 32 channels + the arrival flag
+
+template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF, bool TAIL = false>
 __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT)) void conv_fwd_group(const int nprob, const int te0, const int te1, const int te2,
                                                                                   const int te3, const int te4, const int te5, const int te6,
-                                                                                  const int te7, const int pool_wgs, const int snake, const GroupArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS];
+                                                                                  const int te7, const int pool_wgs, const int snake,
+                                                                                  const std::conditional_t<TAIL, GroupArgsTail, GroupArgs> a_) {
+    __shared__ __attribute__((aligned(16))) float smem[Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::LDS_FLOATS + (TAIL ? kTailLdsFloats : 0)];
+    const GroupArgs& a = group_of(a_);
     // The launch's fixed cost is what counts at M = 784 (9 us launches, 1.5 us of MFMA work).  The problem table (nprob and
     // the exclusive tile prefix of every problem) travels as the kernel's first SCALAR arguments (eleven with the pooling count and the round dealing): the build preloads
     // them into SGPRs at wave launch (-amdgpu-kernarg-preload-count, Makefile), so a workgroup knows its problem without
@@ -961,6 +1117,7 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
     typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
     typedef const GroupArgs __attribute__((address_space(4))) * karg_ptr;
     // the GroupArgs copy sits behind the eleven ints in the kernarg segment, at its natural alignment
+    static_assert(alignof(GroupArgsTail) == alignof(GroupArgs) && offsetof(GroupArgsTail, g) == 0, "the group leads its tail");
     constexpr size_t kArgsOffset = (11 * sizeof(int) + alignof(GroupArgs) - 1) / alignof(GroupArgs) * alignof(GroupArgs);
     karg_ptr ka = (karg_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + kArgsOffset);
     const int head[1 + kMaxGroup] = {nprob, te0, te1, te2, te3, te4, te5, te6, te7};
@@ -1024,7 +1181,15 @@ __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF,
     __builtin_memcpy((char*)&prob, &ra, 64);
     __builtin_memcpy((char*)&prob + 64, &rb, 64);
     __builtin_memcpy((char*)&prob + 128, &rc, 32);
-    conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(prob, tile - begin, smem);
+    if constexpr (TAIL) {
+        // (the tail's fields are fetched from the kernel arguments where they are used.  Fetching its header here, in the problem's own
+        //  trip, and carrying it in scalar registers through the kernel was measured SLOWER: 13.8 -> 16.1 / 24.1 -> 27.8 us for the two
+        //  launches of inception_5b - the scalar-addressed loader's loop wants those registers)
+        tail_kptr tp = (tail_kptr)((const char __attribute__((address_space(4)))*)ka + offsetof(GroupArgsTail, tail));
+        conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF, true>(prob, tile - begin, smem, tp);
+    } else {
+        conv_body<T, WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>(prob, tile - begin, smem);
+    }
 }
 
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF>
@@ -1998,8 +2163,29 @@ void launch_group_cfg(int cfg, const GroupArgs& ga, int pool_wgs, int snake, int
     }
 }
 
+// the tail variant: float32 split-role shapes with 32-channel tiles (conv_body's static_assert)
+constexpr bool tail_cfg_ok(int cfg) { return cfg == 23 || cfg == 24 || cfg == 25 || cfg == 27; }
+void launch_group_tail(int cfg, const GroupArgsTail& ga, int pool_wgs, int snake, int total, hipStream_t st) {
+    const GroupArgs& g = ga.g;
+    switch (cfg) {
+#define XT(I, A, B, C_, D, E, F, G, H)                                                                                                         \
+    case I:                                                                                                                                    \
+        hipLaunchKernelGGL((conv_fwd_group<float, A, B, C_, D, E, F, G, H, true>), dim3(total), dim3(Cfg<A, B, C_, D, E, F, G, H>::NT), 0, st, g.nprob, \
+                           g.tile_end[0], g.tile_end[1], g.tile_end[2], g.tile_end[3], g.tile_end[4], g.tile_end[5], g.tile_end[6],             \
+                           g.tile_end[7], pool_wgs, snake, ga);                                                                                \
+        break;
+        XT(23, 1, 1, 1, 1, 4, 32, 16 + 4, true)
+        XT(24, 1, 1, 1, 1, 4, 64, 16 + 4, true)
+        XT(25, 1, 1, 2, 1, 2, 32, 16 + 4, true)
+        XT(27, 1, 1, 1, 1, 4, 32, 16 + 6, true)
+#undef XT
+    }
+}
+
 // host copies of prepared groups, keyed by their device workspace (the launch needs the problems by value)
-struct HostGroup { int n; ConvP ps[16]; int npool; PoolP pools[kMaxPool]; };
+struct HostTail { bool on; int finalize; int n; fcn_conv_desc heads[kTailMaxSlices]; float* scratch; unsigned* arrive; TailP t; };
+struct HostGroup { int n; ConvP ps[16]; int npool; PoolP pools[kMaxPool]; HostTail tail; };
+std::unordered_map<const void*, HostTail> g_tails;      // tails announced for a workspace (fcn_conv2d_group_attach_tail), taken by the next prepare()
 std::mutex g_groups_mu;
 std::unordered_map<const void*, HostGroup> g_groups;
 
@@ -2087,8 +2273,59 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
         q.items = d.N * d.OH * d.OW * (d.C / peps);
         q.wg_end = 0;      // depends on the workgroup size of the tile configuration: set at launch
     }
-    const int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
+    HostTail tail = {};
+    {
+        std::lock_guard<std::mutex> lock(g_groups_mu);
+        auto it = g_tails.find(d_workspace);
+        if (it != g_tails.end()) tail = it->second;
+    }
+    if (tail.on) {
+        // which problems write the narrow problems' input?  Each of them contributes partial sums (conv_common.h, TailP)
+        const fcn_conv_desc& h0 = tail.heads[0];
+        int contributors = 0;
+        FCN_REQUIRE(n <= kMaxGroup && !group_f16, FCN_E_UNSUPPORTED, "conv tail: at most %d float32 problems in the launch", kMaxGroup);
+        for (int i = 0; i < n; ++i) {
+            const ConvP& q = ps[i];
+            if ((const float*)q.y != h0.x) continue;
+            FCN_REQUIRE(q.y_cstride == h0.x_cstride && q.M == h0.N * h0.H * h0.W && q.Cout % 32 == 0 && q.y_coffset % 32 == 0 && q.y_coffset + q.Cout <= h0.Cin &&
+                            (q.flags & ~FCN_CONV_RELU) == 0 && ((uintptr_t)q.y & 15) == 0 && q.y_cstride % 4 == 0 && (!q.bias || ((uintptr_t)q.bias & 15) == 0),
+                        FCN_E_UNSUPPORTED, "conv tail: a producer of the narrow problems' input must be a float32 bias + ReLU convolution over the same pixels "
+                                           "that writes whole 32-channel groups of it");
+            ps[i].flags |= FCN_CONV_TAILF;
+            ++contributors;
+        }
+        FCN_REQUIRE(contributors > 0, FCN_E_ARG, "conv tail: no problem of this group writes the narrow problems' input");
+    }
+    int cfg = cfg_request >= 0 ? cfg_request : choose_cfg(ps, n);
+    if (tail.on && cfg_request < 0 && !tail_cfg_ok(cfg)) cfg = 23;
+    FCN_REQUIRE(!tail.on || tail_cfg_ok(cfg), FCN_E_UNSUPPORTED, "conv tail: configuration %d has no tail variant (23, 24, 25, 27 do)", cfg);
     const int total = plan_tiles_cfg(cfg, ps, n);
+    if (tail.on && total > 0) {
+        TailP& t = tail.t;
+        t = TailP{};
+        t.h.scratch = tail.scratch;
+        t.h.arrive = tail.arrive;
+        t.h.K = tail.heads[0].Cin;
+        t.h.M = tail.heads[0].N * tail.heads[0].H * tail.heads[0].W;
+        t.h.nslices = tail.n;
+        int rows = 0;
+        for (int i = 0; i < tail.n; ++i) {
+            const fcn_conv_desc& h = tail.heads[i];
+            TailSlice& sl = t.s[i];
+            sl.bias = h.bias; sl.y = h.y; sl.y2 = h.y2;
+            sl.o0 = rows; sl.nout = h.Cout; sl.y_cstride = h.y_cstride; sl.y_coffset = h.y_coffset; sl.y2_cstride = h.y2_cstride; sl.y2_coffset = h.y2_coffset;
+            sl.flags = h.flags;
+            for (int r = 0; r < h.Cout; r += 4) t.h.gw[(rows + r) / 4] = h.w + (size_t)r * h.Cin;
+            rows += h.Cout;
+        }
+        for (int j = rows / 4; j < kTailRows / 4; ++j) t.h.gw[j] = t.h.gw[0];
+        t.h.rows = rows;
+        t.h.dbg = getenv("FCN_TAIL_DEBUG") ? atoi(getenv("FCN_TAIL_DEBUG")) : 0;      // (elimination switches: 1 no staging, 2 no partial sums, 4 no partial stores)
+        t.h.need = 0;
+        if (tail.finalize)
+            for (int i = 0; i < n; ++i)
+                if (ps[i].flags & FCN_CONV_TAILF) t.h.need += ps[i].tiles_n;
+    }
     FCN_REQUIRE(!(is_stream_cfg(cfg) && (total == -2 || npools || n > kMaxGroup)), FCN_E_UNSUPPORTED,
                 "conv group: configuration %d (persistent half-float streaming kernel) takes at most %d half problems with half outputs, "
                 "bias + ReLU only, Cout / y_cstride / y_coffset multiples of 8, stride-1 1x1 / 3x3 / 5x5 filters with pad (k - 1) / 2 on images wide "
@@ -2106,6 +2343,7 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
         for (int i = 0; i < n; ++i) hg.ps[i] = ps[i];
         hg.npool = npools;
         for (int i = 0; i < kMaxPool; ++i) hg.pools[i] = pools[i];
+        hg.tail = tail;
     }
     h_out->d_probs = d_workspace;
     h_out->n = n;
@@ -2117,6 +2355,64 @@ int fcn_conv2d_group_prepare_fused(const fcn_conv_desc* h_descs, int n, const fc
 int fcn_conv2d_group_release(void* d_workspace) {
     std::lock_guard<std::mutex> lock(g_groups_mu);
     g_groups.erase(d_workspace);
+    g_tails.erase(d_workspace);
+    return 0;
+}
+
+namespace {
+int tail_check(const fcn_conv_tail* t) {
+    FCN_REQUIRE(t && t->n >= 1 && t->n <= kTailMaxSlices, FCN_E_ARG, "conv tail: 1..%d narrow problems", kTailMaxSlices);
+    int rows = 0;
+    const fcn_conv_desc& h0 = t->heads[0];
+    for (int i = 0; i < t->n; ++i) {
+        const fcn_conv_desc& h = t->heads[i];
+        int rc = validate(h);
+        if (rc) return rc;
+        FCN_REQUIRE(h.kh == 1 && h.kw == 1 && h.stride == 1 && h.pad == 0 && (h.flags & ~(FCN_CONV_RELU | FCN_CONV_SIGMOID2)) == 0, FCN_E_UNSUPPORTED,
+                    "conv tail: the narrow problems are float32 1x1 / stride 1 convolutions (bias, ReLU, sigmoid second output)");
+        FCN_REQUIRE(h.x == h0.x && h.x_cstride == h0.x_cstride && h.Cin == h0.Cin && h.N == h0.N && h.H == h0.H && h.W == h0.W, FCN_E_ARG,
+                    "conv tail: the narrow problems read the same blob");
+        FCN_REQUIRE(h.Cout % 4 == 0 && h.Cin % 32 == 0 && h.Cin <= 1024 && h.y_cstride % 4 == 0 && h.y_coffset % 4 == 0 && ((uintptr_t)h.y & 15) == 0 &&
+                        (!h.bias || ((uintptr_t)h.bias & 15) == 0) && (!h.y2 || (((uintptr_t)h.y2 & 15) == 0 && h.y2_cstride % 4 == 0 && h.y2_coffset % 4 == 0)),
+                    FCN_E_UNSUPPORTED, "conv tail: outputs in whole, 16-byte aligned groups of four channels; input channels in whole groups of 32, at most 1024");
+        rows += h.Cout;
+    }
+    FCN_REQUIRE(rows <= kTailRows, FCN_E_UNSUPPORTED, "conv tail: at most %d output channels in all", kTailRows);
+    return 0;
+}
+}  // namespace
+
+size_t fcn_conv2d_tail_scratch_bytes(const fcn_conv_tail* t) {
+    if (tail_check(t)) return 0;
+    size_t rows = 0;
+    for (int i = 0; i < t->n; ++i) rows += (size_t)t->heads[i].Cout;
+    return (size_t)(t->heads[0].Cin / 32) * (size_t)t->heads[0].N * t->heads[0].H * t->heads[0].W * rows * sizeof(float);
+}
+
+size_t fcn_conv2d_tail_arrive_bytes(const fcn_conv_tail* t) {
+    if (tail_check(t)) return 0;
+    return ((size_t)t->heads[0].N * t->heads[0].H * t->heads[0].W / 32 + 1) * sizeof(unsigned);
+}
+
+int fcn_conv2d_group_attach_tail(void* d_workspace, const fcn_conv_tail* t) {
+    FCN_REQUIRE(d_workspace, FCN_E_ARG, "fcn_conv2d_group_attach_tail: null workspace");
+    if (!t) {
+        std::lock_guard<std::mutex> lock(g_groups_mu);
+        g_tails.erase(d_workspace);
+        return 0;
+    }
+    int rc = tail_check(t);
+    if (rc) return rc;
+    FCN_REQUIRE(t->scratch && t->arrive && ((uintptr_t)t->scratch & 15) == 0, FCN_E_ARG, "fcn_conv2d_group_attach_tail: scratch (16-byte aligned) and arrival words");
+    HostTail ht = {};
+    ht.on = true;
+    ht.finalize = t->finalize ? 1 : 0;
+    ht.n = t->n;
+    for (int i = 0; i < t->n; ++i) ht.heads[i] = t->heads[i];
+    ht.scratch = t->scratch;
+    ht.arrive = reinterpret_cast<unsigned*>(t->arrive);
+    std::lock_guard<std::mutex> lock(g_groups_mu);
+    g_tails[d_workspace] = ht;
     return 0;
 }
 
@@ -2212,7 +2508,13 @@ int fcn_conv2d_fwd_group_f32(const fcn_conv_group* g, fcn_stream_t s) {
                 snake = -(grid - cus);      // two rounds: rotate the tile order by the overhang (conv_fwd_group)
             }
         }
-        if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, pool_wgs, snake, grid, as_stream(s));
+        if (hg.tail.on) {      // (n <= kMaxGroup: the only launch)
+            FCN_REQUIRE(tail_cfg_ok(g->cfg) && hg.n <= kMaxGroup, FCN_E_STATE, "fcn_conv2d_fwd_group_f32: group was not prepared with its tail");
+            GroupArgsTail gt;
+            gt.g = ga;
+            gt.tail = hg.tail.t;
+            launch_group_tail(g->cfg, gt, pool_wgs, snake, grid, as_stream(s));
+        } else if (hg.ps[0].flags & FCN_CONV_F16) launch_group_cfg<f16_t>(g->cfg, ga, pool_wgs, snake, grid, as_stream(s));
         else launch_group_cfg<float>(g->cfg, ga, pool_wgs, snake, grid, as_stream(s));
         FCN_LAUNCH_CHECK("conv_fwd_group");
     }

@@ -538,6 +538,7 @@ class Engine:
                 lv = i            # strict layer order, one launch per layer
             levels.append(lv)
         self._move_floaters(tasks, levels, hit)
+        tail = self._plan_tail(tasks, levels, hit)
         order = sorted(range(len(tasks)), key=lambda i: (levels[i], 0 if tasks[i]["kind"] == "op" else 1, i))
 
         def emit_group(chunk: List[dict], fused: List[dict]) -> None:
@@ -551,6 +552,15 @@ class Engine:
             grp = L.ConvGroup()
             parr = (L.PoolDesc * max(len(fused), 1))(*[pt["pool_desc"] for pt in fused])
             tune_key = name + ("{+%d pool}" % len(fused) if fused else "")
+            tailed = tail is not None and any(id(it) in tail["producers"] for it in chunk)
+            if tailed:      # this launch writes (part of) the blob the narrow heads read: it carries them as its tail
+                fin = 1 if any(tail["producers"][id(it)] == tail["final_level"] for it in chunk if id(it) in tail["producers"]) else 0
+                tail["desc"].finalize = fin
+                L.call("fcn_conv2d_group_attach_tail", ws.ptr, C.byref(tail["desc"]))
+                tune_key += "{+tail%d}" % fin
+                if fin:
+                    flops += sum(ht["flops"] for ht in tail["heads"])
+                    byts += sum(4.0 * ht["desc"].Cout * (ht["desc"].N * ht["desc"].OH * ht["desc"].OW + ht["desc"].Cin) for ht in tail["heads"])
             cfg = self._tuned_cfg(tune_key, arr, len(chunk), ws, parr, len(fused)) if self.autotune else -1
             L.call("fcn_conv2d_group_prepare_fused", arr, len(chunk), parr, len(fused), ws.ptr, cfg, C.byref(grp))
             self._keep.extend([arr, parr, ws, grp])
@@ -559,6 +569,8 @@ class Engine:
             if fused:
                 label = "%s {+%s}" % (label, "+".join(pt["layer"].name for pt in fused))
                 byts += sum(pt["ops"][0].bytes for pt in fused)
+            if tailed:
+                label = "%s {%s %s}" % (label, "tail:" if tail["desc"].finalize else "partial sums of", "+".join(ht["layer"].name for ht in tail["heads"]))
             self.ops.append(Op(kind, label, lambda st, g=grp: L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(g), st)), flops, byts))
 
         def emit_convs(items: List[dict], pools: List[dict]) -> None:
@@ -587,6 +599,8 @@ class Engine:
             if levels[i] != cur:
                 emit_convs(pending, pending_pools)
                 pending, cur = [], levels[i]
+            if tail is not None and any(tasks[i] is ht for ht in tail["heads"]):
+                continue      # evaluated by the launches that produce its input
             if tasks[i]["kind"] == "conv":
                 pending.append(tasks[i])
             elif tasks[i].get("pool_desc") is not None and self.fuse and self.group_convs:
@@ -595,6 +609,64 @@ class Engine:
                 self.ops.extend(tasks[i]["ops"])
         emit_convs(pending, pending_pools)
         self.levels = max(levels) + 1 if levels else 0
+
+    def _plan_tail(self, tasks: List[dict], levels: List[int], hit) -> Optional[dict]:
+        """The detection heads (cvg/classifier + bbox/regressor of models/deploy.prototxt: 4 + 16 outputs over inception_5b/output) as the
+        TAIL of the launches that produce their input (fcn_conv2d_group_attach_tail, csrc/conv_common.h): as a launch of their own they are
+        0.03 GFLOP behind a whole launch's fixed cost (6 us of a 266 us frame).  Taken when the net's LAST convolution level holds only
+        narrow float32 1x1 problems over one blob whose channels are all written by bias + ReLU convolutions of the one or two levels
+        before, in whole 32-channel groups.  Returns None (heads launched as before) or the plan emit_group() works from."""
+        if self.f16 or self.spec.phase != "TEST" or not (self.fuse and self.group_convs) or os.environ.get("FCN_CONV_TAIL", "0") != "1":
+            return None
+        conv_idx = [i for i, t in enumerate(tasks) if t["kind"] == "conv"]
+        if not conv_idx:
+            return None
+        lh = max(levels[i] for i in conv_idx)
+        heads = [i for i in conv_idx if levels[i] == lh]
+        if any(levels[i] >= lh for i, t in enumerate(tasks) if t["kind"] != "conv") or not 1 <= len(heads) <= 4:
+            return None
+        d0 = tasks[heads[0]]["desc"]
+        m = d0.N * d0.OH * d0.OW
+        rows = 0
+        for i in heads:
+            d = tasks[i]["desc"]
+            if (d.kh, d.kw, d.stride, d.pad) != (1, 1, 1, 0) or d.x != d0.x or d.x_cstride != d0.x_cstride or d.Cin != d0.Cin or d.Cin % 32 or d.Cin > 1024 or d.Cout % 4 \
+                    or (d.flags & ~(L.CONV_RELU | L.CONV_SIGMOID2)) or d.y_cstride % 4 or d.y_coffset % 4 or (d.y2 and (d.y2_cstride % 4 or d.y2_coffset % 4)):
+                return None
+            rows += d.Cout
+        if rows > 24 or m > 4096:      # (scratch: K / 32 x M x rows floats)
+            return None
+        xr = tasks[heads[0]]["reads"]
+        producers: Dict[int, int] = {}
+        covered = 0
+        for i, t in enumerate(tasks):
+            if i in heads or not hit(t["writes"], xr):
+                continue
+            d = t.get("desc")
+            if t["kind"] != "conv" or levels[i] not in (lh - 1, lh - 2) or d.y != d0.x or d.y_cstride != d0.x_cstride or d.N * d.OH * d.OW != m \
+                    or d.Cout % 32 or d.y_coffset % 32 or d.y_coffset + d.Cout > d0.Cin or (d.flags & ~L.CONV_RELU) or d.y_cstride % 4:
+                return None
+            producers[id(t)] = levels[i]
+            covered += d.Cout
+        if covered != d0.Cin or not producers:
+            return None
+        for lv in set(producers.values()):      # each producing level is ONE launch
+            if sum(1 for i in conv_idx if levels[i] == lv) > 8:
+                return None
+        if any(hit(t["reads"], xr) for i, t in enumerate(tasks) if i not in heads and levels[i] <= lh and id(t) not in producers and levels[i] > min(producers.values())):
+            pass      # (other readers of the blob see it complete: the tail changes nothing for them)
+        lib = L.load()
+        desc = L.ConvTail()
+        desc.n = len(heads)
+        for j, i in enumerate(heads):
+            desc.heads[j] = tasks[i]["desc"]
+        sb, ab = int(lib.fcn_conv2d_tail_scratch_bytes(C.byref(desc))), int(lib.fcn_conv2d_tail_arrive_bytes(C.byref(desc)))
+        if sb <= 0 or ab <= 0:
+            return None
+        scratch, arrive = DeviceBuffer(sb, zero=False), DeviceBuffer(ab, zero=True)
+        desc.scratch, desc.arrive = scratch.ptr, arrive.ptr
+        self._keep.extend([scratch, arrive, desc])
+        return dict(desc=desc, heads=[tasks[i] for i in heads], producers=producers, final_level=max(producers.values()))
 
     def _fuse_pool_lrn(self, tasks: List[dict]) -> List[dict]:
         """MAX pooling directly followed by LRN (pool1 -> norm1) or LRN directly followed by MAX pooling (norm2 -> pool2)

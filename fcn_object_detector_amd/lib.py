@@ -37,6 +37,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvTail(C.Structure):
+    _fields_ = [("n", C.c_int32), ("finalize", C.c_int32), ("heads", ConvDesc * 4), ("scratch", C.c_void_p), ("arrive", C.c_void_p)]
+
+
 class ConvGroup(C.Structure):
     _fields_ = [("d_probs", C.c_void_p), ("n", C.c_int32), ("cfg", C.c_int32), ("total_tiles", C.c_int32)]
 
@@ -129,6 +133,9 @@ PROTOTYPES = {
     "fcn_conv2d_group_prepare_fused": (_i, [C.POINTER(ConvDesc), _i, C.POINTER(PoolDesc), _i, _vp, _i, C.POINTER(ConvGroup)]),
     "fcn_conv2d_fwd_group_f32": (_i, [C.POINTER(ConvGroup), _vp]),
     "fcn_conv2d_group_release": (_i, [_vp]),
+    "fcn_conv2d_tail_scratch_bytes": (C.c_size_t, [C.POINTER(ConvTail)]),
+    "fcn_conv2d_tail_arrive_bytes": (C.c_size_t, [C.POINTER(ConvTail)]),
+    "fcn_conv2d_group_attach_tail": (_i, [_vp, C.POINTER(ConvTail)]),
     "fcn_maxpool_fwd_f32": (_i, [_vp, _vp, _vp] + [_i] * 12 + [_vp]),
     "fcn_avepool_fwd_f32": (_i, [_vp, _vp] + [_i] * 12 + [_vp]),
     "fcn_lrn_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _vp]),

@@ -147,6 +147,28 @@ int  fcn_conv2d_num_configs(void);
  *                                        pixels with at most 32 output channels in all, counted in slices of 8 per problem (the
  *                                        detection heads cvg/classifier + bbox/regressor); ReLU and FCN_CONV_SIGMOID2 allowed. */
 int  fcn_conv2d_first_layer_config(void);
+/* A "tail": narrow 1x1 problems (the detection heads cvg/classifier + bbox/regressor, deploy.prototxt:2363-2410 - 4 + 16 outputs over the
+ * 1024 channels of inception_5b/output) evaluated BY THE LAUNCHES THAT PRODUCE THEIR INPUT instead of a launch of their own: every tile
+ * that has written 32 channels of a block of pixels leaves their contribution to the narrow outputs in `scratch`, and the tile that
+ * arrives last at a pixel block adds the contributions in channel order (a fixed order: bit-reproducible), applies bias / ReLU /
+ * sigmoid and writes the narrow problems' outputs.  Announce the tail for a workspace BEFORE fcn_conv2d_group_prepare[_fused] on that
+ * workspace; every problem of the group whose y is heads[0].x then contributes (it must be a float32 bias + ReLU problem over the same
+ * pixels writing whole 32-channel groups of that blob).  finalize = 1 for the launch that completes the blob, 0 for an earlier launch
+ * that writes part of it (partial sums only).  Tile configurations 23, 24, 25 and 27 have a tail variant; prepare() returns
+ * FCN_E_UNSUPPORTED for the others.  heads: float32 1x1 / stride 1 problems reading the same blob, outputs in whole groups of four
+ * channels, at most 24 in all; flags within FCN_CONV_RELU | FCN_CONV_SIGMOID2.  scratch / arrive: device memory of
+ * fcn_conv2d_tail_scratch_bytes() / fcn_conv2d_tail_arrive_bytes() bytes, arrive zeroed once by the caller (launches leave it zero);
+ * two launches that share them must not overlap in time.  fcn_conv2d_group_attach_tail(ws, NULL) and fcn_conv2d_group_release(ws) forget it. */
+typedef struct fcn_conv_tail {
+    int32_t n;                 /* 1..4 narrow problems */
+    int32_t finalize;
+    fcn_conv_desc heads[4];
+    float*  scratch;
+    void*   arrive;
+} fcn_conv_tail;
+size_t fcn_conv2d_tail_scratch_bytes(const fcn_conv_tail* t);
+size_t fcn_conv2d_tail_arrive_bytes(const fcn_conv_tail* t);
+int  fcn_conv2d_group_attach_tail(void* d_workspace, const fcn_conv_tail* t);
 /* LDS bytes one workgroup of that configuration holds (a CU has 160 KiB: it bounds how many workgroups - of this or of a
  * concurrent launch on another stream - fit on a CU); -1 for an unknown index */
 int  fcn_conv2d_config_lds_bytes(int cfg);

@@ -573,3 +573,78 @@ def test_maxpool_fused_into_conv_group(gpu, cfg, with_idx):
     pools[0].y_coffset = 2
     bad = (L.PoolDesc * 1)(pools[0])
     assert L.load().fcn_conv2d_group_prepare_fused(arr, 2, bad, 1, ws.ptr, cfg, C.byref(grp)) == 2      # FCN_E_ALIGN
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("cfg", [23, 24, 25, 27])
+@pytest.mark.parametrize("hw", [(28, 28), (9, 7)])
+def test_narrow_heads_as_the_tail_of_their_producers(gpu, cfg, hw, split):
+    """fcn_conv2d_group_attach_tail: the detection heads (cvg/classifier with its sigmoid + bbox/regressor, deploy.prototxt:2363-2410)
+    evaluated by the launches that produce their input - three branches of a concat blob, all in the finalising launch or one of them
+    in an earlier contribute-only launch - against the oracle's convolutions; a second pair of launches must give the same bits (the
+    arrival words are left zero, the partial sums are added in slot order)."""
+    rng = np.random.default_rng(31)
+    h, w = hw
+    n, cin = 1, 64
+    x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+    xd = dev_from(nhwc(x))
+    couts, ks = [64, 96, 32], [1, 3, 1]
+    K = sum(couts)
+    ws = [(rng.standard_normal((co, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32) for co, k in zip(couts, ks)]
+    bs = [rng.standard_normal(co).astype(np.float32) * 0.1 for co in couts]
+    blob = dev_from(np.zeros((n, h, w, K), np.float32))
+    keep, descs, off = [], [], 0
+    for wt, b, co, k in zip(ws, bs, couts, ks):
+        wd, bd = dev_from(pack_ohwi(wt)), dev_from(b)
+        keep += [wd, bd]
+        descs.append(conv_desc(xd, wd, bd, blob, n, h, w, cin, cin, co, k, k // 2, 1, h, w, K, off, L.CONV_RELU))
+        off += co
+    hws = [(rng.standard_normal((co, K, 1, 1)) / np.sqrt(K)).astype(np.float32) for co in (4, 16)]
+    hbs = [rng.standard_normal(co).astype(np.float32) for co in (4, 16)]
+    cvg, sig, box = (dev_from(np.full((n, h, w, c), -3.0, np.float32)) for c in (4, 4, 16))
+    tail = L.ConvTail()
+    tail.n = 2
+    hd = [dev_from(np.ascontiguousarray(hw_.reshape(hw_.shape[0], K))) for hw_ in hws]
+    hb = [dev_from(b) for b in hbs]
+    tail.heads[0] = conv_desc(blob, hd[0], hb[0], cvg, n, h, w, K, K, 4, 1, 0, 1, h, w, 4, 0, L.CONV_SIGMOID2, 0.0, sig, 4, 0)
+    tail.heads[1] = conv_desc(blob, hd[1], hb[1], box, n, h, w, K, K, 16, 1, 0, 1, h, w, 16, 0, 0)
+    lib = L.load()
+    sb, ab = int(lib.fcn_conv2d_tail_scratch_bytes(C.byref(tail))), int(lib.fcn_conv2d_tail_arrive_bytes(C.byref(tail)))
+    assert sb == (K // 32) * n * h * w * 20 * 4 and ab >= 4 * ((n * h * w + 31) // 32)
+    scratch = dev_from(np.full(sb // 4, np.nan, np.float32))       # (every slot of a pixel is written before it is read)
+    arrive = dev_from(np.zeros(ab // 4, np.uint32))
+    tail.scratch, tail.arrive = scratch.ptr, arrive.ptr
+    launches = [([0], 0), ([1, 2], 1)] if split else [([0, 1, 2], 1)]
+    groups = []
+    for idx, fin in launches:
+        arr = (L.ConvDesc * len(idx))(*[descs[i] for i in idx])
+        wsd = DeviceBuffer(int(lib.fcn_conv2d_group_workspace_bytes(len(idx))), zero=False)
+        tail.finalize = fin
+        L.call("fcn_conv2d_group_attach_tail", wsd.ptr, C.byref(tail))
+        grp = L.ConvGroup()
+        L.call("fcn_conv2d_group_prepare", arr, len(idx), wsd.ptr, cfg, C.byref(grp))
+        assert grp.cfg == cfg
+        groups.append((arr, wsd, grp))
+    results = []
+    for _ in range(2):
+        for _, _, grp in groups:
+            L.call("fcn_conv2d_fwd_group_f32", C.byref(grp), None)
+        results.append([dev_to(d, (n, h, w, c)) for d, c in ((blob, K), (cvg, 4), (sig, 4), (box, 16))])
+        assert not dev_to(arrive, (ab // 4,), np.uint32).any()
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+    yb, yc, ys, yx = results[0]
+    ref = np.concatenate([R.relu(R.conv2d(x, wt, b, k // 2, 1)) for wt, b, k in zip(ws, bs, ks)], axis=1)
+    assert rel_err(nchw(yb, K), ref) < TOL
+    rc, rx = R.conv2d(ref, hws[0], hbs[0], 0, 1), R.conv2d(ref, hws[1], hbs[1], 0, 1)
+    assert rel_err(nchw(yc, 4), rc) < TOL and rel_err(nchw(yx, 16), rx) < TOL
+    assert elem_err(nchw(yc, 4), rc, tol=1e-4)[0] <= 1.0 and elem_err(nchw(yx, 16), rx, tol=1e-4)[0] <= 1.0
+    assert np.abs(nchw(ys, 4) - R.sigmoid(rc)).max() < 1e-5
+    # a configuration without a tail variant is refused while the tail is attached; detached, the plain group runs there
+    _, wsd, grp = groups[-1]
+    arr = groups[-1][0]
+    assert lib.fcn_conv2d_group_prepare(arr, len(launches[-1][0]), wsd.ptr, 5, C.byref(grp)) != 0
+    L.call("fcn_conv2d_group_attach_tail", wsd.ptr, None)
+    L.call("fcn_conv2d_group_prepare", arr, len(launches[-1][0]), wsd.ptr, 5, C.byref(grp))
+    for _, wsd, _ in groups:
+        L.call("fcn_conv2d_group_release", wsd.ptr)

@@ -57,6 +57,39 @@ def test_deploy_448_matches_oracle(gpu):
     eng.close()
 
 
+@pytest.mark.parametrize("batch,hw", [(1, (448, 448)), (2, (96, 128))])
+def test_heads_as_the_tail_of_inception_5b(gpu, monkeypatch, batch, hw):
+    """FCN_CONV_TAIL=1 (opt-in: measured no faster at batch 1): cvg/classifier + bbox/regressor evaluated by the launches that
+    write inception_5b/output instead of a launch of their own - the plan holds no heads launch, the heads' blobs match the oracle and
+    the default plan, graph replay and eager launches give the same bits."""
+    h, w = hw
+    cls = 4 if batch == 1 else 1      # (one class: cvg/classifier has a single channel - not in whole fours - and the plan keeps the heads' launch)
+    x = np.random.default_rng(11).random((batch, 3, h, w), dtype=np.float32) * 255 - 127
+    msg, params, plain = build(batch, h, w, cls)
+    plain.host_array("data")[...] = x
+    want = {k: v.copy() for k, v in plain.forward().items()}
+    plain.close()
+    monkeypatch.setenv("FCN_CONV_TAIL", "1")
+    msg, params, eng = build(batch, h, w, cls)
+    names = [op.name for op in eng.ops]
+    if cls == 4:
+        assert not any(nm.startswith("cvg/classifier") for nm in names) and any("tail: cvg/classifier+bbox/regressor" in nm for nm in names)
+    else:
+        assert any(nm.startswith("cvg/classifier") for nm in names)
+    eng.host_array("data")[...] = x
+    out = {k: v.copy() for k, v in eng.forward().items()}
+    rb = oracle_forward(msg, params, x)
+    for name in ("coverage", "bboxes"):
+        assert rel_err(out[name], rb[name]) < TOL and rel_err(out[name], want[name]) < 1e-5, name
+        assert elem_err(out[name], rb[name], TOL)[0] <= 1.0
+    assert rel_err(eng.read_blob("cvg/classifier"), rb["cvg/classifier"]) < TOL and rel_err(eng.read_blob("inception_5b/output"), rb["inception_5b/output"]) < TOL
+    again = eng.forward()
+    eager = eng.forward(use_graph=False)
+    for name in out:
+        assert np.array_equal(again[name], out[name]) and np.array_equal(eager[name], out[name])
+    eng.close()
+
+
 @pytest.mark.parametrize("fuse,group", [(False, False), (True, False)])
 def test_unfused_plans_agree(gpu, fuse, group):
     msg, params, eng = build(2, 96, 128, 3, fuse=fuse, group_convs=group)
