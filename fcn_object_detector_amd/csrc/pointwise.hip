@@ -872,6 +872,97 @@ __global__ __launch_bounds__(512) void pool_lrn5_f16_lds_kernel(const _Float16* 
     }
 }
 
+// pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce (+ ReLU) of models/deploy.prototxt:54-104 at batch 32, half floats, ONE launch: the pool-first
+// form of pool_lrn5_f16_lds_kernel for 64 channels (a workgroup owns 4 x 16 output pixels), whose last step writes the normalised tile
+// to LDS instead of HBM and multiplies it by the 64 x 64 filter bank with v_mfma_f32_16x16x16_f16 as out^T = W . act^T (A = 16 filters x
+// 16 k, B = 16 k x 16 pixels; the k index of (step, lane group, element) is 16 * group + 4 * step + element, so a lane's filter values are one
+// 32-byte run loaded at the top of the kernel and its pixel values two ds_read_b128; D's register r of lane (pixel j, group h) is output
+// channel 16 * tile + 4 h + r): bias, ReLU, one rounding to half, an 8-byte store per lane.  The convolution as a launch of its own was
+// 29 us of the 1.39 ms forward (a 51 MB blob written and read back); pooling and LRN are the stand-alone kernel's arithmetic.
+template <bool B075>
+__global__ __launch_bounds__(512) void pool_lrn5_conv1x1_f16_lds_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ w, const float* __restrict__ bias,
+                                                                        _Float16* __restrict__ y, int H, int W, int x_cstride, int OH, int OW, int y_cstride,
+                                                                        int y_coffset, int relu, float alpha_over_n, float beta, float kk) {
+    constexpr int C = 64, TW = 16, TH = 4, NT = 512, segs = C / 8, pitch = C * 2;
+    constexpr int PWp = 2 * TW + 1, PH = 2 * TH + 1, npix = PH * PWp, nitems = npix * segs;      // 9 x 33 pixels, 2376 staging items
+    constexpr int apitch = pitch + 16;                                                            // normalised tile: 144 bytes per pixel (bank spread)
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef const void __attribute__((address_space(1))) * gptr;
+    typedef void __attribute__((address_space(3))) * lptr;
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    typedef float f4_t __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int oy0 = (int)blockIdx.y * TH, ox0 = (int)blockIdx.x * TW, n = (int)blockIdx.z;
+    const _Float16* xn = x + (size_t)n * H * W * x_cstride;
+    // wave -> output-channel tile ct = wave & 3; lane (i = lane & 15, h = lane >> 4) holds W[16 ct + i][16 h .. 16 h + 15]
+    const int ct = wave & 3, fi = lane & 15, fh = lane >> 4;
+    for (int i = wave; i * 64 < nitems; i += NT / 64) {
+        int g = i * 64 + lane;
+        g = g < nitems ? g : nitems - 1;
+        const int p = g / segs, sg = g - p * segs;
+        const int pr = p / PWp, pc = p - pr * PWp;
+        int iy = 2 * oy0 + pr, ix = 2 * ox0 + pc;
+        iy = iy >= H ? H - 1 : iy;
+        ix = ix >= W ? W - 1 : ix;
+        __builtin_amdgcn_global_load_lds((gptr)(xn + ((size_t)iy * W + ix) * x_cstride + sg * 8), (lptr)(lds + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // (the filter fragments are needed last: their latency hides behind the pooling and the normalisation)
+    const h8_t wf0 = *reinterpret_cast<const h8_t*>(w + (size_t)(16 * ct + fi) * C + 16 * fh);
+    const h8_t wf1 = *reinterpret_cast<const h8_t*>(w + (size_t)(16 * ct + fi) * C + 16 * fh + 8);
+    const f4_t bv = bias ? *reinterpret_cast<const f4_t*>(bias + 16 * ct + 4 * fh) : f4_t{0.f, 0.f, 0.f, 0.f};
+    h8_t zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (_Float16)0.f;
+    constexpr int nout = TH * TW * segs;                          // 512 items: one per thread
+    constexpr int staged = (nitems + 63) / 64 * 1024;
+    char* const pooled = lds + staged;                             // [64 pixels][128 bytes]
+    char* const act = pooled + TH * TW * pitch;                    // [64 pixels][144 bytes]
+    {
+        const int op = tid / segs, sg = tid - op * segs;
+        const int oyl = op / TW, oxl = op - oyl * TW;
+        const char* w0 = lds + ((2 * oyl) * PWp + 2 * oxl) * pitch + sg * 16;
+        h8_t m = *reinterpret_cast<const h8_t*>(w0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if (dy || dx) m = max8(m, *reinterpret_cast<const h8_t*>(w0 + (dy * PWp + dx) * pitch));
+        *reinterpret_cast<h8_t*>(pooled + (size_t)tid * 16) = m;
+        __syncthreads();
+        const char* base = pooled + (size_t)op * pitch;
+        const h8_t c = *reinterpret_cast<const h8_t*>(base + sg * 16);
+        const h8_t l = sg > 0 ? *reinterpret_cast<const h8_t*>(base + sg * 16 - 16) : zero;
+        const h8_t r = sg + 1 < segs ? *reinterpret_cast<const h8_t*>(base + sg * 16 + 16) : zero;
+        *reinterpret_cast<h8_t*>(act + (size_t)op * apitch + sg * 16) = lrn5_h8<B075>(l, c, r, alpha_over_n, beta, kk);
+        static_assert(nout == NT, "one pooling / LRN item per thread");
+    }
+    __syncthreads();
+    // out^T = W . act^T: wave -> channel tile ct and the pixel tiles 2 (wave >> 2), 2 (wave >> 2) + 1
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int pt = 2 * (wave >> 2) + t;
+        const char* ap = act + (size_t)(16 * pt + fi) * apitch + 32 * fh;
+        const h8_t a0 = *reinterpret_cast<const h8_t*>(ap), a1 = *reinterpret_cast<const h8_t*>(ap + 16);
+        f4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h4_t{wf0[0], wf0[1], wf0[2], wf0[3]}, h4_t{a0[0], a0[1], a0[2], a0[3]}, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h4_t{wf0[4], wf0[5], wf0[6], wf0[7]}, h4_t{a0[4], a0[5], a0[6], a0[7]}, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h4_t{wf1[0], wf1[1], wf1[2], wf1[3]}, h4_t{a1[0], a1[1], a1[2], a1[3]}, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h4_t{wf1[4], wf1[5], wf1[6], wf1[7]}, h4_t{a1[4], a1[5], a1[6], a1[7]}, acc, 0, 0, 0);
+        const int op = 16 * pt + fi;
+        const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+        h4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[e] + bv[e];
+            if (relu) v = fmaxf(v, 0.f);
+            o[e] = (_Float16)v;
+        }
+        if (oy < OH && ox < OW) *reinterpret_cast<h4_t*>(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + y_coffset + 16 * ct + 4 * fh) = o;
+    }
+}
+
 extern "C" {
 
 int fcn_nchw_to_nhwc_f32(const float* src, float* dst, int N, int C, int H, int W, int dst_cstride, int dst_coffset, float shift,
@@ -1187,6 +1278,31 @@ int fcn_maxpool_lrn5_fwd_f16(const void* x, void* y, int N, int H, int W, int C,
     else FCN_ML_LAUNCH(false, false);
 #undef FCN_ML_LAUNCH
     FCN_LAUNCH_CHECK("maxpool_lrn5_f16");
+    return 0;
+}
+
+int fcn_maxpool_lrn5_conv1x1_fwd_f16(const void* x, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad, int OH, int OW,
+                                     float alpha, float beta, float lrn_k, const void* w, const float* bias, int Cout, int relu, void* y,
+                                     int y_cstride, int y_coffset, fcn_stream_t s) {
+    FCN_REQUIRE(x && y && w && N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0 && y_coffset >= 0, FCN_E_ARG, "maxpool_lrn5_conv1x1_f16: bad args");
+    FCN_REQUIRE(C == 64 && Cout == 64 && k == 3 && stride == 2 && pad == 0, FCN_E_UNSUPPORTED,
+                "maxpool_lrn5_conv1x1_f16: 3 x 3 / stride 2 windows without padding, 64 -> 64 channels only (run the three layers separately)");
+    FCN_REQUIRE(2 * (OH - 1) < H && 2 * (OW - 1) < W, FCN_E_ARG, "maxpool_lrn5_conv1x1_f16: OH/OW too large");
+    FCN_REQUIRE(x_cstride >= C && x_cstride % 8 == 0 && y_cstride >= y_coffset + Cout && y_cstride % 4 == 0 && y_coffset % 4 == 0 && aligned16(x) &&
+                aligned16(w) && ((uintptr_t)y & 7) == 0 && (!bias || aligned16(bias)), FCN_E_ALIGN, "maxpool_lrn5_conv1x1_f16: channel groups / alignment");
+    FCN_REQUIRE(cdiv(OH, 4) <= 65535 && N <= 65535, FCN_E_UNSUPPORTED, "maxpool_lrn5_conv1x1_f16: grid too large");
+    const dim3 grid(cdiv(OW, 16), cdiv(OH, 4), N);
+    const unsigned lds_bytes = (9 * 33 * 8 + 63) / 64 * 1024 + 64 * 128 + 64 * 144;      // staged patch + pooled tile + normalised tile
+    const _Float16* xh = reinterpret_cast<const _Float16*>(x);
+    const _Float16* wh = reinterpret_cast<const _Float16*>(w);
+    _Float16* yh = reinterpret_cast<_Float16*>(y);
+    if (beta == 0.75f)
+        hipLaunchKernelGGL((pool_lrn5_conv1x1_f16_lds_kernel<true>), grid, dim3(512), lds_bytes, as_stream(s), xh, wh, bias, yh, H, W, x_cstride, OH, OW, y_cstride,
+                           y_coffset, relu, alpha / 5.f, beta, lrn_k);
+    else
+        hipLaunchKernelGGL((pool_lrn5_conv1x1_f16_lds_kernel<false>), grid, dim3(512), lds_bytes, as_stream(s), xh, wh, bias, yh, H, W, x_cstride, OH, OW, y_cstride,
+                           y_coffset, relu, alpha / 5.f, beta, lrn_k);
+    FCN_LAUNCH_CHECK("maxpool_lrn5_conv1x1_f16");
     return 0;
 }
 

@@ -703,7 +703,7 @@ class Engine:
         """MAX pooling -> LRN -> 1x1 convolution (+ in-place ReLU) as one launch (fcn_maxpool_lrn5_conv1x1_fwd_f32: deploy.prototxt's
         pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce): as a launch of its own that convolution is two chunks of K behind a whole
         launch's fixed cost.  The FLOPs of the convolution are booked on this op (kind "pool_lrn_conv")."""
-        if os.environ.get("FCN_FUSE_POOL_LRN_CONV", "1") == "0" or la.type != "Pooling" or self.f16:
+        if os.environ.get("FCN_FUSE_POOL_LRN_CONV", "1") == "0" or la.type != "Pooling":
             return None
         B, lib = self.blobs, L.load()
         lc, d = ct["layer"], ct["desc"]
@@ -714,18 +714,24 @@ class Engine:
         xb, nb = B[la.bottoms[0]], B[mid]
         k, s, pad = kernel_stride_pad(la.sub("pooling_param"))
         lp = lb.sub("lrn_param")
-        if (d.kh, d.kw, d.stride, d.pad) != (1, 1, 1, 0) or d.Cin != 64 or d.Cout != 64 or xb.channels != 64 or k != 3 or xb.esize != 4 \
-                or (d.flags & ~L.CONV_RELU) or d.in_shift != 0.0 or nb.coffset or d.y_cstride % 4 or d.y_coffset % 4:
+        esz = xb.esize
+        want = (L.CONV_F16 if esz == 2 else 0)
+        if (d.kh, d.kw, d.stride, d.pad) != (1, 1, 1, 0) or d.Cin != 64 or d.Cout != 64 or xb.channels != 64 or k != 3 or nb.esize != esz \
+                or (d.flags & ~L.CONV_RELU) != want or d.in_shift != 0.0 or nb.coffset or d.y_cstride % 4 or d.y_coffset % 4 or B[lc.tops[0]].esize != esz:
             return None
         n, c, h, w = xb.shape
         oh, ow = d.OH, d.OW
         if (oh + 3) // 4 > 65535 or n > 65535:
             return None
+        # halves: the LDS-patch form only (3 x 3 / stride 2 / unpadded), and only where that form is the one the two-layer launch takes (large blobs)
+        if esz == 2 and ((s, pad) != (2, 0) or n * c * h * w < 1 << 22):
+            return None
         al, be, kk = float(lp.get("alpha", 1.0)), float(lp.get("beta", 0.75)), float(lp.get("k", 1.0))
         relu = 1 if d.flags & L.CONV_RELU else 0
-        return Op("pool_lrn_conv", "%s+%s+%s" % (la.name, lb.name, lc.name), lambda st: L.check(lib.fcn_maxpool_lrn5_conv1x1_fwd_f32(
+        fn = lib.fcn_maxpool_lrn5_conv1x1_fwd_f16 if esz == 2 else lib.fcn_maxpool_lrn5_conv1x1_fwd_f32
+        return Op("pool_lrn_conv", "%s+%s+%s" % (la.name, lb.name, lc.name), lambda st: L.check(fn(
             xb.ptr, n, h, w, c, xb.cstride, k, s, pad, oh, ow, al, be, kk, d.w, d.bias, d.Cout, relu, d.y, d.y_cstride, d.y_coffset, st)),
-            ct["flops"], 4.0 * (xb.pixels * c + n * oh * ow * d.Cout))
+            ct["flops"], float(esz) * (xb.pixels * c + n * oh * ow * d.Cout))
 
     def _pool_lrn_op(self, la: Layer, lb: Layer) -> Optional[Op]:
         B, lib = self.blobs, L.load()

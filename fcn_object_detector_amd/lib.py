@@ -142,6 +142,7 @@ PROTOTYPES = {
     "fcn_maxpool_lrn5_fwd_f32": (_i, [_vp, _vp] + [_i] * 12 + [_f, _f, _f, _vp]),
     "fcn_maxpool_lrn5_fwd_f16": (_i, [_vp, _vp] + [_i] * 12 + [_f, _f, _f, _vp]),
     "fcn_maxpool_lrn5_conv1x1_fwd_f32": (_i, [_vp] + [_i] * 10 + [_f, _f, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
+    "fcn_maxpool_lrn5_conv1x1_fwd_f16": (_i, [_vp] + [_i] * 10 + [_f, _f, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp]),
     "fcn_relu_fwd_f32": (_i, [_vp, _vp, _sz, _f, _vp]),
     "fcn_sigmoid_fwd_f32": (_i, [_vp, _vp, _sz, _vp]),
     "fcn_power_fwd_f32": (_i, [_vp, _vp, _sz, _f, _f, _f, _vp]),

@@ -217,6 +217,12 @@ int  fcn_maxpool_lrn5_fwd_f32(const float* x, float* y, int N, int H, int W, int
 int  fcn_maxpool_lrn5_conv1x1_fwd_f32(const float* x, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
                                       int OH, int OW, float alpha, float beta, float lrn_k, const float* w, const float* bias,
                                       int Cout, int relu, float* y, int y_cstride, int y_coffset, fcn_stream_t s);
+/* the half twin (x, w, y hold halves, bias float32; 3 x 3 / stride 2 / unpadded windows only): the LDS-patch form of
+ * fcn_maxpool_lrn5_fwd_f16 whose last step multiplies the normalised tile by the filter bank (v_mfma_f32_16x16x16_f16, f32 accumulate,
+ * one rounding after bias and ReLU) */
+int  fcn_maxpool_lrn5_conv1x1_fwd_f16(const void* x, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
+                                      int OH, int OW, float alpha, float beta, float lrn_k, const void* w, const float* bias,
+                                      int Cout, int relu, void* y, int y_cstride, int y_coffset, fcn_stream_t s);
 int  fcn_relu_fwd_f32(const float* x, float* y, size_t count, float negative_slope, fcn_stream_t s);
 int  fcn_sigmoid_fwd_f32(const float* x, float* y, size_t count, fcn_stream_t s);
 int  fcn_power_fwd_f32(const float* x, float* y, size_t count, float power, float scale, float shift, fcn_stream_t s);

@@ -505,3 +505,40 @@ def test_f16_pool_lrn_lds_patch_kernel(gpu, lrn_first, n, h, w, c):
     x32 = x.astype(np.float32).transpose(0, 3, 1, 2)
     ref = R.max_pool(R.lrn_across(x32, 5, 1e-4, 0.75, 1.0), 3, 2, 0) if lrn_first else R.lrn_across(R.max_pool(x32, 3, 2, 0), 5, 1e-4, 0.75, 1.0)
     assert rel_err(a.astype(np.float32).transpose(0, 3, 1, 2), ref) < 1e-3
+
+
+@pytest.mark.parametrize("n,h,w,relu,ycs,yco", [(8, 224, 224, 1, 64, 0), (3, 57, 61, 1, 64, 0), (2, 45, 52, 0, 96, 32)])
+def test_f16_pool_lrn_conv1x1_single_pass(gpu, n, h, w, relu, ycs, yco):
+    """fcn_maxpool_lrn5_conv1x1_fwd_f16 (pool1/3x3_s2 -> pool1/norm1 -> conv2/3x3_reduce + ReLU at batch 32 as one launch): against
+    the library's own pool + LRN launch (whose halves are the convolution's exact inputs) followed by an f32 matrix product of the same
+    halves - only the summation order and the one final rounding differ - and against the oracle's three layers."""
+    rng = np.random.default_rng(n * h + w)
+    c = co = 64
+    x = np.maximum(rng.standard_normal((n, h, w, c)) * 30, 0).astype(np.float16)
+    wt = (rng.standard_normal((co, c)) * 0.1).astype(np.float16)
+    b = rng.standard_normal(co).astype(np.float32)
+    oh, ow = R.pool_out(h, 3, 0, 2), R.pool_out(w, 3, 0, 2)
+    xd, wd, bd = dev_from(x), dev_from(wt), dev_from(b)
+    yd = dev_from(np.full((n, oh, ow, ycs), 7.0, np.float16))
+    L.call("fcn_maxpool_lrn5_conv1x1_fwd_f16", xd.ptr, n, h, w, c, c, 3, 2, 0, oh, ow, 1e-4, 0.75, 1.0, wd.ptr, bd.ptr, co, relu, yd.ptr, ycs, yco, None)
+    full = dev_to(yd, (n, oh, ow, ycs), np.float16)
+    y = full[..., yco:yco + co].astype(np.float32)
+    md = dev_from(np.zeros((n, oh, ow, c), np.float16))
+    L.call("fcn_maxpool_lrn5_fwd_f16", xd.ptr, md.ptr, n, h, w, c, c, 3, 2, 0, oh, ow, c, 0, 1e-4, 0.75, 1.0, None)
+    mid = dev_to(md, (n, oh, ow, c), np.float16).astype(np.float32)
+    two = mid.reshape(-1, c) @ wt.astype(np.float32).T + b
+    if relu:
+        two = np.maximum(two, 0)
+    two = two.reshape(n, oh, ow, co)
+    # one rounding to half of a float32 sum: half an f16 ulp (2^-11) of the value + the summation order
+    assert np.all(np.abs(y - two) <= 6e-4 * np.abs(two) + 1e-3 * np.sqrt(np.mean(two * two)))
+    keep = np.ones(ycs, bool)
+    keep[yco:yco + co] = False
+    assert np.all(full[..., keep] == np.float16(7.0))
+    x32 = x.astype(np.float32).transpose(0, 3, 1, 2)
+    ref = R.conv2d(R.lrn_across(R.max_pool(x32, 3, 2, 0), 5, 1e-4, 0.75, 1.0), wt.astype(np.float32).reshape(co, c, 1, 1), b, 0, 1)
+    if relu:
+        ref = np.maximum(ref, 0)
+    assert rel_err(y.transpose(0, 3, 1, 2), ref) < 2e-3      # (the normalised halves carry half an ulp each into a 64-term sum)
+    with pytest.raises(L.FcnError):
+        L.call("fcn_maxpool_lrn5_conv1x1_fwd_f16", xd.ptr, n, h, w, c, c, 3, 1, 1, oh, ow, 1e-4, 0.75, 1.0, wd.ptr, bd.ptr, co, relu, yd.ptr, ycs, yco, None)
