@@ -370,6 +370,74 @@ __global__ __launch_bounds__(256) void pool3_lrn5_conv1x1_kernel(const float* __
     }
 }
 
+// conv2/norm2 -> pool2/3x3_s2 of models/deploy.prototxt:137-158 (float32 inference, batch 1) through an LDS patch: the single pass above
+// normalises every input pixel once per WINDOW it lies in (2.25 times on average, each time from three 16-byte loads) - 8.2 us for a
+// 9.6 MB blob, 10.2 in the kernel trace.  Here a workgroup owns TH x 8 output pixels x ALL channels: the (2 TH + 1) x 17 input pixels
+// under them go to LDS once by LDS-DMA (pixels outside the image - ceil-mode windows that hang over the edge - are replaced by the
+// nearest pixel inside: same maximum), the LRN runs once per patch pixel in place (lrn5_apply<true>: the single pass's arithmetic, bit
+// for bit), and the windows are pooled from LDS.  3 x 3 / stride 2 windows without padding; the patch must fit 64 KiB.
+__global__ __launch_bounds__(512) void lrn5_pool3s2_lds_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int x_cstride, int OH,
+                                                             int OW, int y_cstride, int TH, float alpha_over_n, float beta, float kk) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef const void __attribute__((address_space(1))) * gptr;
+    typedef void __attribute__((address_space(3))) * lptr;
+    constexpr int TW = 8, PWp = 2 * TW + 1, NT = 512, MAXI = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int segs = C / 4, pitch = C * 4;
+    const int oy0 = (int)blockIdx.y * TH, ox0 = (int)blockIdx.x * TW, n = (int)blockIdx.z;
+    const int PH = 2 * TH + 1, npix = PH * PWp, nitems = npix * segs;
+    const float* xn = x + (size_t)n * H * W * x_cstride;
+    for (int i = wave; i * 64 < nitems; i += NT / 64) {
+        int g = i * 64 + lane;
+        g = g < nitems ? g : nitems - 1;
+        const int p = g / segs, sg = g - p * segs;
+        const int pr = p / PWp, pc = p - pr * PWp;
+        int iy = 2 * oy0 + pr, ix = 2 * ox0 + pc;
+        iy = iy >= H ? H - 1 : iy;
+        ix = ix >= W ? W - 1 : ix;
+        __builtin_amdgcn_global_load_lds((gptr)(xn + ((size_t)iy * W + ix) * x_cstride + sg * 4), (lptr)(lds + i * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 res[MAXI];      // normalise in place: all results first (they read their neighbours' raw values), then all writes
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int g = tid + NT * j;
+        if (g < nitems) {
+            const int sg = g % segs;
+            const char* at = lds + (size_t)g * 16;
+            const float4 c = *reinterpret_cast<const float4*>(at);
+            const float4 l = sg > 0 ? *reinterpret_cast<const float4*>(at - 16) : zero;
+            const float4 r = sg + 1 < segs ? *reinterpret_cast<const float4*>(at + 16) : zero;
+            float4 sc;
+            res[j] = lrn5_apply<true>(l, c, r, alpha_over_n, beta, kk, sc);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int g = tid + NT * j;
+        if (g < nitems) *reinterpret_cast<float4*>(lds + (size_t)g * 16) = res[j];
+    }
+    __syncthreads();
+    const int nout = TH * TW * segs;
+    for (int g = tid; g < nout; g += NT) {
+        const int op = g / segs, sg = g - op * segs;
+        const int oyl = op / TW, oxl = op - oyl * TW;
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
+        if (oy >= OH || ox >= OW) continue;
+        const char* w0 = lds + (size_t)((2 * oyl) * PWp + 2 * oxl) * pitch + sg * 16;
+        float4 m = *reinterpret_cast<const float4*>(w0);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                if (dy || dx) m = max4(m, *reinterpret_cast<const float4*>(w0 + (size_t)(dy * PWp + dx) * pitch));
+        st4(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + sg * 4, m);
+    }
+}
+
 // generic window (any odd/even local_size, any C)
 __global__ __launch_bounds__(256) void lrn_generic_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ scale,
                                                           long long pixels, int C, int x_cstride, int y_cstride, int local_size,
@@ -1110,6 +1178,23 @@ int fcn_maxpool_lrn5_fwd_f32(const float* x, float* y, int N, int H, int W, int 
     FCN_REQUIRE(gx < (1ll << 31) && cdiv(OH, 8) <= 65535 && N <= 65535, FCN_E_UNSUPPORTED, "maxpool_lrn5: grid too large");
     const dim3 grid((unsigned)gx, cdiv(OH, 8), N);
     const float aon = alpha / 5.f;
+    if (lrn_first && k == 3 && stride == 2 && pad == 0) {      // the LDS-patch form where a patch of at least two output rows fits 64 KiB
+        static const bool lds_ok = !(getenv("FCN_POOL_LDS") && atoi(getenv("FCN_POOL_LDS")) == 0);
+        static const int th_env = getenv("FCN_LP_TH") ? atoi(getenv("FCN_LP_TH")) : 0;
+        // (a workgroup stages, normalises and pools one step after the other: what hides the waits is the workgroups beside it - patches of at
+        //  most 40 KiB leave room for three or four per CU.  192 channels: one output row per workgroup 7.4 us, two rows (64 KiB, one workgroup
+        //  per CU) 7.8, the single pass without LDS 8.3)
+        int TH = th_env >= 1 && th_env <= 4 ? th_env : 4;
+        while (TH > 1 && (long long)(2 * TH + 1) * 17 * C * 4 > (th_env ? 64 : 40) * 1024) TH >>= 1;
+        const long long patch = (long long)(2 * TH + 1) * 17 * C * 4, items = patch / 16;
+        if (lds_ok && TH >= 1 && patch <= 64 * 1024 && items <= 8 * 512 && cdiv(OH, TH) <= 65535 && (long long)H * W * C >= (1 << 18)) {
+            const unsigned lds_bytes = (unsigned)((items + 63) / 64 * 1024);
+            hipLaunchKernelGGL(lrn5_pool3s2_lds_kernel, dim3(cdiv(OW, 8), cdiv(OH, TH), N), dim3(512), lds_bytes, as_stream(s), x, y, H, W, C, x_cstride, OH, OW,
+                               y_cstride, TH, aon, beta, lrn_k);
+            FCN_LAUNCH_CHECK("lrn5_pool3s2_lds");
+            return 0;
+        }
+    }
     if (lrn_first)
         hipLaunchKernelGGL(maxpool_lrn5_kernel<true>, grid, dim3(512), 0, as_stream(s), x, y, H, W, C, x_cstride, k, stride, pad, OH, OW, y_cstride,
                            cgroups, aon, beta, lrn_k);

@@ -369,7 +369,8 @@ def test_lane_split_1x1_kernel_matches_oracle(gpu, n, h, w, cin, couts):
 
 @pytest.mark.parametrize("lrn_first", [0, 1])
 @pytest.mark.parametrize("k,s,p,h,w,c,cs", [(3, 2, 0, 28, 28, 64, 64), (3, 2, 0, 15, 21, 8, 12), (3, 1, 1, 9, 7, 12, 12), (3, 2, 1, 10, 11, 40, 40),
-                                            (3, 2, 0, 17, 9, 192, 192)])
+                                            (3, 2, 0, 17, 9, 192, 192),
+                                            (3, 2, 0, 112, 112, 192, 192), (3, 2, 0, 57, 61, 96, 96), (3, 2, 0, 64, 70, 64, 80)])      # (LRN first: the LDS-patch form)
 def test_maxpool_lrn_single_pass_matches_oracle(gpu, lrn_first, k, s, p, h, w, c, cs):
     """fcn_maxpool_lrn5_fwd_f32 (pool1 -> norm1 and norm2 -> pool2 of deploy.prototxt as one launch) against the oracle's
     two layers, and against the library's own two launches (bit for bit when the pooling comes first)."""
