@@ -1178,8 +1178,12 @@ int fcn_maxpool_lrn5_fwd_f32(const float* x, float* y, int N, int H, int W, int 
     FCN_REQUIRE(gx < (1ll << 31) && cdiv(OH, 8) <= 65535 && N <= 65535, FCN_E_UNSUPPORTED, "maxpool_lrn5: grid too large");
     const dim3 grid((unsigned)gx, cdiv(OH, 8), N);
     const float aon = alpha / 5.f;
-    if (lrn_first && k == 3 && stride == 2 && pad == 0) {      // the LDS-patch form where a patch of at least two output rows fits 64 KiB
-        static const bool lds_ok = !(getenv("FCN_POOL_LDS") && atoi(getenv("FCN_POOL_LDS")) == 0);
+    if (lrn_first && k == 3 && stride == 2 && pad == 0) {
+        // The LDS-patch form: OPT-IN ($FCN_LRN_POOL_LDS=1).  Repeated back to back it is faster than the single pass below (7.4 against 8.3 us
+        // for conv2/norm2 -> pool2 at batch 1), but inside a forward pass - inputs cold, rocprofv3's kernel trace - it is SLOWER (11.2 against
+        // 10.2 us): its workgroups stage, wait, normalise and pool one step after the other, the single pass has every load in flight at once.
+        const char* lds_env = getenv("FCN_LRN_POOL_LDS");      // (read per call: the tests run both forms in one process)
+        const bool lds_ok = lds_env && atoi(lds_env) == 1;
         static const int th_env = getenv("FCN_LP_TH") ? atoi(getenv("FCN_LP_TH")) : 0;
         // (a workgroup stages, normalises and pools one step after the other: what hides the waits is the workgroups beside it - patches of at
         //  most 40 KiB leave room for three or four per CU.  192 channels: one output row per workgroup 7.4 us, two rows (64 KiB, one workgroup

@@ -371,8 +371,9 @@ def test_lane_split_1x1_kernel_matches_oracle(gpu, n, h, w, cin, couts):
 @pytest.mark.parametrize("k,s,p,h,w,c,cs", [(3, 2, 0, 28, 28, 64, 64), (3, 2, 0, 15, 21, 8, 12), (3, 1, 1, 9, 7, 12, 12), (3, 2, 1, 10, 11, 40, 40),
                                             (3, 2, 0, 17, 9, 192, 192),
                                             (3, 2, 0, 112, 112, 192, 192), (3, 2, 0, 57, 61, 96, 96), (3, 2, 0, 64, 70, 64, 80)])      # (LRN first: the LDS-patch form)
-def test_maxpool_lrn_single_pass_matches_oracle(gpu, lrn_first, k, s, p, h, w, c, cs):
-    """fcn_maxpool_lrn5_fwd_f32 (pool1 -> norm1 and norm2 -> pool2 of deploy.prototxt as one launch) against the oracle's
+def test_maxpool_lrn_single_pass_matches_oracle(gpu, monkeypatch, lrn_first, k, s, p, h, w, c, cs):
+    """(the large LRN-first shapes run twice: the default single pass and the opt-in LDS-patch form, FCN_LRN_POOL_LDS=1 - same bits)
+    fcn_maxpool_lrn5_fwd_f32 (pool1 -> norm1 and norm2 -> pool2 of deploy.prototxt as one launch) against the oracle's
     two layers, and against the library's own two launches (bit for bit when the pooling comes first)."""
     rng = np.random.default_rng(13)
     x = (rng.standard_normal((2, c, h, w)) * 30).astype(np.float32)
@@ -381,6 +382,12 @@ def test_maxpool_lrn_single_pass_matches_oracle(gpu, lrn_first, k, s, p, h, w, c
     yd = dev_from(np.zeros((2, oh, ow, cs), np.float32))
     L.call("fcn_maxpool_lrn5_fwd_f32", xd.ptr, yd.ptr, 2, h, w, c, cs, k, s, p, oh, ow, cs, lrn_first, 1e-4, 0.75, 1.0, None)
     y = nchw(dev_to(yd, (2, oh, ow, cs)), c)
+    if lrn_first and h * w * c >= 1 << 18:
+        monkeypatch.setenv("FCN_LRN_POOL_LDS", "1")
+        pd = dev_from(np.zeros((2, oh, ow, cs), np.float32))
+        L.call("fcn_maxpool_lrn5_fwd_f32", xd.ptr, pd.ptr, 2, h, w, c, cs, k, s, p, oh, ow, cs, lrn_first, 1e-4, 0.75, 1.0, None)
+        monkeypatch.delenv("FCN_LRN_POOL_LDS")
+        assert np.array_equal(nchw(dev_to(pd, (2, oh, ow, cs)), c), y)
     ref = R.max_pool(R.lrn_across(x, 5, 1e-4, 0.75, 1.0), k, s, p) if lrn_first else R.lrn_across(R.max_pool(x, k, s, p), 5, 1e-4, 0.75, 1.0)
     assert rel_err(y, ref) < 1e-5
     mh, mw = (h, w) if lrn_first else (oh, ow)
