@@ -59,6 +59,13 @@ SHAPES = [
     ("4eB+5aA", [(160, 320, 3, 1, 1, 28, 28), (32, 128, 5, 2, 1, 28, 28), (528, 128, 1, 0, 1, 28, 28),
                  (832, 256, 1, 0, 1, 28, 28), (832, 160, 1, 0, 1, 28, 28), (832, 32, 1, 0, 1, 28, 28)]),
     ("4e_Bfull", [(160, 320, 3, 1, 1, 28, 28), (32, 128, 5, 2, 1, 28, 28), (528, 128, 1, 0, 1, 28, 28)]),
+    # round 4 (half floats, batch 32): what pool_proj costs inside its level, and alone - the budget of a fused pooling + pool_proj kernel
+    ("3a_B_nopp", [(96, 128, 3, 1, 1, 56, 56), (16, 32, 5, 2, 1, 56, 56)]),
+    ("3a_pp", [(192, 32, 1, 0, 1, 56, 56)]),
+    ("4a_B_nopp", [(96, 208, 3, 1, 1, 28, 28), (16, 48, 5, 2, 1, 28, 28)]),
+    ("4a_pp", [(480, 64, 1, 0, 1, 28, 28)]),
+    ("5b_B_nopp", [(192, 384, 3, 1, 1, 28, 28), (48, 128, 5, 2, 1, 28, 28)]),
+    ("5b_pp", [(832, 128, 1, 0, 1, 28, 28)]),
 ]
 
 
