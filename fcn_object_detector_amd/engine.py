@@ -653,8 +653,7 @@ class Engine:
         for lv in set(producers.values()):      # each producing level is ONE launch
             if sum(1 for i in conv_idx if levels[i] == lv) > 8:
                 return None
-        if any(hit(t["reads"], xr) for i, t in enumerate(tasks) if i not in heads and levels[i] <= lh and id(t) not in producers and levels[i] > min(producers.values())):
-            pass      # (other readers of the blob see it complete: the tail changes nothing for them)
+        # (other readers of the blob - none in the reference's nets - still see it complete: every producer stores its own output as before)
         lib = L.load()
         desc = L.ConvTail()
         desc.n = len(heads)
