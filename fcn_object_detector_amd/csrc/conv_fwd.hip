@@ -1099,7 +1099,11 @@ __device__ __forceinline__ void conv_body(const ConvP& p, int tile, float* smem,
 
 __device__ __forceinline__ const GroupArgs& group_of(const GroupArgs& a) { return a; }
 __device__ __forceinline__ const GroupArgs& group_of(const GroupArgsTail& a) { return a.g; }
+#ifdef FCN_EXP_TAIL_NOLDS      // (elimination build, timing only with FCN_TAIL_DEBUG=7: the tail variant without its extra LDS)
+constexpr int kTailLdsFloats = 0;
+#else
 constexpr int kTailLdsFloats = kTailRows * 32 + 4;      // the narrow problems' filters over a tile's 32 channels + the arrival flag
+#endif
 
 template <typename T, int WTM, int WTN, int WAVES_M, int WAVES_N, int WAVES_K, int BK, int NBUF, bool PF, bool TAIL = false>
 __global__ __launch_bounds__((Cfg<WTM, WTN, WAVES_M, WAVES_N, WAVES_K, BK, NBUF, PF>::NT)) void conv_fwd_group(const int nprob, const int te0, const int te1, const int te2,
