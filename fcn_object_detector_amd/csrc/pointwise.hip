@@ -127,6 +127,33 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
         if (VEC4) {
             float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
             int4 mi = make_int4(-1, -1, -1, -1);
+            if (k == 3) {
+                // 3 x 3 windows (every pooling of the reference's nets): all nine loads in flight before the first compare - the loop below
+                // waits for each load in turn, nine dependent round trips (pool3/3x3_s2 at batch 1: 5.8 us in the kernel trace for 6 MB).  Taps
+                // outside the image load the nearest pixel inside and are skipped by the compares: same maximum, same first-maximum index.
+                const int y0 = oy * stride - pad, x0 = ox * stride - pad;
+                float4 v[9];
+                int id[9];
+                bool in[9];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int iy = min(max(y0 + r, 0), H - 1);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int ix = min(max(x0 + c, 0), W - 1);
+                        in[3 * r + c] = (unsigned)(y0 + r) < (unsigned)H && (unsigned)(x0 + c) < (unsigned)W;
+                        id[3 * r + c] = iy * W + ix;
+                        v[3 * r + c] = ld4(xb + (size_t)id[3 * r + c] * x_cstride);
+                    }
+                }
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    if (in[t9] & (v[t9].x > m.x)) { m.x = v[t9].x; mi.x = id[t9]; }
+                    if (in[t9] & (v[t9].y > m.y)) { m.y = v[t9].y; mi.y = id[t9]; }
+                    if (in[t9] & (v[t9].z > m.z)) { m.z = v[t9].z; mi.z = id[t9]; }
+                    if (in[t9] & (v[t9].w > m.w)) { m.w = v[t9].w; mi.w = id[t9]; }
+                }
+            } else
             for (int iy = hs; iy < he; ++iy)
                 for (int ix = ws; ix < we; ++ix) {
                     const float4 v = ld4(xb + ((size_t)iy * W + ix) * x_cstride);
@@ -291,7 +318,7 @@ __global__ __launch_bounds__(512) void maxpool_lrn5_kernel(const float* __restri
 //   1. lane (pixel p = tid / 8, q = tid % 8) takes the maximum of channels 8q .. 8q+7 over its window - all 18 loads in flight, taps
 //      outside the image re-read the nearest tap inside (the maximum does not change);
 //   2. LRN: the two channels either side of the lane's eight come from lanes q - 1 / q + 1 (same pixel, same wave) by a lane exchange;
-//      the arithmetic is lrn5_apply's, i.e. the stand-alone kernels' bit for bit;
+//      lrn5_apply<true>: the hardware rsq / sqrt (1 ulp), as in the LRN-first single pass;
 //   3. the 32 x 64 normalised tile goes to LDS (pitch 68 floats), and wave w computes output channels 16w .. 16w+15 of the 32 pixels with
 //      v_mfma_f32_16x16x4_f32 as out^T = W . act^T: A = 16 filters x 4 k-values (lane (i, h): filter 16w + i, k = 16h + s in step s -
 //      any bijection of k serves a sum, this one makes a lane's filter values ONE 64-byte run, loaded at the top of the kernel),
@@ -341,8 +368,10 @@ __global__ __launch_bounds__(256) void pool3_lrn5_conv1x1_kernel(const float* __
     if (q == 0) lft = zero;
     if (q == 7) rgt = zero;
     float4 s;
-    const float4 a0 = lrn5_apply(lft, m0, m1, alpha_over_n, beta, kk, s);
-    const float4 a1 = lrn5_apply(m0, m1, rgt, alpha_over_n, beta, kk, s);
+    // (the hardware reciprocal square root / square root, 1 ulp each - what the LRN-first single pass uses - instead of the IEEE sequences: eight
+    //  elements per lane at ~100 instructions each were 2 us of this kernel)
+    const float4 a0 = lrn5_apply<true>(lft, m0, m1, alpha_over_n, beta, kk, s);
+    const float4 a1 = lrn5_apply<true>(m0, m1, rgt, alpha_over_n, beta, kk, s);
     st4(act + p * kPLC_Pitch + 8 * q, a0);
     st4(act + p * kPLC_Pitch + 8 * q + 4, a1);
     __syncthreads();

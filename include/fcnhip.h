@@ -212,8 +212,9 @@ int  fcn_maxpool_lrn5_fwd_f32(const float* x, float* y, int N, int H, int W, int
 /* pool -> LRN -> 1x1 convolution (+ bias, optional ReLU) in ONE launch: deploy.prototxt pool1/3x3_s2 -> pool1/norm1 ->
  * conv2/3x3_reduce (:54-104).  y[pixel][y_coffset + co] = act(bias[co] + sum_c w[co][c] * LRN(maxpool(x))[pixel][c]); w is
  * [Cout][C] row-major.  Neither the pooled nor the normalised blob is written.  3 x 3 windows and 64 -> 64 channels only
- * (FCN_E_UNSUPPORTED otherwise: fcn_maxpool_lrn5_fwd_f32 + fcn_conv2d_fwd_f32).  Pooling and LRN are bit-identical to
- * fcn_maxpool_lrn5_fwd_f32(lrn_first = 0); the convolution sums K on the matrix cores in its own order (float32). */
+ * (FCN_E_UNSUPPORTED otherwise: fcn_maxpool_lrn5_fwd_f32 + fcn_conv2d_fwd_f32).  The pooling is exact; the LRN takes s^-0.75 from the
+ * hardware reciprocal square root / square root (1 ulp each: within 1e-6 of fcn_maxpool_lrn5_fwd_f32(lrn_first = 0)); the convolution
+ * sums K on the matrix cores in its own order (float32). */
 int  fcn_maxpool_lrn5_conv1x1_fwd_f32(const float* x, int N, int H, int W, int C, int x_cstride, int k, int stride, int pad,
                                       int OH, int OW, float alpha, float beta, float lrn_k, const float* w, const float* bias,
                                       int Cout, int relu, float* y, int y_cstride, int y_coffset, fcn_stream_t s);

@@ -436,7 +436,7 @@ def test_pool_lrn_conv1x1_single_pass_matches_oracle(gpu, s, p, h, w, relu, bias
     keep = np.ones(ycs, bool)
     keep[yco:yco + co] = False
     assert np.all(full[..., keep] == 7.0)
-    # the library's own two launches: pool + LRN (bit-identical inside the single pass), then the tiled convolution
+    # the library's own two launches: pool + LRN (IEEE square roots there, the hardware ones inside the single pass), then the tiled convolution
     md = dev_from(np.zeros((n, oh, ow, c), np.float32))
     L.call("fcn_maxpool_lrn5_fwd_f32", xd.ptr, md.ptr, n, h, w, c, c, k, s, p, oh, ow, c, 0, 1e-4, 0.75, 1.0, None)
     two, _ = run_conv(nchw(dev_to(md, (n, oh, ow, c)), c), wt, b, 0, 1, flags=L.CONV_RELU if relu else 0)
