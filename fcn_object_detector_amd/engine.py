@@ -866,6 +866,7 @@ class Engine:
             self._tune_events = (e0, e1)
         e0, e1 = self._tune_events
         best, best_ms = -1, 1e30
+        timed: List[Tuple[float, int]] = []
         grp = L.ConvGroup()
         first_layer = int(lib.fcn_conv2d_first_layer_config())
         # Cold timing (round 4, $FCN_TUNE_COLD=0 for the old way): inside a forward pass a launch finds its filters in HBM / the Infinity
@@ -875,6 +876,8 @@ class Engine:
         # preceded by a pass over a 64 MB scratch buffer that evicts the L2s; the event pair's own cost is the same for every
         # configuration and leaves the ranking alone.
         cold = self.spec.phase == "TEST" and os.environ.get("FCN_TUNE_COLD", "1") != "0"
+        # (tried, round 4: the plan's previous launch between the eviction and the timed launch, so that the inputs sit where a forward leaves
+        #  them - the chosen plans ran the frame in the same 0.2736 - 0.2743 ms)
         if cold and not hasattr(self, "_tune_flush"):
             self._tune_flush = DeviceBuffer(64 << 20, zero=False)
         for cfg in range(int(lib.fcn_conv2d_num_configs())):
@@ -912,7 +915,7 @@ class Engine:
             elif cold:
                 L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))      # (code object, kernel arguments)
                 samples = []
-                for _ in range(5):
+                for _ in range(7):
                     L.call("fcn_memset_async", self._tune_flush.ptr, 0, self._tune_flush.nbytes, self.stream)
                     L.call("fcn_event_record", e0, self.stream)
                     L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))
@@ -920,7 +923,7 @@ class Engine:
                     L.call("fcn_event_sync", e1)
                     L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
                     samples.append(ms.value)
-                t = 6.0 * float(np.median(samples))
+                t = 6.0 * float(np.percentile(samples, 25))      # (disturbances only ever lengthen a launch: the lower quartile, not the median)
             else:
                 for _ in range(2):
                     L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))
@@ -933,6 +936,30 @@ class Engine:
                 t = ms.value
             if t < best_ms:
                 best, best_ms = cfg, t
+            timed.append((t, cfg))
+        if cold and len(timed) > 1:
+            # Second look at the closest contenders (round 4): the first pass's median of five separates configurations that differ by 2 % or
+            # more; two that differ by less are a coin toss there, and the plan of a 20-launch net then moves by half a per cent from run to run.
+            # The four fastest within 5 % are timed again, 31 cold launches each, and the smallest lower quartile wins.
+            finals = []
+            for t1, cfg in sorted(timed)[:4]:
+                if t1 > 1.05 * best_ms:
+                    break
+                if lib.fcn_conv2d_group_prepare_fused(arr, n, parr, npool, ws.ptr, cfg, C.byref(grp)) != 0:
+                    continue
+                samples = []
+                ms = C.c_float()
+                for _ in range(31):
+                    L.call("fcn_memset_async", self._tune_flush.ptr, 0, self._tune_flush.nbytes, self.stream)
+                    L.call("fcn_event_record", e0, self.stream)
+                    L.check(lib.fcn_conv2d_fwd_group_f32(C.byref(grp), self.stream))
+                    L.call("fcn_event_record", e1, self.stream)
+                    L.call("fcn_event_sync", e1)
+                    L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+                    samples.append(ms.value)
+                finals.append((6.0 * float(np.percentile(samples, 25)), cfg))
+            if finals:
+                best_ms, best = min(finals)
         return best, best_ms / 6.0
 
     def _move_floaters(self, tasks: List[dict], levels: List[int], hit) -> None:
@@ -999,7 +1026,7 @@ class Engine:
                         base_ms = ms
                     if best_ms is None or ms < best_ms:
                         best, best_ms = "".join("1" if code >> b & 1 else "0" for b in range(len(fl))), ms
-                if base_ms is not None and best_ms > 0.97 * base_ms:      # (timing noise: a move must be worth 3 % of the pair)
+                if base_ms is not None and best_ms > float(os.environ.get("FCN_MOVE_MARGIN", "0.99")) * base_ms:      # (timing noise: a move must be worth 1 % of the pair - 3 % until the tuner took a second look at close contenders)
                     best = "0" * len(fl)
                 choice = best
                 cache = self._load_tune_cache()

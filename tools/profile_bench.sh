@@ -11,7 +11,21 @@ export FCN_TUNE_CACHE=$OUT/${TAG}_tune.json
 ARGS="--steps 50 --warmup 5 --no-cpu-baseline --no-secondary $*"
 cd "$ROOT"
 python3 bench.py $ARGS > "$OUT/${TAG}_bench_plain.json"            # fills the tune cache: profiled runs replay the plan
-python3 bench.py $ARGS --in-flight 1 --no-train > /dev/null            # ... and the plan of the one-frame-in-flight mode (no LDS cap: its own cache keys)
+# ... and the plan of the one-frame-in-flight mode (no LDS cap: its own cache keys).  The tuner decides by timing and two tunings of the same
+# 20 launches differ by up to 1 % in the frame (round 4: 243.1 .. 246.1 us on one box): the mode is tuned THREE times, each into a cache of its
+# own that starts from the four-in-flight plan, and the plan with the shortest frame (device time of 200 forwards) is the one the profiled passes
+# replay.  All three lines are kept ($OUT/${TAG}_tune1_*.json).
+BASE_CACHE=$FCN_TUNE_CACHE
+best=""; best_ms=""
+for i in 1 2 3; do
+    cp "$BASE_CACHE" "$OUT/${TAG}_tune1_$i.cache.json"
+    FCN_TUNE_CACHE="$OUT/${TAG}_tune1_$i.cache.json" python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline --no-secondary $* --in-flight 1 --no-train --no-io-region > "$OUT/${TAG}_tune1_$i.json"
+    ms=$(python3 -c "import json,sys; print(json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])['single_stream']['device_ms_per_step'])" "$OUT/${TAG}_tune1_$i.json")
+    echo "one-frame-in-flight tuning $i: $ms ms per frame"
+    if [ -z "$best" ] || python3 -c "import sys; sys.exit(0 if float(sys.argv[1]) < float(sys.argv[2]) else 1)" "$ms" "$best_ms"; then best=$i; best_ms=$ms; fi
+done
+echo "kept tuning $best ($best_ms ms)"
+cp "$OUT/${TAG}_tune1_$best.cache.json" "$BASE_CACHE"
 export TMPDIR=/tmp
 # Order (round 3, after the advisor's note): the plain-launch passes FIRST - they have never failed - and every pass guarded, so that a
 # failure of a later pass (the hipGraph replay under the profiler crashed once in round 1) cannot cost the data of
