@@ -551,6 +551,7 @@ class TrainEngine(Engine):
                 op.sel["cfg"] = self._chosen_cfgs[key] = int(cache[key])
                 continue
             best, best_ms = -1, 1e30
+            timed = []
             for cfg in range(ncfg):
                 op.sel["cfg"] = cfg
                 for _ in range(2):
@@ -564,6 +565,26 @@ class TrainEngine(Engine):
                 L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
                 if ms.value < best_ms:
                     best, best_ms = cfg, ms.value
+                timed.append((ms.value, cfg))
+            # a second look at the contenders within 4 % (as Engine._time_conv_cfgs): four more rounds of five launches each, the minimum counts
+            finals = []
+            for t1, cfg in sorted(timed)[:3]:
+                if t1 > 1.04 * best_ms or len(timed) < 2:
+                    break
+                op.sel["cfg"] = cfg
+                rounds = [t1]
+                for _ in range(4):
+                    L.call("fcn_event_record", e0, self.stream)
+                    for _ in range(5):
+                        op.run(self.stream)
+                    L.call("fcn_event_record", e1, self.stream)
+                    L.call("fcn_event_sync", e1)
+                    ms = C.c_float()
+                    L.call("fcn_event_elapsed_ms", e0, e1, C.byref(ms))
+                    rounds.append(ms.value)
+                finals.append((min(rounds), cfg))
+            if finals:
+                best = min(finals)[1]
             op.sel["cfg"] = self._chosen_cfgs[key] = best
             if cache is not None:
                 cache[key] = best
