@@ -393,6 +393,8 @@ __global__ __launch_bounds__(256) void pool3_lrn5_conv1x1_kernel(const float* __
         }
         float4 o = make_float4(acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w);
         if (relu) o = make_float4(fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f));
+        // (16 bytes per lane, 64 contiguous bytes per pixel and wave: taking this 3.2 MB tile through LDS for whole 256-byte rows was tried
+        //  and is slower - 5.6 -> 5.8 us, two more barriers; the half-float twin's 8-byte stores did gain from it)
         const int pp = 16 * t + fi;
         const int py = (int)blockIdx.y * 4 + (pp >> 3), px = (int)blockIdx.x * 8 + (pp & 7);
         if (py < OH && px < OW) st4(y + ((size_t)(n * OH + py) * OW + px) * y_cstride + y_coffset + 16 * wave + 4 * fh, o);
@@ -1016,6 +1018,7 @@ __global__ __launch_bounds__(512) void pool_lrn5_conv1x1_f16_lds_kernel(const _F
     constexpr int staged = (nitems + 63) / 64 * 1024;
     char* const pooled = lds + staged;                             // [64 pixels][128 bytes]
     char* const act = pooled + TH * TW * pitch;                    // [64 pixels][144 bytes]
+    char* const outt = act + TH * TW * apitch;                     // the output tile, same shape
     {
         const int op = tid / segs, sg = tid - op * segs;
         const int oyl = op / TW, oxl = op - oyl * TW;
@@ -1048,7 +1051,6 @@ __global__ __launch_bounds__(512) void pool_lrn5_conv1x1_f16_lds_kernel(const _F
         acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h4_t{wf1[0], wf1[1], wf1[2], wf1[3]}, h4_t{a1[0], a1[1], a1[2], a1[3]}, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x16f16(h4_t{wf1[4], wf1[5], wf1[6], wf1[7]}, h4_t{a1[4], a1[5], a1[6], a1[7]}, acc, 0, 0, 0);
         const int op = 16 * pt + fi;
-        const int oy = oy0 + op / TW, ox = ox0 + op % TW;
         h4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1056,7 +1058,16 @@ __global__ __launch_bounds__(512) void pool_lrn5_conv1x1_f16_lds_kernel(const _F
             if (relu) v = fmaxf(v, 0.f);
             o[e] = (_Float16)v;
         }
-        if (oy < OH && ox < OW) *reinterpret_cast<h4_t*>(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + y_coffset + 16 * ct + 4 * fh) = o;
+        // (through LDS: an 8-byte store per lane would write 32 bytes to each of 16 pixels per instruction - the first-layer kernel's
+        //  experiment with such stores cost it 15 %; the tile leaves as whole 128-byte pixel rows instead)
+        *reinterpret_cast<h4_t*>(outt + (size_t)op * apitch + (16 * ct + 4 * fh) * 2) = o;
+    }
+    __syncthreads();
+    {
+        const int op = tid >> 3, sg = tid & 7;
+        const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+        if (oy < OH && ox < OW)
+            *reinterpret_cast<h8_t*>(y + ((size_t)(n * OH + oy) * OW + ox) * y_cstride + y_coffset + sg * 8) = *reinterpret_cast<const h8_t*>(outt + (size_t)op * apitch + sg * 16);
     }
 }
 
@@ -1406,11 +1417,11 @@ int fcn_maxpool_lrn5_conv1x1_fwd_f16(const void* x, int N, int H, int W, int C, 
     FCN_REQUIRE(C == 64 && Cout == 64 && k == 3 && stride == 2 && pad == 0, FCN_E_UNSUPPORTED,
                 "maxpool_lrn5_conv1x1_f16: 3 x 3 / stride 2 windows without padding, 64 -> 64 channels only (run the three layers separately)");
     FCN_REQUIRE(2 * (OH - 1) < H && 2 * (OW - 1) < W, FCN_E_ARG, "maxpool_lrn5_conv1x1_f16: OH/OW too large");
-    FCN_REQUIRE(x_cstride >= C && x_cstride % 8 == 0 && y_cstride >= y_coffset + Cout && y_cstride % 4 == 0 && y_coffset % 4 == 0 && aligned16(x) &&
-                aligned16(w) && ((uintptr_t)y & 7) == 0 && (!bias || aligned16(bias)), FCN_E_ALIGN, "maxpool_lrn5_conv1x1_f16: channel groups / alignment");
+    FCN_REQUIRE(x_cstride >= C && x_cstride % 8 == 0 && y_cstride >= y_coffset + Cout && y_cstride % 8 == 0 && y_coffset % 8 == 0 && aligned16(x) &&
+                aligned16(w) && aligned16(y) && (!bias || aligned16(bias)), FCN_E_ALIGN, "maxpool_lrn5_conv1x1_f16: channel groups / alignment");
     FCN_REQUIRE(cdiv(OH, 4) <= 65535 && N <= 65535, FCN_E_UNSUPPORTED, "maxpool_lrn5_conv1x1_f16: grid too large");
     const dim3 grid(cdiv(OW, 16), cdiv(OH, 4), N);
-    const unsigned lds_bytes = (9 * 33 * 8 + 63) / 64 * 1024 + 64 * 128 + 64 * 144;      // staged patch + pooled tile + normalised tile
+    const unsigned lds_bytes = (9 * 33 * 8 + 63) / 64 * 1024 + 64 * 128 + 2 * 64 * 144;      // staged patch + pooled tile + normalised tile + output tile (64 KiB)
     const _Float16* xh = reinterpret_cast<const _Float16*>(x);
     const _Float16* wh = reinterpret_cast<const _Float16*>(w);
     _Float16* yh = reinterpret_cast<_Float16*>(y);

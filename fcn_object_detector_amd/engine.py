@@ -716,7 +716,7 @@ class Engine:
         esz = xb.esize
         want = (L.CONV_F16 if esz == 2 else 0)
         if (d.kh, d.kw, d.stride, d.pad) != (1, 1, 1, 0) or d.Cin != 64 or d.Cout != 64 or xb.channels != 64 or k != 3 or nb.esize != esz \
-                or (d.flags & ~L.CONV_RELU) != want or d.in_shift != 0.0 or nb.coffset or d.y_cstride % 4 or d.y_coffset % 4 or B[lc.tops[0]].esize != esz:
+                or (d.flags & ~L.CONV_RELU) != want or d.in_shift != 0.0 or nb.coffset or d.y_cstride % (16 // esz) or d.y_coffset % (16 // esz) or B[lc.tops[0]].esize != esz:
             return None
         n, c, h, w = xb.shape
         oh, ow = d.OH, d.OW
